@@ -1,0 +1,153 @@
+/* smol_hip.h -- C-ABI boundary of the HIP (gfx950 / MI355X) resampling backend.
+ *
+ * Plain C types only: pointers, fixed-width integers and POD structs. This is
+ * what the host-side dispatcher binds. In the reference the same seam is the
+ * row-function table `SmolImplementation' (reference smolscale-private.h:270-278)
+ * filled by _smol_get_generic_implementation() (smolscale-generic.c:2498) and
+ * consumed by do_rows() (smolscale.c:507-546); a GPU wants whole row RANGES, so
+ * the seam here is one call per smol_scale_batch() instead of one per row.
+ * INTEGRATION.md shows the patch a reference maintainer would apply.
+ *
+ * All functions return 0 on success or a negative value (-(hipError_t), or
+ * SMOL_HIP_E_*) on failure; nothing here falls back to a CPU path. */
+
+#ifndef SMOLSCALE_AMD_SMOL_HIP_H
+#define SMOLSCALE_AMD_SMOL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMOL_HIP_E_INVALID      (-10001)   /* bad argument                           */
+#define SMOL_HIP_E_UNSUPPORTED  (-10002)   /* job outside what the kernels implement */
+#define SMOL_HIP_E_NO_DEVICE    (-10003)   /* no usable GPU                          */
+
+/* Filter classes chosen per axis (replaces reference enum SmolFilterType,
+ * smolscale-private.h:100-116; BILINEAR carries its halvings separately and
+ * only 0..2 are reachable, see smol_hip_plan_job()). */
+enum
+{
+    SMOL_HIP_FILTER_COPY = 0,
+    SMOL_HIP_FILTER_ONE = 1,
+    SMOL_HIP_FILTER_BILINEAR = 2,
+    SMOL_HIP_FILTER_BOX = 3
+};
+
+/* Everything the kernels need to know about one scaling job: the result of the
+ * planner (replaces the reference's pick_filter_params() smolscale.c:427-478,
+ * smol_scale_init() :816-870, get_implementations() :725-783 and the precalc
+ * tables of smolscale-generic.c:14-179, which are kept in closed form here:
+ * sample j of a bilinear axis sits at fixed-point position frac0 + j*step
+ * (32.32), box k ends at (k+1)*step (16.16)). */
+typedef struct
+{
+    uint32_t width_in, height_in;
+    uint32_t width_out, height_out;
+    uint8_t  pixel_type_in, pixel_type_out;   /* SmolPixelType                        */
+    uint8_t  filter_h, filter_v;              /* SMOL_HIP_FILTER_*                    */
+    uint8_t  halvings_h, halvings_v;          /* bilinear only, 0..2                  */
+    uint8_t  wide;                            /* 0: 64bpp-class math, 1: 128bpp-class */
+    uint8_t  premul16;                        /* unassociated -> unassociated         */
+    uint8_t  linear;                          /* sRGB-linear internal representation  */
+    uint8_t  quirk24;                         /* 24bpp sRGB output via `123' packer   */
+    uint8_t  reserved [2];
+    uint32_t span_mul_x, span_mul_y;          /* box normalisers                      */
+    uint64_t frac0_x, step_x;                 /* bilinear: 32.32; box: step is 16.16  */
+    uint64_t frac0_y, step_y;
+}
+SmolHipJob;
+
+/* One image of a batched launch (device pointers). Output row `first_row' is
+ * written at dst + 0; src points at input row 0. */
+typedef struct
+{
+    SmolHipJob job;
+    const void *src;
+    void *dst;
+    uint32_t rowstride_in, rowstride_out;     /* bytes, any alignment */
+    uint32_t first_row, n_rows;
+}
+SmolHipImage;
+
+typedef struct SmolHipPlan SmolHipPlan;
+
+/* ---- host-only helpers (no GPU needed) ---------------------------------- */
+
+/* Planner. Fills *job for scaling (type_in, w_in x h_in) -> (type_out, w_out x h_out). */
+int smol_hip_plan_job (uint32_t pixel_type_in, uint32_t width_in, uint32_t height_in,
+                       uint32_t pixel_type_out, uint32_t width_out, uint32_t height_out,
+                       uint32_t with_srgb, SmolHipJob *job);
+
+/* Inclusive range of INPUT rows that output rows [first_row, first_row+n_rows)
+ * depend on -- what a row-range shard has to hold (multi-GPU scatter). */
+int smol_hip_input_row_range (const SmolHipJob *job, uint32_t first_row, uint32_t n_rows,
+                              uint32_t *in_row_first, uint32_t *in_row_last);
+
+/* Closed-form sampling parameters, for checking against the reference's tables:
+ * bilinear sample j -> (source index, weight F in 0..256);
+ * box k -> (first index, last index, F of the right edge, F of the left carry). */
+void smol_hip_bilinear_sample (uint64_t frac0, uint64_t step, uint32_t dim_in, uint32_t j,
+                               uint32_t *ofs, uint32_t *f);
+void smol_hip_box_span (uint64_t step, uint32_t dim_in, uint32_t k,
+                        uint32_t *ofs0, uint32_t *ofs1, uint32_t *f_right, uint32_t *f_prev);
+
+const char *smol_hip_strerror (int err);
+
+/* ---- device side --------------------------------------------------------- */
+
+int smol_hip_device_count (void);
+
+/* A plan binds a job to one device and owns streams + staging buffers. */
+int smol_hip_plan_create (const SmolHipJob *job, int device, SmolHipPlan **plan_out);
+void smol_hip_plan_destroy (SmolHipPlan *plan);
+
+/* Host-pointer entry (what smol_scale_batch() calls): copies the needed input
+ * rows to the device, runs the kernels, copies rows [first_row, first_row+n_rows)
+ * back to dest_host (row first_row at offset 0, rowstride_out apart; bytes
+ * between rows are left untouched). Thread-safe on one plan. Synchronous. */
+int smol_hip_scale_rows_host (SmolHipPlan *plan,
+                              const void *pixels_in_host, uint32_t rowstride_in,
+                              void *dest_host, uint32_t rowstride_out,
+                              uint32_t first_row, uint32_t n_rows);
+
+/* Device-pointer entry: input image and output strip already live in device
+ * memory. Asynchronous on `hip_stream' (a hipStream_t, NULL = default stream). */
+int smol_hip_scale_rows_device (SmolHipPlan *plan,
+                                const void *pixels_in_dev, uint32_t rowstride_in,
+                                void *dest_dev, uint32_t rowstride_out,
+                                uint32_t first_row, uint32_t n_rows,
+                                void *hip_stream);
+
+/* Batched entry: n images (each with its own job, pointers and row range) in
+ * as few launches as possible; one launch when all images use the same kernel
+ * class. `images' is a HOST array. Asynchronous on hip_stream. */
+typedef struct SmolHipBatch SmolHipBatch;
+int smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device,
+                           SmolHipBatch **batch_out);
+int smol_hip_batch_launch (SmolHipBatch *batch, void *hip_stream);
+/* Number of kernel launches one smol_hip_batch_launch() issues, and the name of
+ * the dominant kernel (for matching against rocprofv3 --stats). */
+int smol_hip_batch_info (const SmolHipBatch *batch, uint32_t *n_launches, const char **kernel_name);
+void smol_hip_batch_destroy (SmolHipBatch *batch);
+
+/* Timing helper for bench.py: `warmup' untimed then `iters' timed launches of
+ * the batch on a private stream, bracketed by hipEvents recorded on that same
+ * stream. Returns total milliseconds for the timed launches. */
+int smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_total);
+
+/* Device memory helpers so that hosts without a HIP binding (ctypes, cgo...)
+ * can stage buffers. */
+int smol_hip_malloc (int device, uint64_t n_bytes, void **dev_ptr_out);
+int smol_hip_free (int device, void *dev_ptr);
+int smol_hip_memcpy_h2d (int device, void *dst_dev, const void *src_host, uint64_t n_bytes);
+int smol_hip_memcpy_d2h (int device, void *dst_host, const void *src_dev, uint64_t n_bytes);
+int smol_hip_memset (int device, void *dst_dev, int value, uint64_t n_bytes);
+int smol_hip_device_synchronize (int device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SMOLSCALE_AMD_SMOL_HIP_H */

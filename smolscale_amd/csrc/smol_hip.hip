@@ -1,0 +1,501 @@
+/* smol_hip.hip -- C-ABI shim + host runtime of the HIP backend (gfx950).
+ *
+ * Exports exactly the functions declared in include/smol_hip.h. Host logic:
+ * turning a planner job into a device job descriptor, choosing a kernel class,
+ * staging rows between host and device for the host-pointer entry, batching.
+ * No CPU compute path exists here: if HIP fails, the error is returned (and the
+ * public API in smolscale_api.c aborts, like the reference does on its internal
+ * errors, reference smolscale.c:779-780). */
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "smol_hip.h"
+#include "smol_kernels.hip.h"
+
+using smolhip::JobDev;
+using namespace smolhip::dispatch;
+
+#define HIP_TRY(expr)                                           \
+    do {                                                        \
+        hipError_t e_ = (expr);                                 \
+        if (e_ != hipSuccess)                                   \
+            return -(int) e_;                                   \
+    } while (0)
+
+namespace {
+
+/* A launch either reads descriptors from device memory (jobs_dev != NULL, one per
+ * blockIdx.y) or takes the single descriptor `rep' by value as kernel argument. */
+template <int HX, int HY>
+void
+launch_pow2_one (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (256), 0, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (256), 0, s, rep);
+}
+
+template <int HX>
+void
+launch_pow2_hy (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
+{
+    switch (rep.halv_v)
+    {
+        case 0: launch_pow2_one<HX, 0> (jobs_dev, rep, grid, s); break;
+        case 1: launch_pow2_one<HX, 1> (jobs_dev, rep, grid, s); break;
+        default: launch_pow2_one<HX, 2> (jobs_dev, rep, grid, s); break;
+    }
+}
+
+/* Launch one kernel over `n_jobs' jobs that all share class k and (for k_pow2)
+ * the same halvings as `rep'. max_* are maxima over the group. */
+hipError_t
+launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &rep,
+              uint32_t max_w_out, uint32_t max_rows, hipStream_t s)
+{
+    if (k == KC_POW2)
+    {
+        const uint32_t rx = 2u << rep.halv_h;
+        const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
+        const uint32_t tcols = max_w_out / opt;
+        dim3 grid (((tcols + 255) / 256) * max_rows, n_jobs);
+
+        switch (rep.halv_h)
+        {
+            case 0: launch_pow2_hy<0> (jobs_dev, rep, grid, s); break;
+            case 1: launch_pow2_hy<1> (jobs_dev, rep, grid, s); break;
+            default: launch_pow2_hy<2> (jobs_dev, rep, grid, s); break;
+        }
+        return hipGetLastError ();
+    }
+
+    dim3 grid (((max_w_out + smolhip::GENERAL_BLOCK - 1) / smolhip::GENERAL_BLOCK) * max_rows, n_jobs);
+    dim3 block (smolhip::GENERAL_BLOCK);
+
+    if (k == KC_GENERAL_WIDE)
+    {
+        if (jobs_dev)
+            hipLaunchKernelGGL (smolhip::k_general_batch<true>, grid, block, 0, s, jobs_dev);
+        else
+            hipLaunchKernelGGL (smolhip::k_general_one<true>, grid, block, 0, s, rep);
+    }
+    else
+    {
+        if (jobs_dev)
+            hipLaunchKernelGGL (smolhip::k_general_batch<false>, grid, block, 0, s, jobs_dev);
+        else
+            hipLaunchKernelGGL (smolhip::k_general_one<false>, grid, block, 0, s, rep);
+    }
+    return hipGetLastError ();
+}
+
+/* ---- per-device lanes: stream + grow-only staging buffers ---------------- */
+
+struct Lane
+{
+    std::mutex mtx;
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    void *src_buf = nullptr;  size_t src_cap = 0;
+    void *dst_buf = nullptr;  size_t dst_cap = 0;
+};
+
+constexpr int N_LANES = 4;
+constexpr int MAX_DEVICES = 16;
+
+struct DeviceState
+{
+    Lane lanes [N_LANES];
+    std::atomic<unsigned> next { 0 };
+};
+
+DeviceState g_devices [MAX_DEVICES];
+
+int
+lane_prepare (Lane &ln, size_t src_need, size_t dst_need)
+{
+    if (!ln.ready)
+    {
+        HIP_TRY (hipStreamCreateWithFlags (&ln.stream, hipStreamNonBlocking));
+        ln.ready = true;
+    }
+    if (src_need > ln.src_cap)
+    {
+        if (ln.src_buf)
+            HIP_TRY (hipFree (ln.src_buf));
+        ln.src_buf = nullptr; ln.src_cap = 0;
+        HIP_TRY (hipMalloc (&ln.src_buf, src_need));
+        ln.src_cap = src_need;
+    }
+    if (dst_need > ln.dst_cap)
+    {
+        if (ln.dst_buf)
+            HIP_TRY (hipFree (ln.dst_buf));
+        ln.dst_buf = nullptr; ln.dst_cap = 0;
+        HIP_TRY (hipMalloc (&ln.dst_buf, dst_need));
+        ln.dst_cap = dst_need;
+    }
+    return 0;
+}
+
+} /* namespace */
+
+struct SmolHipPlan
+{
+    SmolHipJob job;
+    int device;
+};
+
+struct SmolHipBatch
+{
+    int device = 0;
+    uint32_t n_images = 0;
+    JobDev *jobs_dev = nullptr;            /* all jobs, grouped by launch */
+    struct Group { KClass k; uint32_t first, count; JobDev rep; uint32_t max_w_out, max_rows; };
+    std::vector<Group> groups;
+    uint64_t dominant_units = 0;
+    const char *dominant_name = "";
+};
+
+extern "C" {
+
+int
+smol_hip_device_count (void)
+{
+    int n = 0;
+    if (hipGetDeviceCount (&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int
+smol_hip_plan_create (const SmolHipJob *job, int device, SmolHipPlan **plan_out)
+{
+    if (!job || !plan_out || device < 0 || device >= MAX_DEVICES)
+        return SMOL_HIP_E_INVALID;
+    if (job->pixel_type_in >= 10 || job->pixel_type_out >= 10)
+        return SMOL_HIP_E_INVALID;
+    if (device >= smol_hip_device_count ())
+        return SMOL_HIP_E_NO_DEVICE;
+
+    SmolHipPlan *p = new (std::nothrow) SmolHipPlan;
+    if (!p)
+        return SMOL_HIP_E_INVALID;
+    p->job = *job;
+    p->device = device;
+    *plan_out = p;
+    return 0;
+}
+
+void
+smol_hip_plan_destroy (SmolHipPlan *plan)
+{
+    delete plan;
+}
+
+int
+smol_hip_scale_rows_device (SmolHipPlan *plan,
+                            const void *pixels_in_dev, uint32_t rowstride_in,
+                            void *dest_dev, uint32_t rowstride_out,
+                            uint32_t first_row, uint32_t n_rows,
+                            void *hip_stream)
+{
+    if (!plan || !pixels_in_dev || !dest_dev)
+        return SMOL_HIP_E_INVALID;
+    if (n_rows == 0)
+        return 0;
+    if (first_row + n_rows > plan->job.height_out)
+        return SMOL_HIP_E_INVALID;
+
+    HIP_TRY (hipSetDevice (plan->device));
+
+    JobDev jd;
+    fill_jobdev (jd, plan->job, pixels_in_dev, rowstride_in, dest_dev, rowstride_out, first_row, n_rows);
+    HIP_TRY (launch_class (classify (jd), nullptr, 1, jd, jd.w_out, n_rows,
+                           static_cast<hipStream_t> (hip_stream)));
+    return 0;
+}
+
+int
+smol_hip_scale_rows_host (SmolHipPlan *plan,
+                          const void *pixels_in_host, uint32_t rowstride_in,
+                          void *dest_host, uint32_t rowstride_out,
+                          uint32_t first_row, uint32_t n_rows)
+{
+    if (!plan || !pixels_in_host || !dest_host)
+        return SMOL_HIP_E_INVALID;
+    if (n_rows == 0)
+        return 0;
+
+    const SmolHipJob &job = plan->job;
+    uint32_t r0, r1;
+    int rc = smol_hip_input_row_range (&job, first_row, n_rows, &r0, &r1);
+    if (rc)
+        return rc;
+
+    HIP_TRY (hipSetDevice (plan->device));
+
+    const TypeInfo &ti = k_types [job.pixel_type_in];
+    const TypeInfo &to = k_types [job.pixel_type_out];
+    const size_t in_row_bytes = (size_t) job.width_in * ti.bpp;
+    const size_t out_row_bytes = (size_t) job.width_out * to.bpp;
+    /* Device rows are re-pitched to 16-byte multiples whatever the host strides
+     * are, so kernels see aligned rows even for odd host layouts (the reference
+     * copies odd rows to an aligned temporary: smolscale-generic.c:1623-1634). */
+    const size_t src_pitch = align_up (in_row_bytes, 16);
+    const size_t dst_pitch = align_up (out_row_bytes, 16);
+    const size_t n_in_rows = (size_t) r1 - r0 + 1;
+
+    if (src_pitch > 0xffffffffu || dst_pitch > 0xffffffffu)
+        return SMOL_HIP_E_INVALID;
+
+    DeviceState &ds = g_devices [plan->device];
+    Lane &ln = ds.lanes [ds.next.fetch_add (1) % N_LANES];
+    std::lock_guard<std::mutex> guard (ln.mtx);
+
+    rc = lane_prepare (ln, n_in_rows * src_pitch + 64, (size_t) n_rows * dst_pitch + 64);
+    if (rc)
+        return rc;
+
+    const uint8_t *host_src = static_cast<const uint8_t *> (pixels_in_host) + (size_t) r0 * rowstride_in;
+    HIP_TRY (hipMemcpy2DAsync (ln.src_buf, src_pitch, host_src, rowstride_in,
+                               in_row_bytes, n_in_rows, hipMemcpyHostToDevice, ln.stream));
+
+    /* Row 0 of the virtual source image lies r0 rows before the slab. */
+    const uint8_t *virt_src = static_cast<const uint8_t *> (ln.src_buf) - (size_t) r0 * src_pitch;
+    JobDev jd;
+    fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch, ln.dst_buf, (uint32_t) dst_pitch,
+                 first_row, n_rows);
+    HIP_TRY (launch_class (classify (jd), nullptr, 1, jd, jd.w_out, n_rows, ln.stream));
+    HIP_TRY (hipMemcpy2DAsync (dest_host, rowstride_out, ln.dst_buf, dst_pitch,
+                               out_row_bytes, n_rows, hipMemcpyDeviceToHost, ln.stream));
+    HIP_TRY (hipStreamSynchronize (ln.stream));
+    return 0;
+}
+
+/* ---- batches -------------------------------------------------------------- */
+
+int
+smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device,
+                       SmolHipBatch **batch_out)
+{
+    if (!images || !n_images || !batch_out || device < 0 || device >= MAX_DEVICES)
+        return SMOL_HIP_E_INVALID;
+    if (device >= smol_hip_device_count ())
+        return SMOL_HIP_E_NO_DEVICE;
+
+    HIP_TRY (hipSetDevice (device));
+
+    std::vector<JobDev> jobs (n_images);
+    std::vector<KClass> cls (n_images);
+
+    for (uint32_t i = 0; i < n_images; i++)
+    {
+        const SmolHipImage &im = images [i];
+
+        if (im.job.pixel_type_in >= 10 || im.job.pixel_type_out >= 10 || !im.src || !im.dst
+            || im.first_row + im.n_rows > im.job.height_out)
+            return SMOL_HIP_E_INVALID;
+        fill_jobdev (jobs [i], im.job, im.src, im.rowstride_in, im.dst, im.rowstride_out,
+                     im.first_row, im.n_rows);
+        cls [i] = classify (jobs [i]);
+    }
+
+    SmolHipBatch *b = new (std::nothrow) SmolHipBatch;
+    if (!b)
+        return SMOL_HIP_E_INVALID;
+    b->device = device;
+    b->n_images = n_images;
+
+    /* Stable grouping: images that can share one launch (same kernel class and,
+     * for k_pow2, same halvings) become one contiguous run of descriptors. */
+    std::vector<JobDev> sorted;
+    sorted.reserve (n_images);
+    std::vector<bool> taken (n_images, false);
+
+    for (uint32_t i = 0; i < n_images; i++)
+    {
+        if (taken [i])
+            continue;
+
+        SmolHipBatch::Group g;
+        g.k = cls [i];
+        g.first = (uint32_t) sorted.size ();
+        g.count = 0;
+        g.rep = jobs [i];
+        g.max_w_out = 0;
+        g.max_rows = 0;
+        uint64_t units = 0;
+
+        for (uint32_t j = i; j < n_images; j++)
+        {
+            if (taken [j] || cls [j] != g.k)
+                continue;
+            if (g.k == KC_POW2 && (jobs [j].halv_h != g.rep.halv_h || jobs [j].halv_v != g.rep.halv_v))
+                continue;
+            if (g.count == 65535)
+                break;
+            taken [j] = true;
+            sorted.push_back (jobs [j]);
+            g.count++;
+            if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
+            if (jobs [j].n_rows > g.max_rows) g.max_rows = jobs [j].n_rows;
+            units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
+        }
+
+        if (units > b->dominant_units)
+        {
+            b->dominant_units = units;
+            b->dominant_name = kclass_name (g.k, g.rep);
+        }
+        if (g.max_rows > 0)
+            b->groups.push_back (g);
+    }
+
+    hipError_t e = hipMalloc (reinterpret_cast<void **> (&b->jobs_dev), sorted.size () * sizeof (JobDev));
+    if (e == hipSuccess)
+        e = hipMemcpy (b->jobs_dev, sorted.data (), sorted.size () * sizeof (JobDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+        if (b->jobs_dev)
+            (void) hipFree (b->jobs_dev);
+        delete b;
+        return -(int) e;
+    }
+
+    *batch_out = b;
+    return 0;
+}
+
+int
+smol_hip_batch_launch (SmolHipBatch *batch, void *hip_stream)
+{
+    if (!batch)
+        return SMOL_HIP_E_INVALID;
+
+    hipStream_t s = static_cast<hipStream_t> (hip_stream);
+
+    HIP_TRY (hipSetDevice (batch->device));
+    for (const SmolHipBatch::Group &g : batch->groups)
+        HIP_TRY (launch_class (g.k, batch->jobs_dev + g.first, g.count, g.rep, g.max_w_out, g.max_rows, s));
+    return 0;
+}
+
+int
+smol_hip_batch_info (const SmolHipBatch *batch, uint32_t *n_launches, const char **kernel_name)
+{
+    if (!batch)
+        return SMOL_HIP_E_INVALID;
+    if (n_launches)
+        *n_launches = (uint32_t) batch->groups.size ();
+    if (kernel_name)
+        *kernel_name = batch->dominant_name;
+    return 0;
+}
+
+void
+smol_hip_batch_destroy (SmolHipBatch *batch)
+{
+    if (!batch)
+        return;
+    if (hipSetDevice (batch->device) == hipSuccess && batch->jobs_dev)
+        (void) hipFree (batch->jobs_dev);
+    delete batch;
+}
+
+int
+smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_total)
+{
+    if (!batch || !ms_total || !iters)
+        return SMOL_HIP_E_INVALID;
+
+    HIP_TRY (hipSetDevice (batch->device));
+
+    hipStream_t s;
+    hipEvent_t e0, e1;
+    HIP_TRY (hipStreamCreateWithFlags (&s, hipStreamNonBlocking));
+    HIP_TRY (hipEventCreate (&e0));
+    HIP_TRY (hipEventCreate (&e1));
+
+    int rc = 0;
+    for (uint32_t i = 0; i < warmup && !rc; i++)
+        rc = smol_hip_batch_launch (batch, s);
+    if (!rc)
+    {
+        HIP_TRY (hipStreamSynchronize (s));
+        HIP_TRY (hipEventRecord (e0, s));
+        for (uint32_t i = 0; i < iters && !rc; i++)
+            rc = smol_hip_batch_launch (batch, s);
+        HIP_TRY (hipEventRecord (e1, s));
+        HIP_TRY (hipEventSynchronize (e1));
+        HIP_TRY (hipEventElapsedTime (ms_total, e0, e1));
+    }
+
+    (void) hipEventDestroy (e0);
+    (void) hipEventDestroy (e1);
+    (void) hipStreamDestroy (s);
+    return rc;
+}
+
+/* ---- memory helpers ---------------------------------------------------------- */
+
+int
+smol_hip_malloc (int device, uint64_t n_bytes, void **dev_ptr_out)
+{
+    if (!dev_ptr_out)
+        return SMOL_HIP_E_INVALID;
+    HIP_TRY (hipSetDevice (device));
+    HIP_TRY (hipMalloc (dev_ptr_out, n_bytes));
+    return 0;
+}
+
+int
+smol_hip_free (int device, void *dev_ptr)
+{
+    HIP_TRY (hipSetDevice (device));
+    HIP_TRY (hipFree (dev_ptr));
+    return 0;
+}
+
+int
+smol_hip_memcpy_h2d (int device, void *dst_dev, const void *src_host, uint64_t n_bytes)
+{
+    HIP_TRY (hipSetDevice (device));
+    HIP_TRY (hipMemcpy (dst_dev, src_host, n_bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int
+smol_hip_memcpy_d2h (int device, void *dst_host, const void *src_dev, uint64_t n_bytes)
+{
+    HIP_TRY (hipSetDevice (device));
+    HIP_TRY (hipMemcpy (dst_host, src_dev, n_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int
+smol_hip_memset (int device, void *dst_dev, int value, uint64_t n_bytes)
+{
+    HIP_TRY (hipSetDevice (device));
+    HIP_TRY (hipMemset (dst_dev, value, n_bytes));
+    return 0;
+}
+
+int
+smol_hip_device_synchronize (int device)
+{
+    HIP_TRY (hipSetDevice (device));
+    HIP_TRY (hipDeviceSynchronize ());
+    return 0;
+}
+
+} /* extern "C" */

@@ -1,0 +1,137 @@
+/* smol_jobdev.h -- the device job descriptor and the host-side logic that fills
+ * it and picks a kernel class. Plain C++ (no HIP headers) so that the host
+ * emulation harness in tests/emu can share it with smol_hip.hip. */
+
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#include "smol_hip.h"
+
+namespace smolhip {
+
+enum : uint8_t { F_COPY = 0, F_ONE = 1, F_BILINEAR = 2, F_BOX = 3 };
+
+/* One job as the kernels see it (device-resident for batches, by-value kernel
+ * argument for single launches). Channel numbering: 0,1,2 = R,G,B, 3 = A. */
+struct JobDev
+{
+    const uint8_t *src;            /* address of input row 0 (may lie before a row slab) */
+    uint8_t *dst;                  /* address of output row `first_row'                  */
+    uint32_t src_stride, dst_stride;
+    uint32_t w_in, h_in, w_out, h_out;
+    uint32_t first_row, n_rows;
+    uint64_t frac0_x, step_x, frac0_y, step_y;
+    uint32_t span_mul_x, span_mul_y;
+    uint32_t out_perm;             /* v_perm selector, 32bpp -> 32bpp byte shuffle       */
+    uint8_t filter_h, filter_v, halv_h, halv_v;
+    uint8_t bpp_in, bpp_out;
+    uint8_t pos_in [4], pos_out [4];   /* byte index of R,G,B,A; 0xff = no alpha         */
+    uint8_t unassoc_in, unassoc_out, wide, p16, linear, quirk24;
+    uint8_t in_dword_ok, out_dword_ok; /* 4-byte pixels at 4-byte aligned addresses      */
+};
+
+namespace dispatch {
+
+/* byte position of R,G,B,A per SmolPixelType (smolscale.h:16-36 names the
+ * memory order); 0xff = channel absent */
+struct TypeInfo { uint8_t bpp; uint8_t pos [4]; uint8_t unassoc; };
+
+static const TypeInfo k_types [10] = {
+    { 4, { 0, 1, 2, 3 }, 0 }, { 4, { 2, 1, 0, 3 }, 0 }, { 4, { 1, 2, 3, 0 }, 0 }, { 4, { 3, 2, 1, 0 }, 0 },
+    { 4, { 0, 1, 2, 3 }, 1 }, { 4, { 2, 1, 0, 3 }, 1 }, { 4, { 1, 2, 3, 0 }, 1 }, { 4, { 3, 2, 1, 0 }, 1 },
+    { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
+};
+
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_COUNT };
+
+inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline void
+fill_jobdev (JobDev &d, const SmolHipJob &j, const void *src, uint32_t src_stride,
+             void *dst, uint32_t dst_stride, uint32_t first_row, uint32_t n_rows)
+{
+    const TypeInfo &ti = k_types [j.pixel_type_in];
+    const TypeInfo &to = k_types [j.pixel_type_out];
+
+    memset (&d, 0, sizeof (d));
+    d.src = static_cast<const uint8_t *> (src);
+    d.dst = static_cast<uint8_t *> (dst);
+    d.src_stride = src_stride;
+    d.dst_stride = dst_stride;
+    d.w_in = j.width_in;  d.h_in = j.height_in;
+    d.w_out = j.width_out; d.h_out = j.height_out;
+    d.first_row = first_row; d.n_rows = n_rows;
+    d.frac0_x = j.frac0_x; d.step_x = j.step_x;
+    d.frac0_y = j.frac0_y; d.step_y = j.step_y;
+    d.span_mul_x = j.span_mul_x; d.span_mul_y = j.span_mul_y;
+    d.filter_h = j.filter_h; d.filter_v = j.filter_v;
+    d.halv_h = j.halvings_h; d.halv_v = j.halvings_v;
+    d.bpp_in = ti.bpp; d.bpp_out = to.bpp;
+    for (int i = 0; i < 4; i++)
+    {
+        d.pos_in [i] = ti.pos [i];
+        d.pos_out [i] = to.pos [i];
+    }
+    d.unassoc_in = ti.unassoc; d.unassoc_out = to.unassoc;
+    d.wide = j.wide; d.p16 = j.premul16; d.linear = j.linear; d.quirk24 = j.quirk24;
+    d.in_dword_ok = (ti.bpp == 4 && (((uintptr_t) src | src_stride) & 3) == 0);
+    d.out_dword_ok = (to.bpp == 4 && (((uintptr_t) dst | dst_stride) & 3) == 0);
+
+    /* 32bpp -> 32bpp byte shuffle: output byte pos_out[ch] takes input byte pos_in[ch] */
+    if (ti.bpp == 4 && to.bpp == 4)
+    {
+        uint32_t sel = 0;
+        for (int ch = 0; ch < 4; ch++)
+            sel |= (uint32_t) ti.pos [ch] << (8 * to.pos [ch]);
+        d.out_perm = sel;
+    }
+}
+
+/* Does the job qualify for k_pow2? Exact 2:1/4:1/8:1 on both axes, 32-bit
+ * premultiplied in and out, 64bpp-class math, 16-byte aligned source rows. */
+inline bool
+pow2_ok (const JobDev &d)
+{
+    if (d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR)
+        return false;
+    if (d.wide || d.bpp_in != 4 || d.bpp_out != 4 || d.unassoc_in || d.unassoc_out)
+        return false;
+    if (d.w_in != (d.w_out << (d.halv_h + 1)) || d.h_in != (d.h_out << (d.halv_v + 1)))
+        return false;
+
+    const uint32_t rx = 2u << d.halv_h;
+    const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
+
+    if (d.w_out % opt)
+        return false;
+    if ((((uintptr_t) d.src) | d.src_stride) & 15)
+        return false;
+    if ((((uintptr_t) d.dst) | d.dst_stride) & (opt * 4 - 1))
+        return false;
+    return true;
+}
+
+inline KClass
+classify (const JobDev &d)
+{
+    if (pow2_ok (d))
+        return KC_POW2;
+    return d.wide ? KC_GENERAL_WIDE : KC_GENERAL;
+}
+
+inline const char *
+kclass_name (KClass k, const JobDev &d)
+{
+    switch (k)
+    {
+        case KC_POW2: return "k_pow2_batch";
+        case KC_GENERAL_WIDE: return "k_general_batch<true>";
+        default: return "k_general_batch<false>";
+    }
+    (void) d;
+}
+
+} /* namespace dispatch */
+} /* namespace smolhip */

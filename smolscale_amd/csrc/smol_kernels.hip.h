@@ -1,0 +1,595 @@
+/* smol_kernels.hip.h -- device code of the HIP backend (gfx950 / CDNA4 only).
+ *
+ * Included by smol_hip.hip. Everything here is new code; the arithmetic it has
+ * to reproduce is the reference's integer fixed-point path (citations per
+ * function, paths relative to the reference tree).
+ *
+ * Kernel classes
+ *   k_general<WIDE>   any job. One thread per output pixel; source pixels are
+ *                     gathered straight from global memory. Correctness backstop
+ *                     and the path for exotic jobs (sRGB-linear, premul16, box
+ *                     with huge spans, ...).
+ *   k_pow2<HX,HY>     exact 2:1 / 4:1 / 8:1 bilinear-with-halvings on 32-bit
+ *                     premultiplied pixels (BASELINE configs 1, 2 and 5): every
+ *                     weight is 128, so a tap is a per-byte floor average and
+ *                     the whole 2^n x 2^m block reduces in packed registers.
+ *                     Pure streaming: each lane issues 16-byte loads that are
+ *                     contiguous across the wave (1 KiB per load instruction),
+ *                     no LDS, no tables, every source byte read exactly once.
+ */
+
+#pragma once
+
+#ifdef SMOL_KERNEL_EMU
+/* tests/emu compiles these kernel bodies for the HOST (clang++, no GPU) to debug
+ * kernel logic in the build container; never part of the shipped library. */
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+#define SMOL_LUT_QUAL __constant__
+#include "smol_luts.h"
+
+#include "smol_jobdev.h"
+
+namespace smolhip {
+
+/* ------------------------------------------------------------------------- *
+ * Per-channel arithmetic                                                    *
+ * ------------------------------------------------------------------------- */
+
+/* unassociated -> premultiplied 8 bit: smolscale-generic.c:238-244 */
+__device__ __forceinline__ uint32_t premul8 (uint32_t c, uint32_t a)
+{
+    return (((c + 1u) * (a + 1u) - 1u) >> 8) & 0xffu;
+}
+
+/* linear 11 bit x alpha: smolscale-generic.c:261-269 */
+__device__ __forceinline__ uint32_t premul8l (uint32_t l, uint32_t a)
+{
+    return (((l + 1u) * ((a << 3) + 1u) - 1u) >> 11) & 0x7ffu;
+}
+
+/* premultiplied -> unassociated 8 bit via the inverse table: :227-236, 246-259 */
+__device__ __forceinline__ uint32_t unpremul8 (uint32_t c, uint32_t a)
+{
+    return (uint32_t) ((((uint64_t) c * smol_inv_p8_lut [a]) >> 13) & 0xffu);
+}
+
+/* one bilinear tap: q + floor ((p - q) * F / 256): :1317, :1704.
+ * Lanes never exceed 16 bits (B.6 of SURVEY.md), so int32 is exact. */
+__device__ __forceinline__ uint32_t lerp8 (uint32_t p, uint32_t q, uint32_t F, uint32_t mask)
+{
+    int32_t d = ((int32_t) p - (int32_t) q) * (int32_t) F;
+    return (uint32_t) ((d >> 8) + (int32_t) q) & mask;
+}
+
+/* box normalisation: :1231-1261 (16-bit lanes for 64bpp, 32-bit lanes for 128bpp) */
+template <bool WIDE>
+__device__ __forceinline__ uint32_t box_scale (uint32_t acc, uint32_t mul)
+{
+    if (!WIDE)
+        acc &= 0xffffu;
+    uint64_t v = (uint64_t) acc * mul + (1u << 23);
+    return (uint32_t) (v >> 24) & (WIDE ? 0xffffu : 0xffu);
+}
+
+/* ------------------------------------------------------------------------- *
+ * Unpack one source pixel into internal channels                            *
+ *   64bpp-class: smolscale-generic.c:353-464                                *
+ *   128bpp-class: :470-752                                                  *
+ * ------------------------------------------------------------------------- */
+template <bool WIDE>
+__device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, uint32_t x,
+                                          uint32_t (&c) [4])
+{
+    uint32_t a;
+
+    if (J.bpp_in == 4)
+    {
+        const uint8_t *p = rowp + (size_t) x * 4;
+        uint32_t w;
+
+        if (J.in_dword_ok)
+            w = *reinterpret_cast<const uint32_t *> (p);
+        else
+            w = (uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t) p [2] << 16) | ((uint32_t) p [3] << 24);
+
+        c [0] = (w >> (8 * J.pos_in [0])) & 0xffu;
+        c [1] = (w >> (8 * J.pos_in [1])) & 0xffu;
+        c [2] = (w >> (8 * J.pos_in [2])) & 0xffu;
+        a = (w >> (8 * J.pos_in [3])) & 0xffu;
+    }
+    else
+    {
+        const uint8_t *p = rowp + (size_t) x * 3;
+
+        c [0] = p [J.pos_in [0]];
+        c [1] = p [J.pos_in [1]];
+        c [2] = p [J.pos_in [2]];
+        a = 0xffu;
+    }
+
+    if (WIDE && J.p16)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+        {
+            uint32_t v = c [i];
+            if (J.linear)
+                v = smol_from_srgb_lut [v];
+            c [i] = v * a;
+        }
+        c [3] = (a << 8) | 0x80u;
+        return;
+    }
+
+    if (WIDE && J.linear)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+        {
+            uint32_t v = c [i];
+            if (!J.unassoc_in)
+                v = unpremul8 (v, a);
+            c [i] = premul8l (smol_from_srgb_lut [v], a);
+        }
+    }
+    else if (J.unassoc_in)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            c [i] = premul8 (c [i], a);
+    }
+
+    c [3] = a;
+}
+
+/* ------------------------------------------------------------------------- *
+ * Pack internal channels into one destination pixel                         *
+ *   64bpp-class: smolscale-generic.c:758-906; 128bpp-class: :912-1164       *
+ * ------------------------------------------------------------------------- */
+template <bool WIDE>
+__device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32_t x,
+                                          const uint32_t (&v) [4])
+{
+    uint32_t a, c [3];
+
+    if (WIDE && J.p16)
+        a = (v [3] >> 8) & 0xffu;
+    else
+        a = v [3] & 0xffu;
+
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+    {
+        uint32_t s = v [i];
+
+        if (!WIDE)
+        {
+            c [i] = J.unassoc_out ? unpremul8 (s, a) : (s & 0xffu);
+        }
+        else if (J.p16)
+        {
+            if (J.linear)
+                c [i] = smol_to_srgb_lut [(uint32_t) (((uint64_t) s * smol_inv_p16l_lut [a]) >> 19) & 0x7ffu];
+            else
+                c [i] = (uint32_t) (((uint64_t) s * smol_inv_p16_lut [a]) >> 16) & 0xffu;
+        }
+        else if (!J.linear)
+        {
+            c [i] = J.unassoc_out ? unpremul8 (s, a) : (s & 0xffu);
+        }
+        else
+        {
+            uint32_t u = (uint32_t) (((uint64_t) s * smol_inv_p8l_lut [a]) >> 10) & 0x7ffu;
+
+            if (J.bpp_out == 3)
+                c [i] = J.quirk24 ? smol_to_srgb_lut [s & 0x7ffu] : smol_to_srgb_lut [u];
+            else if (J.unassoc_out)
+                c [i] = smol_to_srgb_lut [u];
+            else
+                c [i] = premul8 (smol_to_srgb_lut [u], a);
+        }
+    }
+
+    if (J.bpp_out == 4)
+    {
+        uint8_t *p = rowp + (size_t) x * 4;
+        uint32_t w = (c [0] << (8 * J.pos_out [0])) | (c [1] << (8 * J.pos_out [1]))
+                   | (c [2] << (8 * J.pos_out [2])) | (a << (8 * J.pos_out [3]));
+
+        if (J.out_dword_ok)
+        {
+            *reinterpret_cast<uint32_t *> (p) = w;
+        }
+        else
+        {
+            p [0] = (uint8_t) w;
+            p [1] = (uint8_t) (w >> 8);
+            p [2] = (uint8_t) (w >> 16);
+            p [3] = (uint8_t) (w >> 24);
+        }
+    }
+    else
+    {
+        uint8_t *p = rowp + (size_t) x * 3;
+
+        p [J.pos_out [0]] = (uint8_t) c [0];
+        p [J.pos_out [1]] = (uint8_t) c [1];
+        p [J.pos_out [2]] = (uint8_t) c [2];
+    }
+}
+
+/* ------------------------------------------------------------------------- *
+ * Closed-form sample positions (host twins: smol_plan.c)                    *
+ * ------------------------------------------------------------------------- */
+__device__ __forceinline__ void bilin_tap (uint64_t pos, uint32_t dim_in, uint32_t &ofs, uint32_t &F)
+{
+    uint32_t o = (uint32_t) (pos >> 32);
+
+    if (o >= dim_in - 1)
+    {
+        ofs = dim_in - 2;
+        F = 0;
+    }
+    else
+    {
+        ofs = o;
+        F = 256u - ((uint32_t) (pos >> 24) & 0xffu);
+    }
+}
+
+__device__ __forceinline__ void box_span (uint64_t step, uint32_t dim_in, uint32_t k,
+                                          uint32_t &o0, uint32_t &o1, uint32_t &f_right, uint32_t &w_left)
+{
+    uint64_t b = (uint64_t) k * step;
+    uint64_t e = b + step;
+    uint32_t last = (uint32_t) (e >> 16);
+
+    o0 = (uint32_t) (b >> 16);
+    o1 = last > dim_in - 1 ? dim_in - 1 : last;
+    f_right = (uint32_t) (e >> 8) & 0xffu;
+    w_left = k ? 255u - ((uint32_t) (b >> 8) & 0xffu) : 256u;
+}
+
+/* ------------------------------------------------------------------------- *
+ * Horizontal result H(row, x): the value the reference's hfilter leaves in   *
+ * its scaled row (smolscale-generic.c:1290-1611), computed on demand.       *
+ * A single loop over "source taps" keeps one fetch_px call site.            *
+ * ------------------------------------------------------------------------- */
+template <bool WIDE>
+__device__ void hsample (const JobDev &J, uint32_t row, uint32_t x, uint32_t (&out) [4])
+{
+    const uint8_t *rowp = J.src + (size_t) row * J.src_stride;
+    const uint32_t mask = WIDE ? 0x00ffffffu : 0xffu;
+    uint32_t acc [4] = { 0, 0, 0, 0 };
+    uint32_t px [4], prev [4] = { 0, 0, 0, 0 };
+
+    if (J.filter_h == F_BILINEAR)
+    {
+        const uint32_t h = J.halv_h;
+        const uint32_t ntaps = 2u << h;
+        uint64_t pos = J.frac0_x + (uint64_t) (x << h) * J.step_x;
+        uint32_t ofs = 0, F = 0;
+
+        for (uint32_t t = 0; t < ntaps; t++)
+        {
+            if (!(t & 1))
+            {
+                bilin_tap (pos, J.w_in, ofs, F);
+                pos += J.step_x;
+            }
+
+            fetch_px<WIDE> (J, rowp, ofs + (t & 1), px);
+
+            if (t & 1)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += lerp8 (prev [i], px [i], F, mask);
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    prev [i] = px [i];
+            }
+        }
+
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out [i] = (acc [i] >> h) & mask;
+    }
+    else if (J.filter_h == F_BOX)
+    {
+        uint32_t o0, o1, fr, wl;
+
+        box_span (J.step_x, J.w_in, x, o0, o1, fr, wl);
+
+        for (uint32_t s = o0; s <= o1; s++)
+        {
+            fetch_px<WIDE> (J, rowp, s, px);
+
+            if (s == o0)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += ((px [i] * wl) >> 8) & mask;
+            }
+            else if (s == o1)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += ((px [i] * fr) >> 8) & mask;
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += px [i];
+            }
+        }
+
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out [i] = box_scale<WIDE> (acc [i], J.span_mul_x);
+    }
+    else
+    {
+        fetch_px<WIDE> (J, rowp, J.filter_h == F_ONE ? 0u : x, out);
+    }
+}
+
+/* ------------------------------------------------------------------------- *
+ * k_general: one thread = one output pixel                                  *
+ *   vertical bilinear: smolscale-generic.c:1648-2007                        *
+ *   vertical box 64bpp: :2026-2161, 128bpp: :2163-2260                      *
+ *   copy / one: :2262-2318                                                  *
+ * ------------------------------------------------------------------------- */
+template <bool WIDE>
+__device__ void general_pixel (const JobDev &J, uint32_t x, uint32_t y)
+{
+    const uint32_t mask = WIDE ? 0x00ffffffu : 0xffu;
+    uint32_t acc [4] = { 0, 0, 0, 0 };
+    uint32_t v [4], top [4] = { 0, 0, 0, 0 };
+
+    if (J.filter_v == F_BILINEAR)
+    {
+        const uint32_t h = J.halv_v;
+        const uint32_t ntaps = 2u << h;
+        uint64_t pos = J.frac0_y + (uint64_t) (y << h) * J.step_y;
+        uint32_t oy = 0, F = 0;
+
+        for (uint32_t t = 0; t < ntaps; t++)
+        {
+            if (!(t & 1))
+            {
+                bilin_tap (pos, J.h_in, oy, F);
+                pos += J.step_y;
+            }
+
+            hsample<WIDE> (J, oy + (t & 1), x, v);
+
+            if (t & 1)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += lerp8 (top [i], v [i], F, mask);
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    top [i] = v [i];
+            }
+        }
+
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            v [i] = (acc [i] >> h) & mask;
+    }
+    else if (J.filter_v == F_BOX)
+    {
+        uint32_t y0, y1, w2, w1;
+
+        box_span (J.step_y, J.h_in, y, y0, y1, w2, w1);
+
+        /* 128bpp-class rows weight the last row by w2 - 1 and skip it when
+         * w2 == 0 (:2236-2253); 64bpp-class rows use w2 as is (:2042-2069). */
+        uint32_t last_w = WIDE ? (w2 ? w2 - 1 : 0) : w2;
+        uint32_t y_end = (WIDE && w2 == 0) ? y1 - 1 : y1;
+
+        for (uint32_t r = y0; r <= y_end; r++)
+        {
+            hsample<WIDE> (J, r, x, v);
+
+            if (r == y0)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += ((v [i] * w1) >> 8) & mask;
+            }
+            else if (r == y1)
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += ((v [i] * last_w) >> 8) & mask;
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += v [i];
+            }
+        }
+
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            v [i] = box_scale<WIDE> (acc [i], J.span_mul_y);
+    }
+    else
+    {
+        hsample<WIDE> (J, J.filter_v == F_ONE ? 0u : y, x, v);
+    }
+
+    store_px<WIDE> (J, J.dst + (size_t) (y - J.first_row) * J.dst_stride, x, v);
+}
+
+constexpr int GENERAL_BLOCK = 256;
+
+template <bool WIDE>
+__device__ __forceinline__ void general_body (const JobDev &J)
+{
+    const uint32_t tiles_x = (J.w_out + GENERAL_BLOCK - 1) / GENERAL_BLOCK;
+    const uint32_t row = blockIdx.x / tiles_x;
+    const uint32_t x = (blockIdx.x % tiles_x) * GENERAL_BLOCK + threadIdx.x;
+
+    if (row >= J.n_rows || x >= J.w_out)
+        return;
+
+    general_pixel<WIDE> (J, x, J.first_row + row);
+}
+
+/* batch form: one descriptor per blockIdx.y, descriptors in device memory */
+template <bool WIDE>
+__global__ void __launch_bounds__ (GENERAL_BLOCK)
+k_general_batch (const JobDev *jobs)
+{
+    general_body<WIDE> (jobs [blockIdx.y]);
+}
+
+/* single-job form: descriptor passed by value in the kernel arguments */
+template <bool WIDE>
+__global__ void __launch_bounds__ (GENERAL_BLOCK)
+k_general_one (const JobDev J)
+{
+    general_body<WIDE> (J);
+}
+
+/* ------------------------------------------------------------------------- *
+ * k_pow2: exact 2^n : 1 bilinear-with-halvings, 32-bit premultiplied pixels *
+ *                                                                           *
+ * With w_in == w_out << (HX+1) every horizontal sample j sits at offset 2j  *
+ * with weight F = 128 (closed form of smolscale-generic.c:24-52), so a tap  *
+ *      q + (((p - q) * 128) >> 8)  ==  floor ((p + q) / 2)   per channel,   *
+ * and the halving step is (sum of 2^HX taps) >> HX (:1363-1387). The same   *
+ * holds vertically on the 8-bit horizontal results (:1684-1811). All four   *
+ * channels of a pixel stay packed in one 32-bit register.                   *
+ * ------------------------------------------------------------------------- */
+
+/* per-byte floor average of two packed pixels */
+__device__ __forceinline__ uint32_t avg4 (uint32_t a, uint32_t b)
+{
+    return (a & b) + (((a ^ b) >> 1) & 0x7f7f7f7fu);
+}
+
+/* (a + b + c + d) >> 2 per byte, exact (16-bit lanes) */
+__device__ __forceinline__ uint32_t sum4_shift2 (uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t m = 0x00ff00ffu;
+    uint32_t lo = (a & m) + (b & m) + (c & m) + (d & m);
+    uint32_t hi = ((a >> 8) & m) + ((b >> 8) & m) + ((c >> 8) & m) + ((d >> 8) & m);
+    return ((lo >> 2) & m) | (((hi >> 2) & m) << 8);
+}
+
+/* Reduce 2^(H+1) consecutive packed pixels px[0..] to one: taps then halving. */
+template <int H>
+__device__ __forceinline__ uint32_t reduce_pow2 (const uint32_t *px)
+{
+    if (H == 0)
+        return avg4 (px [0], px [1]);
+    if (H == 1)
+        return avg4 (avg4 (px [0], px [1]), avg4 (px [2], px [3]));
+    return sum4_shift2 (avg4 (px [0], px [1]), avg4 (px [2], px [3]),
+                        avg4 (px [4], px [5]), avg4 (px [6], px [7]));
+}
+
+template <int HX, int HY>
+struct Pow2Cfg
+{
+    static constexpr int RX = 2 << HX;                 /* source px per output px, x */
+    static constexpr int RY = 2 << HY;                 /* source rows per output row */
+    static constexpr int OPT = RX >= 4 ? 1 : 4 / RX;   /* output px per thread       */
+    static constexpr int NLOAD = OPT * RX / 4;         /* 16-byte loads per src row  */
+    static constexpr int BLOCK = 256;
+};
+
+typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+
+template <int HX, int HY>
+__device__ __forceinline__ void pow2_body (const JobDev &J)
+{
+    using C = Pow2Cfg<HX, HY>;
+
+    const uint32_t tcols = J.w_out / C::OPT;
+    const uint32_t tiles_x = (tcols + C::BLOCK - 1) / C::BLOCK;
+    const uint32_t row = blockIdx.x / tiles_x;
+    const uint32_t tc = (blockIdx.x % tiles_x) * C::BLOCK + threadIdx.x;
+
+    if (row >= J.n_rows || tc >= tcols)
+        return;
+
+    const uint32_t y = J.first_row + row;
+    const uint8_t *sp = J.src + (size_t) y * C::RY * J.src_stride + (size_t) tc * (C::NLOAD * 16);
+
+    /* Issue every load of the block first: RY * NLOAD independent 16-byte loads
+     * in flight per lane. */
+    u32x4 raw [C::RY][C::NLOAD];
+#pragma unroll
+    for (int r = 0; r < C::RY; r++)
+#pragma unroll
+        for (int l = 0; l < C::NLOAD; l++)
+            raw [r][l] = __builtin_nontemporal_load (
+                reinterpret_cast<const u32x4 *> (sp + (size_t) r * J.src_stride) + l);
+
+    uint32_t hres [C::OPT][C::RY];
+#pragma unroll
+    for (int r = 0; r < C::RY; r++)
+    {
+        uint32_t px [C::NLOAD * 4];
+#pragma unroll
+        for (int l = 0; l < C::NLOAD; l++)
+        {
+            px [l * 4 + 0] = raw [r][l].x;
+            px [l * 4 + 1] = raw [r][l].y;
+            px [l * 4 + 2] = raw [r][l].z;
+            px [l * 4 + 3] = raw [r][l].w;
+        }
+#pragma unroll
+        for (int o = 0; o < C::OPT; o++)
+            hres [o][r] = reduce_pow2<HX> (&px [o * C::RX]);
+    }
+
+    uint32_t outv [C::OPT];
+#pragma unroll
+    for (int o = 0; o < C::OPT; o++)
+    {
+        uint32_t v = reduce_pow2<HY> (hres [o]);
+        outv [o] = __builtin_amdgcn_perm (v, v, J.out_perm);
+    }
+
+    uint8_t *dp = J.dst + (size_t) row * J.dst_stride + (size_t) tc * (C::OPT * 4);
+    if (C::OPT == 1)
+        *reinterpret_cast<uint32_t *> (dp) = outv [0];
+    else
+        *reinterpret_cast<uint2 *> (dp) = make_uint2 (outv [0], outv [C::OPT - 1]);
+}
+
+template <int HX, int HY>
+__global__ void __launch_bounds__ (256)
+k_pow2_batch (const JobDev *jobs)
+{
+    pow2_body<HX, HY> (jobs [blockIdx.y]);
+}
+
+template <int HX, int HY>
+__global__ void __launch_bounds__ (256)
+k_pow2_one (const JobDev J)
+{
+    pow2_body<HX, HY> (J);
+}
+
+} /* namespace smolhip */

@@ -1,0 +1,71 @@
+/* emu_kernels.cpp -- TEST INFRASTRUCTURE: runs the HIP kernel bodies on the host,
+ * block by block and thread by thread, through the same descriptor-filling and
+ * kernel-class selection code the real runtime uses (smol_jobdev.h).
+ * Built by tests/emu/Makefile with clang++ -DSMOL_KERNEL_EMU. */
+#define SMOL_KERNEL_EMU 1
+#include "smol_kernels.hip.h"
+
+using namespace smolhip;
+using namespace smolhip::dispatch;
+
+template <typename F>
+static void run_grid (unsigned gx, unsigned gy, unsigned bx, F body)
+{
+    gridDim = { gx, gy, 1 };
+    blockDim = { bx, 1, 1 };
+    for (unsigned by = 0; by < gy; by++)
+        for (unsigned b = 0; b < gx; b++)
+            for (unsigned t = 0; t < bx; t++)
+            {
+                blockIdx = { b, by, 0 };
+                threadIdx = { t, 0, 0 };
+                body ();
+            }
+}
+
+template <int HX>
+static void run_pow2_hy (const JobDev &J, unsigned gx)
+{
+    switch (J.halv_v)
+    {
+        case 0: run_grid (gx, 1, 256, [&] { k_pow2_one<HX, 0> (J); }); break;
+        case 1: run_grid (gx, 1, 256, [&] { k_pow2_one<HX, 1> (J); }); break;
+        default: run_grid (gx, 1, 256, [&] { k_pow2_one<HX, 2> (J); }); break;
+    }
+}
+
+extern "C" int
+emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
+                void *dst, uint32_t stride_out, uint32_t first_row, uint32_t n_rows,
+                int force_general, int *kclass_out)
+{
+    JobDev J;
+    fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
+    KClass k = classify (J);
+    if (force_general && k == KC_POW2)
+        k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
+    if (kclass_out)
+        *kclass_out = (int) k;
+
+    if (k == KC_POW2)
+    {
+        const uint32_t rx = 2u << J.halv_h;
+        const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
+        const uint32_t tcols = J.w_out / opt;
+        unsigned gx = ((tcols + 255) / 256) * n_rows;
+        switch (J.halv_h)
+        {
+            case 0: run_pow2_hy<0> (J, gx); break;
+            case 1: run_pow2_hy<1> (J, gx); break;
+            default: run_pow2_hy<2> (J, gx); break;
+        }
+        return 0;
+    }
+
+    unsigned gx = ((J.w_out + GENERAL_BLOCK - 1) / GENERAL_BLOCK) * n_rows;
+    if (k == KC_GENERAL_WIDE)
+        run_grid (gx, 1, GENERAL_BLOCK, [&] { k_general_one<true> (J); });
+    else
+        run_grid (gx, 1, GENERAL_BLOCK, [&] { k_general_one<false> (J); });
+    return 0;
+}
