@@ -93,6 +93,20 @@ plan_axis (uint32_t dim_in, uint32_t dim_out, uint32_t with_srgb,
     }
 }
 
+/* smolscale-generic.c:82-91: the box normaliser computed at the top of
+ * precalc_boxes_array(). */
+static uint32_t
+box_span_mul (uint32_t dim_in, uint32_t dim_out)
+{
+    uint64_t step = ((uint64_t) dim_in * 65536) / (uint64_t) dim_out;
+    uint64_t stride = step / 65536;
+    uint64_t f = (step / 256) % 256;
+    uint64_t a = ((uint64_t) 65536 * 256) * 255;
+    uint64_t b = (stride * 255) + ((f * 255) / 256);
+
+    return (uint32_t) ((a + (b / 2)) / b);
+}
+
 /* smolscale.c:816-870 smol_scale_init() + :725-783 get_implementations().
  * quirk24: which of the two 128bpp->24bpp packers find_repacks() (:647-719)
  * lands on. With 128bpp storage the unpackers leave channels in mid order
@@ -116,6 +130,10 @@ smol_oracle_plan (uint32_t type_in, uint32_t w_in, uint32_t h_in,
     plan_axis (w_in, w_out, with_srgb, &p->filter_h, &st_h, &p->width_halvings, &p->width_bilin_out);
     plan_axis (h_in, h_out, with_srgb, &p->filter_v, &st_v, &p->height_halvings, &p->height_bilin_out);
     p->storage_type = st_h > st_v ? st_h : st_v;                         /* :862 */
+    if (p->filter_h == ORACLE_FILTER_BOX)
+        p->span_mul_x = box_span_mul (w_in, w_out);
+    if (p->filter_v == ORACLE_FILTER_BOX)
+        p->span_mul_y = box_span_mul (h_in, h_out);
     p->gamma_type = with_srgb ? 1 : 0;                                   /* :846 */
 
     if (type_meta [type_in].unassoc && type_meta [type_out].unassoc)     /* :751-758 */

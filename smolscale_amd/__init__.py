@@ -1,0 +1,271 @@
+"""smolscale_amd -- MI355X-native image resampler with smolscale's C API.
+
+The product is the shared library ``libsmolscale_amd.so`` (host C planner + HIP
+kernels for gfx950, sources in ``smolscale_amd/csrc``). This Python package is
+only the host-side binding used by the tests and by ``bench.py``: thin ctypes
+mirrors of the C entry points with the same names and argument meaning as
+``include/smolscale.h`` (the reference's public header, smolscale.h:48-83) and
+``include/smol_hip.h`` (the C-ABI boundary of the HIP backend).
+
+There is no CPU implementation behind any of it: if the library is missing,
+importing :func:`lib` raises; if the GPU is missing, the C API aborts the process
+with a message (the reference aborts on its own unusable configurations,
+smolscale.c:779-780).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmolscale_amd.so")
+
+# SmolPixelType, include/smolscale.h
+SMOL_PIXEL_RGBA8_PREMULTIPLIED = 0
+SMOL_PIXEL_BGRA8_PREMULTIPLIED = 1
+SMOL_PIXEL_ARGB8_PREMULTIPLIED = 2
+SMOL_PIXEL_ABGR8_PREMULTIPLIED = 3
+SMOL_PIXEL_RGBA8_UNASSOCIATED = 4
+SMOL_PIXEL_BGRA8_UNASSOCIATED = 5
+SMOL_PIXEL_ARGB8_UNASSOCIATED = 6
+SMOL_PIXEL_ABGR8_UNASSOCIATED = 7
+SMOL_PIXEL_RGB8 = 8
+SMOL_PIXEL_BGR8 = 9
+SMOL_PIXEL_MAX = 10
+
+SMOL_HIP_FILTER_COPY, SMOL_HIP_FILTER_ONE, SMOL_HIP_FILTER_BILINEAR, SMOL_HIP_FILTER_BOX = 0, 1, 2, 3
+
+_u8 = ctypes.c_uint8
+_u32 = ctypes.c_uint32
+_u64 = ctypes.c_uint64
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+
+def bytes_per_pixel(pixel_type):
+    return 3 if pixel_type >= SMOL_PIXEL_RGB8 else 4
+
+
+class SmolHipJob(ctypes.Structure):
+    """include/smol_hip.h: SmolHipJob"""
+    _fields_ = [
+        ("width_in", _u32), ("height_in", _u32), ("width_out", _u32), ("height_out", _u32),
+        ("pixel_type_in", _u8), ("pixel_type_out", _u8),
+        ("filter_h", _u8), ("filter_v", _u8),
+        ("halvings_h", _u8), ("halvings_v", _u8),
+        ("wide", _u8), ("premul16", _u8), ("linear", _u8), ("quirk24", _u8),
+        ("reserved", _u8 * 2),
+        ("span_mul_x", _u32), ("span_mul_y", _u32),
+        ("frac0_x", _u64), ("step_x", _u64), ("frac0_y", _u64), ("step_y", _u64),
+    ]
+
+
+class SmolHipImage(ctypes.Structure):
+    """include/smol_hip.h: SmolHipImage"""
+    _fields_ = [
+        ("job", SmolHipJob), ("src", _vp), ("dst", _vp),
+        ("rowstride_in", _u32), ("rowstride_out", _u32),
+        ("first_row", _u32), ("n_rows", _u32),
+    ]
+
+
+# SmolPostRowFunc (include/smolscale.h)
+POST_ROW_FUNC = ctypes.CFUNCTYPE(None, ctypes.POINTER(_u32), _int, _vp)
+
+_SCALE_ARGS = [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _u8]
+
+# name -> (restype, argtypes): every symbol include/*.h declares
+EXPORTS = {
+    # include/smolscale.h
+    "smol_scale_simple": (None, _SCALE_ARGS),
+    "smol_scale_new": (_vp, _SCALE_ARGS),
+    "smol_scale_new_full": (_vp, _SCALE_ARGS + [_vp, _vp]),
+    "smol_scale_destroy": (None, [_vp]),
+    "smol_scale_batch": (None, [_vp, _u32, _u32]),
+    "smol_scale_batch_full": (None, [_vp, _vp, _u32, _u32]),
+    # include/smol_hip.h
+    "smol_hip_plan_job": (_int, [_u32] * 7 + [ctypes.POINTER(SmolHipJob)]),
+    "smol_hip_input_row_range": (_int, [ctypes.POINTER(SmolHipJob), _u32, _u32,
+                                        ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "smol_hip_bilinear_sample": (None, [_u64, _u64, _u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "smol_hip_box_span": (None, [_u64, _u32, _u32] + [ctypes.POINTER(_u32)] * 4),
+    "smol_hip_strerror": (ctypes.c_char_p, [_int]),
+    "smol_hip_device_count": (_int, []),
+    "smol_hip_plan_create": (_int, [ctypes.POINTER(SmolHipJob), _int, ctypes.POINTER(_vp)]),
+    "smol_hip_plan_destroy": (None, [_vp]),
+    "smol_hip_scale_rows_host": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32]),
+    "smol_hip_scale_rows_device": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp]),
+    "smol_hip_batch_create": (_int, [ctypes.POINTER(SmolHipImage), _u32, _int, ctypes.POINTER(_vp)]),
+    "smol_hip_batch_launch": (_int, [_vp, _vp]),
+    "smol_hip_batch_info": (_int, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_char_p)]),
+    "smol_hip_batch_destroy": (None, [_vp]),
+    "smol_hip_batch_time": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
+    "smol_hip_malloc": (_int, [_int, _u64, ctypes.POINTER(_vp)]),
+    "smol_hip_free": (_int, [_int, _vp]),
+    "smol_hip_memcpy_h2d": (_int, [_int, _vp, _vp, _u64]),
+    "smol_hip_memcpy_d2h": (_int, [_int, _vp, _vp, _u64]),
+    "smol_hip_memset": (_int, [_int, _vp, _int, _u64]),
+    "smol_hip_device_synchronize": (_int, [_int]),
+}
+
+_lib = None
+
+
+def build():
+    """Compile libsmolscale_amd.so in-tree (hipcc --offload-arch=gfx950)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    """The loaded C library. Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "smolscale_amd: %s is missing; build it with `make -C smolscale_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in EXPORTS.items():
+            fn = getattr(handle, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HipError("%s failed: %s (%d)" % (what or "HIP call", lib().smol_hip_strerror(rc).decode(), rc))
+
+
+def plan_job(pixel_type_in, width_in, height_in, pixel_type_out, width_out, height_out, with_srgb=0):
+    job = SmolHipJob()
+    check(lib().smol_hip_plan_job(pixel_type_in, width_in, height_in, pixel_type_out,
+                                  width_out, height_out, int(with_srgb), ctypes.byref(job)),
+          "smol_hip_plan_job")
+    return job
+
+
+def input_row_range(job, first_row, n_rows):
+    a, b = _u32(0), _u32(0)
+    check(lib().smol_hip_input_row_range(ctypes.byref(job), first_row, n_rows,
+                                         ctypes.byref(a), ctypes.byref(b)), "smol_hip_input_row_range")
+    return a.value, b.value
+
+
+def _as_u8(buf):
+    arr = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    return arr
+
+
+def smol_scale_simple(pixels_in, pixel_type_in, width_in, height_in, rowstride_in,
+                      pixels_out, pixel_type_out, width_out, height_out, rowstride_out, with_srgb=0):
+    """smol_scale_simple() of include/smolscale.h on numpy uint8 buffers (in place)."""
+    src = _as_u8(pixels_in)
+    dst = pixels_out.view(np.uint8).reshape(-1)
+    lib().smol_scale_simple(src.ctypes.data, pixel_type_in, width_in, height_in, rowstride_in,
+                            dst.ctypes.data, pixel_type_out, width_out, height_out, rowstride_out,
+                            int(with_srgb))
+
+
+class SmolScaleCtx:
+    """smol_scale_new() / smol_scale_batch() / smol_scale_destroy() of include/smolscale.h."""
+
+    def __init__(self, pixels_in, pixel_type_in, width_in, height_in, rowstride_in,
+                 pixels_out, pixel_type_out, width_out, height_out, rowstride_out,
+                 with_srgb=0, post_row_func=None, user_data=None):
+        self._src = _as_u8(pixels_in)
+        self._dst = None if pixels_out is None else pixels_out.view(np.uint8).reshape(-1)
+        self._cb = POST_ROW_FUNC(post_row_func) if post_row_func else None
+        dst_ptr = None if self._dst is None else self._dst.ctypes.data
+        if self._cb:
+            self._ctx = lib().smol_scale_new_full(
+                self._src.ctypes.data, pixel_type_in, width_in, height_in, rowstride_in,
+                dst_ptr, pixel_type_out, width_out, height_out, rowstride_out, int(with_srgb),
+                ctypes.cast(self._cb, _vp), user_data)
+        else:
+            self._ctx = lib().smol_scale_new(
+                self._src.ctypes.data, pixel_type_in, width_in, height_in, rowstride_in,
+                dst_ptr, pixel_type_out, width_out, height_out, rowstride_out, int(with_srgb))
+        self.rowstride_out = rowstride_out
+
+    def batch(self, first_outrow, n_outrows):
+        lib().smol_scale_batch(self._ctx, first_outrow, n_outrows)
+
+    def batch_full(self, outrows_dest, first_outrow, n_outrows):
+        dst = outrows_dest.view(np.uint8).reshape(-1)
+        lib().smol_scale_batch_full(self._ctx, dst.ctypes.data, first_outrow, n_outrows)
+
+    def destroy(self):
+        if self._ctx:
+            lib().smol_scale_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+
+class HipBatch:
+    """smol_hip_batch_*() of include/smol_hip.h: many images (device pointers), few launches."""
+
+    def __init__(self, images, device=0):
+        arr = (SmolHipImage * len(images))(*images)
+        self._h = _vp()
+        check(lib().smol_hip_batch_create(arr, len(images), device, ctypes.byref(self._h)),
+              "smol_hip_batch_create")
+
+    def launch(self, stream=None):
+        check(lib().smol_hip_batch_launch(self._h, stream), "smol_hip_batch_launch")
+
+    def time(self, warmup, iters):
+        ms = ctypes.c_float(0)
+        check(lib().smol_hip_batch_time(self._h, warmup, iters, ctypes.byref(ms)), "smol_hip_batch_time")
+        return ms.value
+
+    def info(self):
+        n = _u32(0)
+        name = ctypes.c_char_p()
+        check(lib().smol_hip_batch_info(self._h, ctypes.byref(n), ctypes.byref(name)), "smol_hip_batch_info")
+        return n.value, (name.value or b"").decode()
+
+    def destroy(self):
+        if self._h:
+            lib().smol_hip_batch_destroy(self._h)
+            self._h = None
+
+
+class DeviceBuffer:
+    """Raw device memory through smol_hip_malloc()/free() (for hosts without a HIP binding)."""
+
+    def __init__(self, n_bytes, device=0):
+        self.device = device
+        self.n_bytes = int(n_bytes)
+        p = _vp()
+        check(lib().smol_hip_malloc(device, self.n_bytes, ctypes.byref(p)), "smol_hip_malloc")
+        self.ptr = p.value
+
+    def upload(self, host, offset=0):
+        h = _as_u8(host)
+        check(lib().smol_hip_memcpy_h2d(self.device, self.ptr + offset, h.ctypes.data, h.size), "h2d")
+
+    def download(self, n_bytes=None, offset=0):
+        n = self.n_bytes - offset if n_bytes is None else n_bytes
+        out = np.empty(n, np.uint8)
+        check(lib().smol_hip_memcpy_d2h(self.device, out.ctypes.data, self.ptr + offset, n), "d2h")
+        return out
+
+    def fill(self, value):
+        check(lib().smol_hip_memset(self.device, self.ptr, value, self.n_bytes), "memset")
+
+    def free(self):
+        if self.ptr:
+            lib().smol_hip_free(self.device, self.ptr)
+            self.ptr = None

@@ -1,0 +1,23 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """Oracle + product libraries are built in-tree; (re)build if missing."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libsmol_oracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"])
+    if not os.path.exists(os.path.join(ROOT, "smolscale_amd", "libsmolscale_amd.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "smolscale_amd", "csrc")])
+    yield

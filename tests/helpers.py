@@ -152,127 +152,71 @@ def fnv1a(buf, row_bytes, height, stride):
 
 
 # --------------------------------------------------------------------------- #
-# Product library (C-ABI of include/smol_hip.h + include/smolscale.h)          #
+# Product library (C-ABI of include/smol_hip.h + include/smolscale.h) through   #
+# the package's own ctypes binding                                              #
 # --------------------------------------------------------------------------- #
 
-PRODUCT_SO = os.path.join(ROOT, "smolscale_amd", "libsmolscale_amd.so")
+import sys
+
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import smolscale_amd as sm  # noqa: E402
+from smolscale_amd import SmolHipJob, SmolHipImage  # noqa: E402,F401
+
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libsmol_emu.so")
 
 FILTER_COPY, FILTER_ONE, FILTER_BILINEAR, FILTER_BOX = 0, 1, 2, 3
 
 
-class SmolHipJob(ctypes.Structure):
-    _fields_ = [
-        ("width_in", _u32), ("height_in", _u32), ("width_out", _u32), ("height_out", _u32),
-        ("pixel_type_in", ctypes.c_uint8), ("pixel_type_out", ctypes.c_uint8),
-        ("filter_h", ctypes.c_uint8), ("filter_v", ctypes.c_uint8),
-        ("halvings_h", ctypes.c_uint8), ("halvings_v", ctypes.c_uint8),
-        ("wide", ctypes.c_uint8), ("premul16", ctypes.c_uint8),
-        ("linear", ctypes.c_uint8), ("quirk24", ctypes.c_uint8),
-        ("reserved", ctypes.c_uint8 * 2),
-        ("span_mul_x", _u32), ("span_mul_y", _u32),
-        ("frac0_x", ctypes.c_uint64), ("step_x", ctypes.c_uint64),
-        ("frac0_y", ctypes.c_uint64), ("step_y", ctypes.c_uint64),
-    ]
-
-
-class SmolHipImage(ctypes.Structure):
-    _fields_ = [
-        ("job", SmolHipJob), ("src", _vp), ("dst", _vp),
-        ("rowstride_in", _u32), ("rowstride_out", _u32),
-        ("first_row", _u32), ("n_rows", _u32),
-    ]
-
-
-_product = None
-
-
 def product():
-    global _product
-    if _product is None:
-        if not os.path.exists(PRODUCT_SO):
-            raise RuntimeError("libsmolscale_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        lib = ctypes.CDLL(PRODUCT_SO)
-        lib.smol_hip_plan_job.argtypes = [_u32] * 7 + [ctypes.POINTER(SmolHipJob)]
-        lib.smol_hip_plan_job.restype = ctypes.c_int
-        lib.smol_hip_input_row_range.argtypes = [ctypes.POINTER(SmolHipJob), _u32, _u32,
-                                                 ctypes.POINTER(_u32), ctypes.POINTER(_u32)]
-        lib.smol_hip_input_row_range.restype = ctypes.c_int
-        lib.smol_hip_bilinear_sample.argtypes = [ctypes.c_uint64, ctypes.c_uint64, _u32, _u32,
-                                                 ctypes.POINTER(_u32), ctypes.POINTER(_u32)]
-        lib.smol_hip_bilinear_sample.restype = None
-        lib.smol_hip_box_span.argtypes = [ctypes.c_uint64, _u32, _u32] + [ctypes.POINTER(_u32)] * 4
-        lib.smol_hip_box_span.restype = None
-        lib.smol_hip_strerror.argtypes = [ctypes.c_int]
-        lib.smol_hip_strerror.restype = ctypes.c_char_p
-        lib.smol_hip_device_count.restype = ctypes.c_int
-        lib.smol_hip_plan_create.argtypes = [ctypes.POINTER(SmolHipJob), ctypes.c_int, ctypes.POINTER(_vp)]
-        lib.smol_hip_plan_create.restype = ctypes.c_int
-        lib.smol_hip_plan_destroy.argtypes = [_vp]
-        lib.smol_hip_plan_destroy.restype = None
-        lib.smol_hip_scale_rows_host.argtypes = [_vp, _vp, _u32, _vp, _u32, _u32, _u32]
-        lib.smol_hip_scale_rows_host.restype = ctypes.c_int
-        lib.smol_hip_scale_rows_device.argtypes = [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp]
-        lib.smol_hip_scale_rows_device.restype = ctypes.c_int
-        lib.smol_hip_batch_create.argtypes = [ctypes.POINTER(SmolHipImage), _u32, ctypes.c_int, ctypes.POINTER(_vp)]
-        lib.smol_hip_batch_create.restype = ctypes.c_int
-        lib.smol_hip_batch_launch.argtypes = [_vp, _vp]
-        lib.smol_hip_batch_launch.restype = ctypes.c_int
-        lib.smol_hip_batch_info.argtypes = [_vp, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_char_p)]
-        lib.smol_hip_batch_info.restype = ctypes.c_int
-        lib.smol_hip_batch_destroy.argtypes = [_vp]
-        lib.smol_hip_batch_destroy.restype = None
-        lib.smol_hip_batch_time.argtypes = [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]
-        lib.smol_hip_batch_time.restype = ctypes.c_int
-        lib.smol_hip_malloc.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(_vp)]
-        lib.smol_hip_malloc.restype = ctypes.c_int
-        lib.smol_hip_free.argtypes = [ctypes.c_int, _vp]
-        lib.smol_hip_free.restype = ctypes.c_int
-        lib.smol_hip_memcpy_h2d.argtypes = [ctypes.c_int, _vp, _vp, ctypes.c_uint64]
-        lib.smol_hip_memcpy_h2d.restype = ctypes.c_int
-        lib.smol_hip_memcpy_d2h.argtypes = [ctypes.c_int, _vp, _vp, ctypes.c_uint64]
-        lib.smol_hip_memcpy_d2h.restype = ctypes.c_int
-        lib.smol_hip_memset.argtypes = [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_uint64]
-        lib.smol_hip_memset.restype = ctypes.c_int
-        lib.smol_hip_device_synchronize.argtypes = [ctypes.c_int]
-        lib.smol_hip_device_synchronize.restype = ctypes.c_int
-        # public API (include/smolscale.h)
-        lib.smol_scale_simple.argtypes = [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, ctypes.c_uint8]
-        lib.smol_scale_simple.restype = None
-        lib.smol_scale_new.argtypes = lib.smol_scale_simple.argtypes
-        lib.smol_scale_new.restype = _vp
-        lib.smol_scale_new_full.argtypes = lib.smol_scale_simple.argtypes + [_vp, _vp]
-        lib.smol_scale_new_full.restype = _vp
-        lib.smol_scale_destroy.argtypes = [_vp]
-        lib.smol_scale_destroy.restype = None
-        lib.smol_scale_batch.argtypes = [_vp, _u32, _u32]
-        lib.smol_scale_batch.restype = None
-        lib.smol_scale_batch_full.argtypes = [_vp, _vp, _u32, _u32]
-        lib.smol_scale_batch_full.restype = None
-        _product = lib
-    return _product
+    return sm.lib()
 
 
 def plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb=0):
-    job = SmolHipJob()
-    rc = product().smol_hip_plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb, ctypes.byref(job))
-    assert rc == 0, rc
-    return job
+    return sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
 
 
 def hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb=0,
               stride_in=None, stride_out=None, first=0, n=None, fill=0xA5):
-    """Through the public smol_scale_new()/smol_scale_batch_full() API (host pointers)."""
+    """HIP path through the public smol_scale_new()/smol_scale_batch_full() C API
+    (host pointers in, host pointers out)."""
     stride_in = stride_in or w_in * bpp(t_in)
     stride_out = stride_out or w_out * bpp(t_out)
     n = h_out - first if n is None else n
     dst = np.full(n * stride_out, fill, dtype=np.uint8)
-    lib = product()
-    ctx = lib.smol_scale_new(src.ctypes.data, t_in, w_in, h_in, stride_in,
-                             None, t_out, w_out, h_out, stride_out, srgb)
-    lib.smol_scale_batch_full(ctx, dst.ctypes.data, first, n)
-    lib.smol_scale_destroy(ctx)
+    ctx = sm.SmolScaleCtx(src, t_in, w_in, h_in, stride_in, None, t_out, w_out, h_out, stride_out, srgb)
+    ctx.batch_full(dst, first, n)
+    ctx.destroy()
     return dst
+
+
+def hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb=0,
+                     stride_in=None, stride_out=None, first=0, n=None, fill=0xA5,
+                     src_misalign=0, dst_misalign=0, device=0):
+    """HIP path through smol_hip_scale_rows_device(): caller-owned device buffers with
+    the caller's own strides/alignment (what a zero-copy pipeline would hand over)."""
+    import ctypes as C
+    stride_in = stride_in or w_in * bpp(t_in)
+    stride_out = stride_out or w_out * bpp(t_out)
+    n = h_out - first if n is None else n
+    lib = sm.lib()
+    dsrc = sm.DeviceBuffer(src.size + 64, device)
+    ddst = sm.DeviceBuffer(n * stride_out + 64, device)
+    ddst.fill(fill)
+    dsrc.upload(src, offset=src_misalign)
+    job = plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+    plan = C.c_void_p()
+    sm.check(lib.smol_hip_plan_create(C.byref(job), device, C.byref(plan)), "plan_create")
+    sm.check(lib.smol_hip_scale_rows_device(plan, dsrc.ptr + src_misalign, stride_in,
+                                            ddst.ptr + dst_misalign, stride_out, first, n, None),
+             "scale_rows_device")
+    sm.check(lib.smol_hip_device_synchronize(device), "sync")
+    out = ddst.download(n * stride_out, offset=dst_misalign)
+    lib.smol_hip_plan_destroy(plan)
+    dsrc.free()
+    ddst.free()
+    return out
 
 
 _emu = None
@@ -308,3 +252,19 @@ def emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb=0,
 
 def rows_view(buf, h, row_bytes, stride):
     return np.lib.stride_tricks.as_strided(buf, (h, row_bytes), (stride, 1))
+
+
+def aligned_copy(buf, align=16):
+    """Copy of `buf` whose first byte sits on an `align`-byte boundary."""
+    raw = np.zeros(buf.size + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    out = raw[off:off + buf.size]
+    out[:] = buf
+    return out
+
+
+def have_gpu():
+    try:
+        return sm.lib().smol_hip_device_count() > 0
+    except Exception:
+        return False

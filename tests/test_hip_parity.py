@@ -1,0 +1,229 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle on the
+same seeded inputs, and against the committed golden vectors. Bit-exact: the path
+is integer fixed-point, so the tolerance is zero bytes."""
+import ctypes
+import random
+import threading
+
+import numpy as np
+import pytest
+
+import cases as C
+import helpers as H
+import smolscale_amd as sm
+from test_oracle_vs_reference import random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(got, want, h, row_bytes, stride, ctx):
+    if np.array_equal(got, want):
+        return
+    G, W = H.rows_view(got, h, row_bytes, stride), H.rows_view(want, h, row_bytes, stride)
+    nz = np.argwhere(G != W)
+    if len(nz) == 0:
+        raise AssertionError("row padding bytes were modified: %r" % (ctx,))
+    raise AssertionError("%r: %d differing bytes, first at row %d byte %d: got %d want %d"
+                         % (ctx, len(nz), nz[0][0], nz[0][1], G[tuple(nz[0])], W[tuple(nz[0])]))
+
+
+def test_gpu_present_and_native_library_loaded():
+    assert sm.lib().smol_hip_device_count() >= 1
+    assert H.os.path.exists(sm.LIB_PATH)
+
+
+def test_golden_matrix_every_type_pair_and_filter_class():
+    """2800 reference-captured vectors: 10x10 type pairs x srgb x 14 geometry classes."""
+    n = 0
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb, seed, valid), want in C.matrix_cases():
+        src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        n += 1
+    assert n == 2800
+
+
+def test_random_sweep_vs_oracle_host_pointers():
+    rng = random.Random(4242)
+    for it in range(250):
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout = random_case(rng, 600_000)
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=16)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        assert_same(got, want, n, w_out * H.bpp(t_out), sout,
+                    (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n))
+
+
+def test_random_sweep_vs_oracle_device_pointers_unaligned():
+    """Caller-owned device buffers with odd strides and misaligned bases."""
+    rng = random.Random(777)
+    for it in range(120):
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout = random_case(rng, 300_000)
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=16)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n,
+                                 src_misalign=rng.choice([0, 1, 2, 3, 5, 8]), dst_misalign=rng.choice([0, 1, 2, 3, 4]))
+        assert_same(got, want, n, w_out * H.bpp(t_out), sout,
+                    (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n))
+
+
+def test_pow2_fast_path_vs_oracle():
+    rng = random.Random(31)
+    for it in range(60):
+        hx, hy = rng.randrange(3), rng.randrange(3)
+        w_out = rng.choice([2, 4, 6, 64, 66, 130, 256, 300, 514, 1024])
+        h_out = rng.randint(1, 40)
+        w_in, h_in = w_out << (hx + 1), h_out << (hy + 1)
+        t_in, t_out = rng.randrange(4), rng.randrange(4)
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), pad=16)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out)
+        assert np.array_equal(got, want), (hx, hy, w_out, h_out, t_in, t_out)
+
+
+def test_strip_split_determinism():
+    """Any partition of the output rows gives the one-shot bytes."""
+    rng = random.Random(9)
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
+            (0, 640, 480, 0, 320, 240, 0), (4, 200, 150, 0, 333, 401, 0), (0, 900, 700, 5, 90, 70, 0),
+            (8, 513, 300, 2, 64, 300, 0), (6, 128, 128, 7, 32, 32, 1), (0, 700, 3000, 0, 2, 3, 0)):
+        src = H.make_input(t_in, w_in, h_in, seed=3, valid=False, pad=16)
+        full = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(full, H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb))
+        stride = w_out * H.bpp(t_out)
+        cuts = sorted(set([0, h_out] + [rng.randint(0, h_out) for _ in range(6)]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            part = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, first=a, n=b - a)
+            assert np.array_equal(part, full[a * stride:b * stride]), (t_in, t_out, a, b)
+
+
+def test_baseline_configs_against_golden_digests():
+    g = C.load_golden("baseline.npz")
+    for name in ("C1", "C2", "C3", "C5", "BOX", "C4"):
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb, valid, stride_in = [int(v) for v in g[name + "_params"]]
+        src = H.make_input(t_in, w_in, h_in, seed=0, valid=bool(valid), stride=stride_in, pad=16)
+        out = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, stride_in=stride_in)
+        bo = H.bpp(t_out)
+        assert H.fnv1a(out, w_out * bo, h_out, w_out * bo) == int(g[name + "_fnv"][0]), name
+        cw, ch = min(64, w_out), min(64, h_out)
+        x0, y0 = (w_out - cw) // 2, (h_out - ch) // 2
+        rows = H.rows_view(out, h_out, w_out * bo, w_out * bo)
+        assert np.array_equal(rows[y0:y0 + ch, x0 * bo:(x0 + cw) * bo], g[name + "_crop"]), name
+        del src, out
+
+
+def test_north_star_config_full_frame_vs_oracle():
+    """4096^2 -> 1024^2 RGBA8 premultiplied, every byte, plus linearity-free properties."""
+    src = H.make_input(0, 4096, 4096, seed=5, valid=True, pad=16)
+    want = H.oracle_scale(src, 0, 4096, 4096, 0, 1024, 1024)
+    got = H.hip_scale(src, 0, 4096, 4096, 0, 1024, 1024)
+    assert np.array_equal(got, want)
+    # solid colour stays that colour (test.c:1128-1192 invariant), idempotent channel swap
+    solid = np.tile(np.array([4, 5, 6, 7], np.uint8), 4096 * 4096)
+    out = H.hip_scale(solid, 2, 4096, 4096, 2, 1024, 1024)
+    assert np.array_equal(out.reshape(-1, 4), np.tile(np.array([4, 5, 6, 7], np.uint8), (1024 * 1024, 1)))
+
+
+def test_solid_colour_invariant_all_filter_classes():
+    """test.c:1194-1298 restated on a pruned grid: premultiplied ARGB solids (i,i+1,i+2,i+3)."""
+    sizes = [(1, 1, 5, 5), (7, 7, 7, 7), (300, 200, 640, 480), (640, 480, 320, 240), (1000, 900, 300, 250),
+             (1000, 1000, 130, 140), (4096, 64, 448, 7), (2000, 600, 3, 2), (65535, 2, 1, 1), (2, 65535, 1, 7)]
+    for (w_in, h_in, w_out, h_out) in sizes:
+        for i in (0, 60, 128, 252):
+            px = np.array([i + 3, i, i + 1, i + 2], np.uint8)      # A first; colour <= alpha
+            src = np.concatenate([np.tile(px, w_in * h_in), np.zeros(16, np.uint8)])
+            out = H.hip_scale(src, H.ARGB8_P, w_in, h_in, H.ARGB8_P, w_out, h_out)
+            want = H.oracle_scale(src, H.ARGB8_P, w_in, h_in, H.ARGB8_P, w_out, h_out)
+            assert np.array_equal(out, want)
+            assert np.array_equal(out.reshape(-1, 4), np.tile(px, (w_out * h_out, 1))), (w_in, h_in, w_out, h_out, i)
+
+
+def test_batched_images_mixed_types_single_call():
+    """Config 5 shape: many 256^2 -> 64^2 thumbnails with mixed pixel types in one batch."""
+    rng = random.Random(55)
+    n_img = 48
+    lib = sm.lib()
+    specs, srcs, images, dbufs = [], [], [], []
+    for i in range(n_img):
+        t_in, t_out = rng.randrange(10), rng.randrange(10)
+        src = H.make_input(t_in, 256, 256, seed=i, valid=True, pad=16)
+        dsrc = sm.DeviceBuffer(src.size)
+        dsrc.upload(src)
+        ddst = sm.DeviceBuffer(64 * 64 * H.bpp(t_out))
+        ddst.fill(0)
+        im = sm.SmolHipImage()
+        im.job = H.plan_job(t_in, 256, 256, t_out, 64, 64, 0)
+        im.src, im.dst = dsrc.ptr, ddst.ptr
+        im.rowstride_in, im.rowstride_out = 256 * H.bpp(t_in), 64 * H.bpp(t_out)
+        im.first_row, im.n_rows = 0, 64
+        specs.append((t_in, t_out))
+        srcs.append(src)
+        images.append(im)
+        dbufs.append((dsrc, ddst))
+    batch = sm.HipBatch(images)
+    n_launches, name = batch.info()
+    assert 1 <= n_launches <= 3 and name
+    batch.launch()
+    sm.check(lib.smol_hip_device_synchronize(0))
+    for (t_in, t_out), src, (dsrc, ddst) in zip(specs, srcs, dbufs):
+        want = H.oracle_scale(src, t_in, 256, 256, t_out, 64, 64)
+        assert np.array_equal(ddst.download(), want), (t_in, t_out)
+        dsrc.free()
+        ddst.free()
+    batch.destroy()
+
+
+def test_post_row_callback_runs_per_row_in_order():
+    seen = []
+
+    def cb(row, width, user):
+        seen.append(width)
+        row[0] = 0x11223344
+
+    src = H.make_input(0, 64, 48, seed=1, pad=16)
+    dst = np.zeros(32 * 24 * 4, np.uint8)
+    ctx = sm.SmolScaleCtx(src, 0, 64, 48, 256, dst, 0, 32, 24, 128, 0, post_row_func=cb)
+    ctx.batch(0, 24)
+    ctx.destroy()
+    want = H.oracle_scale(src, 0, 64, 48, 0, 32, 24).reshape(24, 128).copy()
+    want[:, 0:4] = np.frombuffer(np.uint32(0x11223344).tobytes(), np.uint8)
+    assert seen == [32] * 24
+    assert np.array_equal(dst.reshape(24, 128), want)
+
+
+def test_smol_scale_simple_and_batch_write_in_place():
+    src = H.make_input(1, 300, 200, seed=2, pad=16)
+    dst = np.full(100 * 77 * 4, 0x5a, np.uint8)
+    sm.smol_scale_simple(src, 1, 300, 200, 1200, dst, 3, 100, 77, 400, 0)
+    assert np.array_equal(dst, H.oracle_scale(src, 1, 300, 200, 3, 100, 77))
+
+
+def test_concurrent_batches_on_one_context():
+    """smolscale.h:71-73: concurrent smol_scale_batch() on disjoint rows of one ctx."""
+    src = H.make_input(0, 1600, 1200, seed=9, pad=16)
+    dst = np.zeros(400 * 300 * 4, np.uint8)
+    ctx = sm.SmolScaleCtx(src, 0, 1600, 1200, 6400, dst, 0, 400, 300, 1600, 0)
+    n_threads = 8
+    rows = (300 + n_threads - 1) // n_threads          # test.c:870 strip rule
+    threads = [threading.Thread(target=ctx.batch, args=(i * rows, min(rows, 300 - i * rows)))
+               for i in range(n_threads) if i * rows < 300]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    ctx.destroy()
+    assert np.array_equal(dst, H.oracle_scale(src, 0, 1600, 1200, 0, 400, 300))
+
+
+def test_edge_sizes():
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
+            (0, 1, 1, 0, 1, 1, 0), (8, 1, 1, 9, 65535, 1, 0), (0, 2, 1, 0, 1, 1, 1), (4, 65535, 1, 4, 1, 1, 1),
+            (0, 65535, 3, 0, 65535, 3, 0), (9, 2, 2, 5, 3, 3, 1), (0, 3, 65535, 8, 3, 1, 0)):
+        src = H.make_input(t_in, w_in, h_in, seed=w_in, valid=False, pad=16)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)), \
+            (t_in, w_in, h_in, t_out, w_out, h_out, srgb)

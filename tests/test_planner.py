@@ -1,0 +1,147 @@
+"""Product planner (smolscale_amd/csrc/smol_plan.c, through the C-ABI) against the
+oracle's restatement of the reference planner and its sampling tables. CPU only."""
+import ctypes
+import random
+
+import numpy as np
+
+import cases as C
+import helpers as H
+
+FILTER_TO_REF = {H.FILTER_COPY: 0, H.FILTER_ONE: 1, H.FILTER_BOX: 9}
+
+
+def ref_filter_id(f, halvings):
+    return 2 + halvings if f == H.FILTER_BILINEAR else FILTER_TO_REF[f]
+
+
+def check_against_oracle(t_in, w_in, h_in, t_out, w_out, h_out, srgb):
+    job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+    orc = H.OraclePlan()
+    assert H.oracle().smol_oracle_plan(t_in, w_in, h_in, t_out, w_out, h_out, srgb, ctypes.byref(orc)) == 0
+    key = (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+    assert ref_filter_id(job.filter_h, job.halvings_h) == orc.filter_h, key
+    assert ref_filter_id(job.filter_v, job.halvings_v) == orc.filter_v, key
+    assert job.wide == (orc.storage_type == 3), key
+    assert job.linear == orc.gamma_type, key
+    assert job.premul16 == orc.premul16, key
+    assert job.quirk24 == orc.quirk24, key
+    if job.filter_h == H.FILTER_BOX:
+        assert job.span_mul_x == orc.span_mul_x, key
+    if job.filter_v == H.FILTER_BOX:
+        assert job.span_mul_y == orc.span_mul_y, key
+    return job
+
+
+def test_planner_decisions_random():
+    rng = random.Random(99)
+    for _ in range(6000):
+        def d():
+            i = rng.choice([1, 2, 3, rng.randint(1, 70), rng.randint(1, 65535), 65535])
+            o = rng.choice([1, 2, rng.randint(1, 70), rng.randint(1, 65535), max(1, i // 8), max(1, i // 255),
+                            max(1, i // 8191), 65535])
+            return i, o
+        (w_in, w_out), (h_in, h_out) = d(), d()
+        check_against_oracle(rng.randrange(10), w_in, h_in, rng.randrange(10), w_out, h_out, rng.randrange(2))
+
+
+def test_planner_matches_golden_reference_tuples():
+    rows = C.load_golden("planner.npz")["rows"]
+    for r in rows:
+        (i, o, t_in, t_out, srgb, fh, st_h, g_h, bil_w, hv_w, mul_x, fv, st_v, g_v, bil_h, hv_h, mul_y) = [int(v) for v in r]
+        job = H.plan_job(t_in, i, 3, t_out, o, 3, srgb)
+        assert ref_filter_id(job.filter_h, job.halvings_h) == fh, (i, o)
+        assert job.wide == (st_h == 3) and job.linear == g_h
+        if fh == 9:
+            assert job.span_mul_x == mul_x
+        if 2 <= fh <= 8:
+            assert (o << job.halvings_h) == bil_w
+        job = H.plan_job(t_in, 3, i, t_out, 3, o, srgb)
+        assert ref_filter_id(job.filter_v, job.halvings_v) == fv, (i, o)
+        assert job.wide == (st_v == 3) and job.linear == g_v
+        if fv == 9:
+            assert job.span_mul_y == mul_y
+
+
+def test_baseline_config_filter_classes():
+    """SURVEY 8a1 [measured]: none of the five BASELINE configs is a box filter."""
+    j = H.plan_job(H.RGBA8_P, 640, 480, H.RGBA8_P, 320, 240)
+    assert (j.filter_h, j.halvings_h, j.filter_v, j.halvings_v, j.wide) == (H.FILTER_BILINEAR, 0, H.FILTER_BILINEAR, 0, 0)
+    j = H.plan_job(H.RGBA8_P, 4096, 4096, H.RGBA8_P, 1024, 1024)
+    assert (j.filter_h, j.halvings_h, j.filter_v, j.halvings_v, j.wide) == (H.FILTER_BILINEAR, 1, H.FILTER_BILINEAR, 1, 0)
+    j = H.plan_job(H.RGBA8_U, 1920, 1080, H.RGBA8_P, 7680, 4320)
+    assert (j.filter_h, j.halvings_h, j.filter_v, j.halvings_v, j.wide) == (H.FILTER_BILINEAR, 0, H.FILTER_BILINEAR, 0, 0)
+    j = H.plan_job(H.RGB8, 65535, 4096, H.RGBA8_P, 8192, 4096)
+    assert (j.filter_h, j.halvings_h, j.filter_v, j.wide) == (H.FILTER_BILINEAR, 2, H.FILTER_COPY, 0)
+    j = H.plan_job(H.RGBA8_P, 256, 256, H.RGBA8_P, 64, 64)
+    assert (j.filter_h, j.halvings_h, j.filter_v, j.halvings_v) == (H.FILTER_BILINEAR, 1, H.FILTER_BILINEAR, 1)
+    j = H.plan_job(H.RGBA8_P, 4096, 4096, H.RGBA8_P, 448, 448)
+    assert (j.filter_h, j.filter_v, j.wide, j.span_mul_x) == (H.FILTER_BOX, H.FILTER_BOX, 0, 1836133)
+
+
+def _closed_form_axis(job_step, job_frac0, filt, halv, dim_in, dim_out):
+    """Expand the closed form into the reference's table layout (absolute offsets)."""
+    lib = H.product()
+    a, b, c, d = (ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32())
+    out = []
+    if filt == H.FILTER_BILINEAR:
+        for j in range(dim_out << halv):
+            lib.smol_hip_bilinear_sample(job_frac0, job_step, dim_in, j, ctypes.byref(a), ctypes.byref(b))
+            out += [a.value, b.value]
+    elif filt == H.FILTER_BOX:
+        last = 0
+        for k in range(dim_out):
+            lib.smol_hip_box_span(job_step, dim_in, k, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d))
+            out += [a.value, c.value]
+            last = b.value
+            if k:
+                # left weight is 255 - previous F
+                assert d.value == 255 - out[2 * (k - 1) + 1]
+            else:
+                assert d.value == 256
+        out += [last, 0]
+    return np.array(out, np.uint16)
+
+
+def test_closed_form_sampling_equals_reference_tables():
+    """The kernels never see the reference's uint16 tables; their closed form must
+    expand to exactly those tables (vertical layout = absolute offsets)."""
+    rng = random.Random(4)
+    dims = [(640, 320), (4096, 1024), (1920, 7680), (1080, 4320), (65535, 8192), (4096, 448), (65535, 1),
+            (65535, 65534), (2, 65535), (65534, 65535), (300, 7), (9, 1), (17, 2), (2, 2), (3, 2), (2, 3)]
+    dims += [(rng.randint(2, 6000), rng.randint(1, 6000)) for _ in range(300)]
+    dims += [(rng.randint(2, 65535), rng.randint(1, 65535)) for _ in range(40)]
+    buf = np.zeros(140000, np.uint16)
+    for (i, o) in dims:
+        job = H.plan_job(0, 3, i, 0, 3, o, 0)
+        if job.filter_v in (H.FILTER_COPY, H.FILTER_ONE):
+            continue
+        n = H.oracle().smol_oracle_precalc(3, i, 3, o, 1, buf.ctypes.data, buf.size)
+        mine = _closed_form_axis(job.step_y, job.frac0_y, job.filter_v, job.halvings_v, i, o)
+        assert n == mine.size, (i, o)
+        assert np.array_equal(buf[:n], mine), (i, o)
+
+
+def test_input_row_range_is_tight_and_sufficient():
+    rng = random.Random(8)
+    buf = np.zeros(140000, np.uint16)
+    for _ in range(300):
+        i, o = rng.randint(1, 3000), rng.randint(1, 3000)
+        job = H.plan_job(0, 3, i, 0, 3, o, 0)
+        first = rng.randint(0, o - 1)
+        n = rng.randint(1, o - first)
+        r0, r1 = H.sm.input_row_range(job, first, n)
+        assert 0 <= r0 <= r1 <= i - 1
+        if job.filter_v == H.FILTER_COPY:
+            assert (r0, r1) == (first, first + n - 1)
+        elif job.filter_v == H.FILTER_ONE:
+            assert (r0, r1) == (0, 0)
+        else:
+            cnt = H.oracle().smol_oracle_precalc(3, i, 3, o, 1, buf.ctypes.data, buf.size)
+            tab = buf[:cnt].reshape(-1, 2)
+            if job.filter_v == H.FILTER_BILINEAR:
+                h = job.halvings_v
+                rows = tab[first << h:(first + n) << h, 0].astype(int)
+                assert r0 == rows.min() and r1 == rows.max() + 1
+            else:
+                assert r0 == int(tab[first, 0]) and r1 == int(tab[first + n, 0])
