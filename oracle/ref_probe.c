@@ -8,6 +8,7 @@
 
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include "smolscale-private.h"
 
 typedef struct
@@ -104,4 +105,77 @@ const uint32_t *ref_probe_inv_div_lut (int which)
         case 2: return _smol_inv_div_p16_lut;
         default: return _smol_inv_div_p16l_lut;
     }
+}
+
+/* ---- multi-threaded timing driver for bench.py's cpu_baseline leg ------------
+ * The reference's own MT pattern (test.c:838-883): one context, n_threads workers,
+ * worker i produces output rows [i*R, i*R+R) with R = ceil(h_out / n_threads)
+ * through smol_scale_batch(). Here the workers are plain pthreads that each
+ * repeat their strip n_frames times (no per-frame pool setup, which favours the
+ * CPU relative to test.c, whose timing includes creating the pool). Returns wall
+ * seconds for all frames. */
+
+#include <pthread.h>
+#include <time.h>
+
+typedef struct
+{
+    SmolScaleCtx *ctx;
+    uint32_t first, n, n_frames;
+}
+RefMtWorker;
+
+static void *
+ref_mt_worker (void *arg)
+{
+    RefMtWorker *w = arg;
+    uint32_t f;
+
+    for (f = 0; f < w->n_frames; f++)
+        smol_scale_batch (w->ctx, w->first, w->n);
+    return NULL;
+}
+
+double
+ref_probe_mt_time (const void *pixels_in, uint32_t type_in, uint32_t w_in, uint32_t h_in, uint32_t stride_in,
+                   void *pixels_out, uint32_t type_out, uint32_t w_out, uint32_t h_out, uint32_t stride_out,
+                   uint32_t with_srgb, uint32_t n_threads, uint32_t n_frames)
+{
+    SmolScaleCtx *ctx;
+    pthread_t *tids;
+    RefMtWorker *workers;
+    uint32_t rows, i, n_used = 0;
+    struct timespec t0, t1;
+
+    if (n_threads < 1)
+        n_threads = 1;
+    ctx = smol_scale_new (pixels_in, (SmolPixelType) type_in, w_in, h_in, stride_in,
+                          pixels_out, (SmolPixelType) type_out, w_out, h_out, stride_out,
+                          (uint8_t) with_srgb);
+    tids = calloc (n_threads, sizeof (*tids));
+    workers = calloc (n_threads, sizeof (*workers));
+    rows = (h_out + n_threads - 1) / n_threads;
+
+    clock_gettime (CLOCK_MONOTONIC, &t0);
+    for (i = 0; i < n_threads; i++)
+    {
+        uint32_t first = i * rows;
+
+        if (first >= h_out)
+            break;
+        workers [i].ctx = ctx;
+        workers [i].first = first;
+        workers [i].n = (h_out - first < rows) ? h_out - first : rows;
+        workers [i].n_frames = n_frames;
+        pthread_create (&tids [i], NULL, ref_mt_worker, &workers [i]);
+        n_used++;
+    }
+    for (i = 0; i < n_used; i++)
+        pthread_join (tids [i], NULL);
+    clock_gettime (CLOCK_MONOTONIC, &t1);
+
+    free (tids);
+    free (workers);
+    smol_scale_destroy (ctx);
+    return (double) (t1.tv_sec - t0.tv_sec) + (double) (t1.tv_nsec - t0.tv_nsec) * 1e-9;
 }

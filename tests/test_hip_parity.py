@@ -129,17 +129,22 @@ def test_north_star_config_full_frame_vs_oracle():
 
 
 def test_solid_colour_invariant_all_filter_classes():
-    """test.c:1194-1298 restated on a pruned grid: premultiplied ARGB solids (i,i+1,i+2,i+3)."""
+    """test.c:1194-1298 restated on a pruned grid: premultiplied ARGB solids
+    (i,i+1,i+2,i+3). HIP must equal the oracle everywhere; where the reference
+    keeps the colour exactly (all bilinear/copy/one classes), so must HIP."""
     sizes = [(1, 1, 5, 5), (7, 7, 7, 7), (300, 200, 640, 480), (640, 480, 320, 240), (1000, 900, 300, 250),
              (1000, 1000, 130, 140), (4096, 64, 448, 7), (2000, 600, 3, 2), (65535, 2, 1, 1), (2, 65535, 1, 7)]
     for (w_in, h_in, w_out, h_out) in sizes:
+        job = H.plan_job(H.ARGB8_P, w_in, h_in, H.ARGB8_P, w_out, h_out)
+        has_box = H.FILTER_BOX in (job.filter_h, job.filter_v)
         for i in (0, 60, 128, 252):
             px = np.array([i + 3, i, i + 1, i + 2], np.uint8)      # A first; colour <= alpha
             src = np.concatenate([np.tile(px, w_in * h_in), np.zeros(16, np.uint8)])
             out = H.hip_scale(src, H.ARGB8_P, w_in, h_in, H.ARGB8_P, w_out, h_out)
             want = H.oracle_scale(src, H.ARGB8_P, w_in, h_in, H.ARGB8_P, w_out, h_out)
-            assert np.array_equal(out, want)
-            assert np.array_equal(out.reshape(-1, 4), np.tile(px, (w_out * h_out, 1))), (w_in, h_in, w_out, h_out, i)
+            assert np.array_equal(out, want), (w_in, h_in, w_out, h_out, i)
+            if not has_box:
+                assert np.array_equal(out.reshape(-1, 4), np.tile(px, (w_out * h_out, 1))), (w_in, h_in, w_out, h_out, i)
 
 
 def test_batched_images_mixed_types_single_call():
