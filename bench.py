@@ -39,13 +39,6 @@ FRAMES_PER_GPU = 8
 PIX_TYPE = sm.SMOL_PIXEL_RGBA8_PREMULTIPLIED
 
 
-def strip_of(rank, world, h_out):
-    """test.c:870 strip rule: ceil(h_out / n) rows per worker."""
-    rows = (h_out + world - 1) // world
-    first = min(rank * rows, h_out)
-    return first, max(0, min(rows, h_out - first))
-
-
 def cpu_baseline(seconds_budget=12.0):
     """The REAL reference (oracle/_ref, AVX2 build, all host cores, the reference's
     own strip-per-thread pattern test.c:838-883) on a bounded sample of the same
@@ -135,10 +128,9 @@ def main():
 
     # ---- the job and this rank's shard ------------------------------------------------
     job = sm.plan_job(PIX_TYPE, W_IN, H_IN, PIX_TYPE, W_OUT, H_OUT, 0)
-    first_row, n_rows = strip_of(rank, world, H_OUT)
+    first_row, n_rows, r0, r1 = sm.shard(job, rank, world)
     n_frames = FRAMES_PER_GPU * world
     in_stride, out_stride = W_IN * 4, W_OUT * 4
-    r0, r1 = sm.input_row_range(job, first_row, n_rows)
     slab_rows = r1 - r0 + 1
 
     gen = torch.Generator(device=dev)

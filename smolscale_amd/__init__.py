@@ -269,3 +269,25 @@ class DeviceBuffer:
         if self.ptr:
             lib().smol_hip_free(self.device, self.ptr)
             self.ptr = None
+
+
+# --------------------------------------------------------------------------- #
+# Row-range sharding (multi-GPU): no data-path collective, each rank owns a    #
+# strip of output rows and the slab of input rows that strip depends on.       #
+# --------------------------------------------------------------------------- #
+
+def strip_rows(rank, world, height_out):
+    """Output rows of `rank`: the reference's MT strip rule (test.c:870-877),
+    ceil(height_out / world) rows per worker, last strips may be short or empty."""
+    rows = (height_out + world - 1) // world
+    first = min(rank * rows, height_out)
+    return first, max(0, min(rows, height_out - first))
+
+
+def shard(job, rank, world):
+    """(first_row, n_rows, in_row_first, in_row_last) for `rank`; n_rows may be 0."""
+    first, n = strip_rows(rank, world, job.height_out)
+    if n == 0:
+        return first, 0, 0, -1
+    r0, r1 = input_row_range(job, first, n)
+    return first, n, r0, r1
