@@ -60,7 +60,7 @@ launch_pow2_hy (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_
  * the same halvings as `rep'. max_* are maxima over the group. */
 hipError_t
 launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &rep,
-              uint32_t max_w_out, uint32_t max_rows, hipStream_t s)
+              uint32_t max_w_out, uint32_t max_rows, hipStream_t s, uint32_t max_lds = 0)
 {
     if (k == KC_POW2)
     {
@@ -75,6 +75,21 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
             case 1: launch_pow2_hy<1> (jobs_dev, rep, grid, s); break;
             default: launch_pow2_hy<2> (jobs_dev, rep, grid, s); break;
         }
+        return hipGetLastError ();
+    }
+
+    if (k == KC_TILE)
+    {
+        /* groups share tile_rows and LDS size (see smol_hip_batch_create) */
+        const uint32_t tiles_x = (max_w_out + smolhip::TILE_COLS - 1) / smolhip::TILE_COLS;
+        const uint32_t tiles_y = (max_rows + rep.tile_rows - 1) / rep.tile_rows;
+        dim3 grid (tiles_x * tiles_y, n_jobs);
+        const uint32_t lds = max_lds ? max_lds : tile_lds_bytes (rep);
+
+        if (jobs_dev)
+            hipLaunchKernelGGL (smolhip::k_tile_batch, grid, dim3 (64), lds, s, jobs_dev);
+        else
+            hipLaunchKernelGGL (smolhip::k_tile_one, grid, dim3 (64), lds, s, rep);
         return hipGetLastError ();
     }
 
@@ -160,7 +175,7 @@ struct SmolHipBatch
     int device = 0;
     uint32_t n_images = 0;
     JobDev *jobs_dev = nullptr;            /* all jobs, grouped by launch */
-    struct Group { KClass k; uint32_t first, count; JobDev rep; uint32_t max_w_out, max_rows; };
+    struct Group { KClass k; uint32_t first, count; JobDev rep; uint32_t max_w_out, max_rows, max_lds; };
     std::vector<Group> groups;
     uint64_t dominant_units = 0;
     const char *dominant_name = "";
@@ -334,6 +349,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
         g.rep = jobs [i];
         g.max_w_out = 0;
         g.max_rows = 0;
+        g.max_lds = 0;
         uint64_t units = 0;
 
         for (uint32_t j = i; j < n_images; j++)
@@ -342,6 +358,8 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2 && (jobs [j].halv_h != g.rep.halv_h || jobs [j].halv_v != g.rep.halv_v))
                 continue;
+            if (g.k == KC_TILE && jobs [j].tile_rows != g.rep.tile_rows)
+                continue;
             if (g.count == 65535)
                 break;
             taken [j] = true;
@@ -349,6 +367,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             g.count++;
             if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
             if (jobs [j].n_rows > g.max_rows) g.max_rows = jobs [j].n_rows;
+            if (g.k == KC_TILE && tile_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = tile_lds_bytes (jobs [j]);
             units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
         }
 
@@ -386,7 +405,7 @@ smol_hip_batch_launch (SmolHipBatch *batch, void *hip_stream)
 
     HIP_TRY (hipSetDevice (batch->device));
     for (const SmolHipBatch::Group &g : batch->groups)
-        HIP_TRY (launch_class (g.k, batch->jobs_dev + g.first, g.count, g.rep, g.max_w_out, g.max_rows, s));
+        HIP_TRY (launch_class (g.k, batch->jobs_dev + g.first, g.count, g.rep, g.max_w_out, g.max_rows, s, g.max_lds));
     return 0;
 }
 

@@ -30,6 +30,13 @@ struct JobDev
     uint8_t pos_in [4], pos_out [4];   /* byte index of R,G,B,A; 0xff = no alpha         */
     uint8_t unassoc_in, unassoc_out, wide, p16, linear, quirk24;
     uint8_t in_dword_ok, out_dword_ok; /* 4-byte pixels at 4-byte aligned addresses      */
+    /* k_tile geometry (filled by tile_setup) */
+    uint8_t tile_aligned4;         /* every staged pixel sits on a 4-byte LDS boundary   */
+    uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
+    uint16_t tile_rows;            /* output rows per tile                               */
+    uint16_t group_rows;           /* source rows staged per LDS phase                   */
+    uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
+    uint32_t span_chunks_inv;      /* floor(2^32 / span_chunks) + 1                      */
 };
 
 namespace dispatch {
@@ -44,9 +51,79 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr uint32_t TILE_LDS_BUDGET = 16 * 1024;     /* bytes of LDS per 64-lane workgroup */
+
+inline bool
+tile_ok (const JobDev &d)
+{
+    if (d.wide)
+        return false;
+    return d.filter_h != F_BOX && d.filter_v != F_BOX;
+}
+
+/* Geometry of k_tile for this job: how many source pixels a 64-column tile can
+ * span (bound from the closed-form sampling positions), how many source rows fit
+ * one LDS phase, how many output rows a tile produces. */
+inline void
+tile_setup (JobDev &d)
+{
+    if (!tile_ok (d))
+        return;
+
+    uint64_t span_px;
+    if (d.filter_h == F_BILINEAR)
+        span_px = ((((uint64_t) 64 << d.halv_h) * d.step_x) >> 32) + 3;
+    else
+        span_px = (d.filter_h == F_ONE) ? 1 : 64;
+    if (span_px > d.w_in)
+        span_px = d.w_in;
+
+    /* up to 15 bytes of misalignment in front, 8 bytes of slack for the unaligned reader */
+    const uint32_t bytes = (uint32_t) span_px * d.bpp_in + 15 + 8;
+    d.span_chunks = (bytes + 15) / 16;
+    d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / d.span_chunks) + 1;
+
+    uint32_t rows = TILE_LDS_BUDGET / (d.span_chunks * 16);
+    if (rows < 1) rows = 1;
+    if (rows > 16) rows = 16;
+    d.group_rows = (uint16_t) rows;
+
+    uint32_t th;
+    if (d.filter_v == F_BILINEAR)
+        th = (d.step_y < ((uint64_t) 1 << 32)) ? 32 : (16u >> d.halv_v);
+    else
+        th = (d.filter_v == F_ONE) ? 32 : 16;
+    d.tile_rows = (uint16_t) th;
+    d.tile_aligned4 = (d.bpp_in == 4 && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0);
+
+    uint32_t tapsel;
+    if (d.bpp_in == 3)
+        tapsel = 3;
+    else if (!d.tile_aligned4)
+        tapsel = 2;
+    else
+        tapsel = d.unassoc_in ? 1 : 0;
+
+    const uint32_t hm = (d.filter_h == F_BILINEAR) ? 1u + d.halv_h : 0u;
+
+    uint32_t out;
+    if (d.bpp_out == 4 && d.out_dword_ok)
+        out = d.unassoc_out ? 1 : 0;
+    else
+        out = 2;
+
+    d.tile_variant = (uint8_t) ((tapsel << 4) | (hm << 2) | out);
+}
+
+inline uint32_t
+tile_lds_bytes (const JobDev &d)
+{
+    return d.group_rows * d.span_chunks * 16 + 32;
+}
 
 inline void
 fill_jobdev (JobDev &d, const SmolHipJob &j, const void *src, uint32_t src_stride,
@@ -79,14 +156,20 @@ fill_jobdev (JobDev &d, const SmolHipJob &j, const void *src, uint32_t src_strid
     d.in_dword_ok = (ti.bpp == 4 && (((uintptr_t) src | src_stride) & 3) == 0);
     d.out_dword_ok = (to.bpp == 4 && (((uintptr_t) dst | dst_stride) & 3) == 0);
 
-    /* 32bpp -> 32bpp byte shuffle: output byte pos_out[ch] takes input byte pos_in[ch] */
-    if (ti.bpp == 4 && to.bpp == 4)
+    /* byte shuffle from the internal pixel word (bytes in INPUT memory order; a
+     * 24bpp input gets alpha = 0xff as byte 3) to the output memory order */
     {
         uint32_t sel = 0;
         for (int ch = 0; ch < 4; ch++)
-            sel |= (uint32_t) ti.pos [ch] << (8 * to.pos [ch]);
+        {
+            uint32_t from = (ch == 3 && ti.bpp == 3) ? 3u : ti.pos [ch];
+            if (to.pos [ch] != 0xff)
+                sel |= from << (8 * to.pos [ch]);
+        }
         d.out_perm = sel;
     }
+
+    tile_setup (d);
 }
 
 /* Does the job qualify for k_pow2? Exact 2:1/4:1/8:1 on both axes, 32-bit
@@ -118,6 +201,8 @@ classify (const JobDev &d)
 {
     if (pow2_ok (d))
         return KC_POW2;
+    if (tile_ok (d))
+        return KC_TILE;
     return d.wide ? KC_GENERAL_WIDE : KC_GENERAL;
 }
 
@@ -127,6 +212,7 @@ kclass_name (KClass k, const JobDev &d)
     switch (k)
     {
         case KC_POW2: return "k_pow2_batch";
+        case KC_TILE: return "k_tile_batch";
         case KC_GENERAL_WIDE: return "k_general_batch<true>";
         default: return "k_general_batch<false>";
     }

@@ -1,0 +1,436 @@
+/* smol_kernel_tile.hip.h -- k_tile: wave-autonomous tiled kernel for the
+ * 64bpp-class bilinear family (BILINEAR 0-2H / COPY / ONE on either axis, every
+ * pixel-type pair). Included at the end of smol_kernels.hip.h.
+ *
+ * One 64-lane workgroup (= one wave, so __syncthreads() is free) owns 64 output
+ * columns x tile_rows output rows; lane = output column.
+ *
+ *   stage  the source rows a tile needs come into LDS a group at a time through
+ *          16-byte ALIGNED global loads, contiguous across the wave, whatever the
+ *          pixel size or row alignment (24bpp rows with odd strides included):
+ *          each source byte is fetched once per tile. 32-bit unassociated pixels
+ *          on 4-byte boundaries are premultiplied right here, once per pixel
+ *          (smolscale-generic.c:238-244, 415-464);
+ *   H      each lane evaluates its column's horizontal taps from LDS
+ *          (:1290-1425, :1558-1611). Values of this class are 8 bit, so a tap
+ *              q + (((p - q) * F) >> 8)  ==  (p * F + q * (256 - F)) >> 8
+ *          never goes negative and two channels share one register as 16-bit lanes;
+ *   V      source rows arrive in ascending order, so the vertical filter
+ *          (:1648-2007, :2262-2318) runs in registers per column: the lane keeps
+ *          the previous row's H value and emits an output pixel as soon as the
+ *          rows of its last sample have passed.
+ *
+ * The body is a template over (how a pixel is read from LDS, how many horizontal
+ * samples, how a pixel is stored) so that the per-pixel code has no mode
+ * branches; the kernel entry switches once, wave-uniformly, on J.tile_variant. */
+
+#pragma once
+
+namespace smolhip {
+
+constexpr uint32_t TILE_COLS = 64;
+constexpr uint32_t PAIR_MASK = 0x00ff00ffu;
+
+struct Px2 { uint32_t lo, hi; };     /* bytes 0,2 and bytes 1,3 of a pixel, 16-bit lanes */
+
+__device__ __forceinline__ Px2 px2_from_word (uint32_t w)
+{
+    Px2 r;
+    r.lo = w & PAIR_MASK;
+    r.hi = (w >> 8) & PAIR_MASK;
+    return r;
+}
+
+/* (p*F + q*(256-F)) >> 8 per 16-bit lane; products stay below 2^16 per lane */
+__device__ __forceinline__ Px2 tap2 (Px2 p, Px2 q, uint32_t F)
+{
+    const uint32_t G = 256u - F;
+    Px2 r;
+    r.lo = ((__umul24 (p.lo, F) + __umul24 (q.lo, G)) >> 8) & PAIR_MASK;
+    r.hi = ((__umul24 (p.hi, F) + __umul24 (q.hi, G)) >> 8) & PAIR_MASK;
+    return r;
+}
+
+/* unassociated -> premultiplied on a whole pixel word; ain = alpha byte index */
+__device__ __forceinline__ uint32_t premul_word (uint32_t w, uint32_t ain)
+{
+    const uint32_t a = (w >> (8 * ain)) & 0xffu;
+    const uint32_t m = a + 1u;
+    uint32_t lo = w & PAIR_MASK;
+    uint32_t hi = (w >> 8) & PAIR_MASK;
+
+    /* full 32-bit products: (c+1)*(a+1) reaches 2^16 in a lane before the -1, which
+     * is exact modulo 2^32 but would not survive a 24-bit multiply */
+    lo = (((lo + 0x00010001u) * m - 0x00010001u) >> 8) & PAIR_MASK;
+    hi = (((hi + 0x00010001u) * m - 0x00010001u) >> 8) & PAIR_MASK;
+    const uint32_t r = lo | (hi << 8);
+    const uint32_t am = 0xffu << (8 * ain);
+    return (r & ~am) | (w & am);
+}
+
+/* How a lane reads its taps from the staged row */
+enum : int
+{
+    TAP_A4  = 0,    /* 32-bit pixels on 4-byte LDS boundaries, already premultiplied */
+    TAP_U4  = 1,    /* 32-bit pixels at any byte offset; premultiply here if needed  */
+    TAP_U3  = 2     /* 24-bit pixels at any byte offset                              */
+};
+
+/* How an output pixel is stored */
+enum : int
+{
+    OUT_P4 = 0,     /* 32-bit premultiplied, dword-aligned destination  */
+    OUT_U4 = 1,     /* 32-bit unassociated, dword-aligned destination   */
+    OUT_ANY = 2     /* 24-bit, or byte-aligned 32-bit (either alpha)    */
+};
+
+/* Pixel pair (p, q) for one tap. rowb: LDS row base (already offset by the row's
+ * misalignment), off: byte offset of p inside the span, PAIR: q is the next pixel
+ * (bilinear) or p itself (COPY / ONE). */
+template <int TAP, bool PAIR>
+__device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *rowb, uint32_t off,
+                                                uint32_t &wp, uint32_t &wq)
+{
+    if (TAP == TAP_A4)
+    {
+        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + off);
+        wp = pp [0];
+        wq = PAIR ? pp [1] : wp;
+    }
+    else if (TAP == TAP_U4)
+    {
+        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
+        const uint32_t sh = off & 3u;
+        const uint32_t d0 = pp [0], d1 = pp [1];
+        wp = __builtin_amdgcn_alignbyte (d1, d0, sh);
+        if (PAIR)
+            wq = __builtin_amdgcn_alignbyte (pp [2], d1, sh);
+        else
+            wq = wp;
+        if (J.unassoc_in)
+        {
+            wp = premul_word (wp, J.pos_in [3]);
+            wq = PAIR ? premul_word (wq, J.pos_in [3]) : wp;
+        }
+    }
+    else
+    {
+        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
+        const uint32_t sh = off & 3u;
+        const uint32_t d0 = pp [0], d1 = pp [1];
+        const uint32_t b0 = __builtin_amdgcn_alignbyte (d1, d0, sh);      /* bytes 0..3 from p */
+        wp = b0 | 0xff000000u;
+        if (PAIR)
+        {
+            const uint32_t b1 = __builtin_amdgcn_alignbyte (pp [2], d1, sh);  /* bytes 4..7 */
+            wq = __builtin_amdgcn_alignbyte (b1, b0, 3) | 0xff000000u;        /* bytes 3..5 */
+        }
+        else
+        {
+            wq = wp;
+        }
+    }
+}
+
+/* packed pair -> destination pixel (packers of smolscale-generic.c:758-906) */
+template <int OUT>
+__device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint32_t x, Px2 v)
+{
+    uint32_t w = v.lo | (v.hi << 8);             /* bytes in INPUT memory order */
+
+    if (OUT == OUT_U4 || (OUT == OUT_ANY && J.unassoc_out))
+    {
+        const uint32_t ain = (J.bpp_in == 4) ? J.pos_in [3] : 3u;
+        const uint32_t a = (w >> (8 * ain)) & 0xffu;
+        const uint32_t inv = smol_inv_p8_lut [a];
+        uint32_t o = a << (8 * ain);
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++)
+        {
+            if (b != ain)
+                o |= ((__umul24 ((w >> (8 * b)) & 0xffu, inv) >> 13) & 0xffu) << (8 * b);
+        }
+        w = o;
+    }
+
+    w = __builtin_amdgcn_perm (w, w, J.out_perm);
+
+    if (OUT != OUT_ANY)
+    {
+        *reinterpret_cast<uint32_t *> (rowp + (size_t) x * 4) = w;
+    }
+    else if (J.bpp_out == 4)
+    {
+        uint8_t *p = rowp + (size_t) x * 4;
+        p [0] = (uint8_t) w; p [1] = (uint8_t) (w >> 8); p [2] = (uint8_t) (w >> 16); p [3] = (uint8_t) (w >> 24);
+    }
+    else
+    {
+        uint8_t *p = rowp + (size_t) x * 3;
+        p [0] = (uint8_t) w; p [1] = (uint8_t) (w >> 8); p [2] = (uint8_t) (w >> 16);
+    }
+}
+
+/* vertical sample schedule: (row of the top tap, weight) for sample index jy */
+__device__ __forceinline__ void tile_vsample (const JobDev &J, uint32_t jy, uint32_t &oy, uint32_t &F)
+{
+    if (J.filter_v == F_BILINEAR)
+    {
+        bilin_tap (J.frac0_y + (uint64_t) jy * J.step_y, J.h_in, oy, F);
+    }
+    else
+    {
+        oy = (J.filter_v == F_ONE) ? 0u : jy;
+        F = 256u;
+    }
+}
+
+constexpr int TILE_STAGE_UNROLL = 8;
+
+/* TAP: see above. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples per
+ * output column. STAGE_PREMUL: premultiply 32-bit unassociated pixels while
+ * staging (only with TAP_A4). */
+template <int TAP, int HM, int OUT, bool STAGE_PREMUL>
+__device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
+{
+    constexpr bool HPAIR = (HM != 0);
+    constexpr uint32_t NSX = (HM == 0) ? 1u : (1u << (HM - 1));
+    constexpr uint32_t HX = (HM == 0) ? 0u : (uint32_t) (HM - 1);
+    constexpr uint32_t BPP = (TAP == TAP_U3) ? 3u : 4u;
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+    const uint32_t tx = blockIdx.x % tiles_x;
+    const uint32_t ty = blockIdx.x / tiles_x;
+    const uint32_t yrel0 = ty * J.tile_rows;
+
+    if (yrel0 >= J.n_rows)
+        return;
+
+    const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
+    const uint32_t x0 = tx * TILE_COLS;
+    const uint32_t xn = (x0 + TILE_COLS < J.w_out) ? x0 + TILE_COLS : J.w_out;   /* one past last column */
+    const uint32_t x = x0 + lane;
+    const bool active = x < xn;
+    const uint32_t xc = active ? x : xn - 1;
+
+    /* ---- horizontal taps of this lane (same for every row) ----------------- */
+    uint32_t tap_ofs [NSX], tap_f [NSX];
+    uint32_t sx0, sx1;
+
+    if (HPAIR)
+    {
+        uint64_t pos = J.frac0_x + (uint64_t) (xc << HX) * J.step_x;
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+        {
+            bilin_tap (pos, J.w_in, tap_ofs [s], tap_f [s]);
+            pos += J.step_x;
+        }
+        uint32_t f_unused;
+        bilin_tap (J.frac0_x + (uint64_t) (x0 << HX) * J.step_x, J.w_in, sx0, f_unused);
+        bilin_tap (J.frac0_x + (uint64_t) ((xn << HX) - 1) * J.step_x, J.w_in, sx1, f_unused);
+        sx1 += 1;
+    }
+    else
+    {
+        tap_ofs [0] = (J.filter_h == F_ONE) ? 0u : xc;
+        tap_f [0] = 256u;
+        sx0 = (J.filter_h == F_ONE) ? 0u : x0;
+        sx1 = (J.filter_h == F_ONE) ? 0u : xn - 1;
+    }
+
+    const uint32_t g0 = sx0 * BPP;                      /* first byte of the span in a row */
+    const uint32_t g1 = (sx1 + 1) * BPP;                /* one past the last byte          */
+    const uint32_t row_pitch = J.span_chunks * 16u;     /* LDS bytes per staged row        */
+#pragma unroll
+    for (uint32_t s = 0; s < NSX; s++)
+        tap_ofs [s] = (tap_ofs [s] - sx0) * BPP;        /* byte offset inside the span     */
+
+    /* ---- vertical schedule ---------------------------------------------------- */
+    const bool vpair = (J.filter_v == F_BILINEAR);
+    const uint32_t hv = vpair ? J.halv_v : 0u;
+    const uint32_t nsy = 1u << hv;
+    const uint32_t vlag = vpair ? 1u : 0u;
+    uint32_t y = J.first_row + yrel0;                   /* absolute output row being built */
+    const uint32_t y_end = J.first_row + yrel1;
+    uint32_t s_y = 0;                                   /* sample within the output row    */
+    uint32_t oy, Fy;
+    uint32_t row_first, row_last, f_unused2;
+
+    tile_vsample (J, y << hv, oy, Fy);
+    row_first = oy;
+    tile_vsample (J, (y_end << hv) - 1, row_last, f_unused2);
+    row_last += vlag;
+
+    Px2 hprev = { 0, 0 }, acc = { 0, 0 };
+    const size_t src_stride = J.src_stride;
+    const uintptr_t src_base = (uintptr_t) J.src;
+    uint8_t *out_row = J.dst + (size_t) yrel0 * J.dst_stride;
+    const uint32_t ain = J.pos_in [3];
+
+    for (uint32_t gfirst = row_first; gfirst <= row_last; gfirst += J.group_rows)
+    {
+        const uint32_t nrows = (row_last - gfirst + 1 < J.group_rows) ? row_last - gfirst + 1 : J.group_rows;
+        const uint32_t total = nrows * J.span_chunks;
+
+        __syncthreads ();                               /* previous group fully consumed */
+
+        /* ---- stage: aligned 16-byte chunks, TILE_STAGE_UNROLL loads in flight per lane */
+        for (uint32_t c0 = 0; c0 < total; c0 += TILE_COLS * TILE_STAGE_UNROLL)
+        {
+            u32x4 v [TILE_STAGE_UNROLL];
+            bool ok [TILE_STAGE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < TILE_STAGE_UNROLL; u++)
+            {
+                const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
+                const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
+                const uint32_t k = c - i * J.span_chunks;
+                const uintptr_t rb = src_base + (size_t) (gfirst + i) * src_stride;
+                const uintptr_t a0 = (rb + g0) & ~(uintptr_t) 15;
+                const uint32_t nch = (uint32_t) ((rb + g1 - a0 + 15) >> 4);
+
+                ok [u] = (c < total) && (k < nch);
+                if (ok [u])
+                    v [u] = *reinterpret_cast<const u32x4 *> (a0 + (uintptr_t) k * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < TILE_STAGE_UNROLL; u++)
+            {
+                const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
+                if (ok [u])
+                {
+                    if (STAGE_PREMUL)
+                    {
+                        v [u].x = premul_word (v [u].x, ain);
+                        v [u].y = premul_word (v [u].y, ain);
+                        v [u].z = premul_word (v [u].z, ain);
+                        v [u].w = premul_word (v [u].w, ain);
+                    }
+                    *reinterpret_cast<u32x4 *> (sbuf + (size_t) c * 16) = v [u];
+                }
+            }
+        }
+
+        __syncthreads ();
+
+        /* ---- consume the staged rows in order ------------------------------------- */
+        for (uint32_t i = 0; i < nrows; i++)
+        {
+            const uint32_t r = gfirst + i;
+            const uint32_t mis = (uint32_t) ((src_base + (size_t) r * src_stride + g0) & 15);
+            const uint8_t *rowb = sbuf + i * row_pitch + mis;
+
+            /* horizontal result for this lane's column */
+            Px2 h;
+            if (HM == 0)
+            {
+                uint32_t wp, wq;
+                tile_read_pair<TAP, false> (J, rowb, tap_ofs [0], wp, wq);
+                h = px2_from_word (wp);
+            }
+            else
+            {
+                h.lo = 0; h.hi = 0;
+#pragma unroll
+                for (uint32_t s = 0; s < NSX; s++)
+                {
+                    uint32_t wp, wq;
+                    tile_read_pair<TAP, true> (J, rowb, tap_ofs [s], wp, wq);
+                    const Px2 t = tap2 (px2_from_word (wp), px2_from_word (wq), tap_f [s]);
+                    h.lo += t.lo;
+                    h.hi += t.hi;
+                }
+                if (HX)
+                {
+                    h.lo = (h.lo >> HX) & PAIR_MASK;
+                    h.hi = (h.hi >> HX) & PAIR_MASK;
+                }
+            }
+
+            /* vertical: emit every sample whose last row is r */
+            while (y < y_end && oy + vlag == r)
+            {
+                Px2 t = h;
+                if (vpair)
+                    t = tap2 (hprev, h, Fy);
+                acc.lo += t.lo;
+                acc.hi += t.hi;
+                s_y++;
+                if (s_y == nsy)
+                {
+                    Px2 o;
+                    o.lo = (acc.lo >> hv) & PAIR_MASK;
+                    o.hi = (acc.hi >> hv) & PAIR_MASK;
+                    if (active)
+                        tile_store<OUT> (J, out_row, x, o);
+                    acc.lo = 0; acc.hi = 0;
+                    s_y = 0;
+                    y++;
+                    out_row += J.dst_stride;
+                }
+                if (y < y_end)
+                    tile_vsample (J, (y << hv) + s_y, oy, Fy);
+            }
+            hprev = h;
+        }
+    }
+}
+
+template <int TAP, int HM, bool STAGE_PREMUL>
+__device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf)
+{
+    switch (J.tile_variant & 3u)
+    {
+        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL> (J, sbuf); break;
+        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL> (J, sbuf); break;
+        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL> (J, sbuf); break;
+    }
+}
+
+template <int TAP, bool STAGE_PREMUL>
+__device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf)
+{
+    switch ((J.tile_variant >> 2) & 3u)
+    {
+        case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL> (J, sbuf); break;
+        case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL> (J, sbuf); break;
+        case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL> (J, sbuf); break;
+        default: tile_dispatch_out<TAP, 3, STAGE_PREMUL> (J, sbuf); break;
+    }
+}
+
+/* tile_variant = tapsel << 4 | HM << 2 | OUT; tapsel: 0 A4, 1 A4 + premultiply
+ * while staging, 2 U4, 3 U3 (smol_jobdev.h: tile_setup) */
+__device__ __forceinline__ void tile_dispatch (const JobDev &J, uint8_t *sbuf)
+{
+    switch (J.tile_variant >> 4)
+    {
+        case 0:  tile_dispatch_hm<TAP_A4, false> (J, sbuf); break;
+        case 1:  tile_dispatch_hm<TAP_A4, true> (J, sbuf); break;
+        case 2:  tile_dispatch_hm<TAP_U4, false> (J, sbuf); break;
+        default: tile_dispatch_hm<TAP_U3, false> (J, sbuf); break;
+    }
+}
+
+#ifndef SMOL_KERNEL_EMU
+extern __shared__ __attribute__ ((aligned (16))) uint8_t smol_dyn_lds [];
+#endif
+
+__global__ void __launch_bounds__ (64)
+k_tile_batch (const JobDev *__restrict__ jobs)
+{
+    /* private copy: the descriptor must not be re-read from memory after every
+     * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
+    const JobDev J = jobs [blockIdx.y];
+    tile_dispatch (J, smol_dyn_lds);
+}
+
+__global__ void __launch_bounds__ (64)
+k_tile_one (const JobDev J)
+{
+    tile_dispatch (J, smol_dyn_lds);
+}
+
+} /* namespace smolhip */

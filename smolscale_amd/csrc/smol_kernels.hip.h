@@ -456,9 +456,10 @@ __device__ __forceinline__ void general_body (const JobDev &J)
 /* batch form: one descriptor per blockIdx.y, descriptors in device memory */
 template <bool WIDE>
 __global__ void __launch_bounds__ (GENERAL_BLOCK)
-k_general_batch (const JobDev *jobs)
+k_general_batch (const JobDev *__restrict__ jobs)
 {
-    general_body<WIDE> (jobs [blockIdx.y]);
+    const JobDev J = jobs [blockIdx.y];
+    general_body<WIDE> (J);
 }
 
 /* single-job form: descriptor passed by value in the kernel arguments */
@@ -592,4 +593,7 @@ k_pow2_one (const JobDev J)
     pow2_body<HX, HY> (J);
 }
 
+
 } /* namespace smolhip */
+
+#include "smol_kernel_tile.hip.h"

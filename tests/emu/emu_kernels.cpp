@@ -5,6 +5,36 @@
 #define SMOL_KERNEL_EMU 1
 #include "smol_kernels.hip.h"
 
+#include <thread>
+#include <vector>
+
+pthread_barrier_t emu_block_barrier;
+uint8_t *emu_dyn_lds_ptr;
+
+/* cooperative kernels: the 64 lanes of a block run as real threads, blocks in turn */
+template <typename F>
+static void run_grid_coop (unsigned gx, unsigned bx, size_t lds_bytes, F body)
+{
+    std::vector<uint8_t> lds (lds_bytes + 64, 0xcd);
+    emu_dyn_lds_ptr = (uint8_t *) (((uintptr_t) lds.data () + 15) & ~(uintptr_t) 15);
+    pthread_barrier_init (&emu_block_barrier, nullptr, bx);
+    for (unsigned b = 0; b < gx; b++)
+    {
+        std::vector<std::thread> lanes;
+        for (unsigned t = 0; t < bx; t++)
+            lanes.emplace_back ([=] {
+                gridDim = { gx, 1, 1 };
+                blockDim = { bx, 1, 1 };
+                blockIdx = { b, 0, 0 };
+                threadIdx = { t, 0, 0 };
+                body ();
+            });
+        for (auto &th : lanes)
+            th.join ();
+    }
+    pthread_barrier_destroy (&emu_block_barrier);
+}
+
 using namespace smolhip;
 using namespace smolhip::dispatch;
 
@@ -42,8 +72,10 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
     JobDev J;
     fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
     KClass k = classify (J);
-    if (force_general && k == KC_POW2)
+    if (force_general && (k == KC_POW2 || k == KC_TILE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
+    if (force_general == 2 && tile_ok (J))
+        k = KC_TILE;                      /* force the tiled kernel where the fast path would win */
     if (kclass_out)
         *kclass_out = (int) k;
 
@@ -59,6 +91,14 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
             case 1: run_pow2_hy<1> (J, gx); break;
             default: run_pow2_hy<2> (J, gx); break;
         }
+        return 0;
+    }
+
+    if (k == KC_TILE)
+    {
+        const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+        const uint32_t tiles_y = (n_rows + J.tile_rows - 1) / J.tile_rows;
+        run_grid_coop (tiles_x * tiles_y, 64, tile_lds_bytes (J), [&] { k_tile_one (J); });
         return 0;
     }
 

@@ -31,3 +31,20 @@ static inline uint32_t __builtin_amdgcn_perm (uint32_t s0, uint32_t s1, uint32_t
     }
     return r;
 }
+
+/* v_alignbyte_b32: ({S0,S1} >> (8 * S2[1:0])) & 0xffffffff */
+static inline uint32_t __builtin_amdgcn_alignbyte (uint32_t s0, uint32_t s1, uint32_t sh)
+{
+    uint64_t both = ((uint64_t) s0 << 32) | s1;
+    return (uint32_t) (both >> (8 * (sh & 3)));
+}
+
+/* Block-level barrier + dynamic LDS for kernels whose lanes cooperate: the
+ * harness runs the lanes of ONE block as real threads (emu_kernels.cpp). */
+#include <pthread.h>
+extern pthread_barrier_t emu_block_barrier;
+extern uint8_t *emu_dyn_lds_ptr;
+static inline void __syncthreads (void) { pthread_barrier_wait (&emu_block_barrier); }
+#define smol_dyn_lds emu_dyn_lds_ptr
+
+static inline uint32_t __umul24 (uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }

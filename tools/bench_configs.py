@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Device-resident timing of every BASELINE.json config (+ the BOX row) on ONE GPU.
+
+Not the driver's benchmark (that is bench.py, config 2 only): this is the tool the
+per-config numbers in DESIGN.md / profiles/ come from. One JSON line per config:
+kernel class, launches, average launch time (hipEvents on the launch stream),
+algorithmic GB/s and fraction of the 8 TB/s HBM peak, Mpix_out/s.
+
+    python tools/bench_configs.py [--configs C1,C2,C3,C4,C5,BOX] [--iters 20] [--check]
+
+--check also downloads one image per config and compares it with the oracle.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import smolscale_amd as sm  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+# name: (t_in, w_in, h_in, stride_in, t_out, w_out, h_out, n_images, description)
+CONFIGS = {
+    "C1": (0, 640, 480, None, 0, 320, 240, 384, "640x480->320x240 RGBA8 premul (0H/0H), 384 frames per launch"),
+    "C2": (0, 4096, 4096, None, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul (1H/1H), 8 frames per launch"),
+    "C3": (4, 1920, 1080, None, 0, 7680, 4320, 4, "1920x1080 RGBA unassociated -> 7680x4320 RGBA premul (0H/0H magnify), 4 frames"),
+    "C4": (8, 65535, 4096, 65535 * 3, 0, 8192, 4096, 1, "65535x4096 RGB8 (odd stride 196605) -> 8192x4096 RGBA8 (2H/COPY), 1 frame"),
+    "C5": (0, 256, 256, None, 0, 64, 64, 10000, "10000 thumbnails 256^2->64^2 RGBA8 premul (1H/1H), one batch"),
+    "C5mix": (-1, 256, 256, None, -1, 64, 64, 10000, "10000 thumbnails 256^2->64^2, pixel types drawn uniformly from the 10x10 table"),
+    "BOX": (0, 4096, 4096, None, 0, 448, 448, 8, "4096^2->448^2 RGBA8 premul (BOX/BOX 64bpp), 8 frames per launch"),
+}
+
+
+def bpp(t):
+    return sm.bytes_per_pixel(t)
+
+
+def run_config(name, iters, warmup, check):
+    t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = CONFIGS[name]
+    rng = np.random.default_rng(12345)
+    images, bufs, specs = [], [], []
+    total_in = total_out = 0
+    host_src_kept = None
+
+    # one shared pool of random bytes uploaded once per distinct input size
+    for i in range(n_images):
+        t_in = int(rng.integers(0, 10)) if t_in0 < 0 else t_in0
+        t_out = int(rng.integers(0, 10)) if t_out0 < 0 else t_out0
+        s_in = stride_in or w_in * bpp(t_in)
+        s_out = w_out * bpp(t_out)
+        n_in = h_in * s_in
+        n_out = h_out * s_out
+        dsrc = sm.DeviceBuffer(n_in + 64)
+        ddst = sm.DeviceBuffer(n_out + 64)
+        if i < 16 or n_in > (1 << 24):
+            host = rng.integers(0, 256, n_in, dtype=np.uint8)
+            pool = host
+        else:
+            host = pool          # reuse host bytes (device copies are still distinct allocations)
+        dsrc.upload(host[:n_in])
+        if i == 0:
+            host_src_kept = host[:n_in].copy()
+        im = sm.SmolHipImage()
+        im.job = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+        im.src, im.dst = dsrc.ptr, ddst.ptr
+        im.rowstride_in, im.rowstride_out = s_in, s_out
+        im.first_row, im.n_rows = 0, h_out
+        images.append(im)
+        bufs.append((dsrc, ddst))
+        specs.append((t_in, t_out, s_in, s_out))
+        total_in += w_in * h_in * bpp(t_in)
+        total_out += w_out * h_out * bpp(t_out)
+
+    batch = sm.HipBatch(images)
+    n_launches, kname = batch.info()
+    ms = batch.time(warmup, iters)
+    per_step_ms = ms / iters
+    algo = total_in + total_out
+    line = {
+        "config": name, "desc": desc, "kernel": kname, "launches_per_step": n_launches,
+        "step_us": round(per_step_ms * 1e3, 2),
+        "algorithmic_bytes_per_step": algo,
+        "GBps": round(algo / (per_step_ms * 1e-3) / 1e9, 1),
+        "frac_of_8TBps": round(algo / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "Mpix_out_per_s": round(n_images * w_out * h_out / (per_step_ms * 1e-3) / 1e6, 1),
+        "images_per_s": round(n_images / (per_step_ms * 1e-3), 1),
+    }
+    if check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import helpers as H
+        t_in, t_out, s_in, s_out = specs[0]
+        got = bufs[0][1].download(h_out * s_out)
+        src = np.concatenate([host_src_kept, np.zeros(16, np.uint8)])
+        rows = min(h_out, 96)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, s_in, s_out, first=0, n=rows)
+        line["bit_exact_first_rows_vs_oracle"] = bool(np.array_equal(got[:rows * s_out], want))
+    batch.destroy()
+    for a, b in bufs:
+        a.free()
+        b.free()
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="C1,C2,C3,C4,C5,C5mix,BOX")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    for name in args.configs.split(","):
+        print(json.dumps(run_config(name, args.iters, args.warmup, args.check)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
