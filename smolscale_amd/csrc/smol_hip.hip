@@ -81,7 +81,8 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
     if (k == KC_TILE)
     {
         /* groups share tile_rows and LDS size (see smol_hip_batch_create) */
-        const uint32_t tiles_x = (max_w_out + smolhip::TILE_COLS - 1) / smolhip::TILE_COLS;
+        const uint32_t tw = smolhip::TILE_COLS * rep.tile_cpl;
+        const uint32_t tiles_x = (max_w_out + tw - 1) / tw;
         const uint32_t tiles_y = (max_rows + rep.tile_rows - 1) / rep.tile_rows;
         dim3 grid (tiles_x * tiles_y, n_jobs);
         const uint32_t lds = max_lds ? max_lds : tile_lds_bytes (rep);
@@ -358,7 +359,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2 && (jobs [j].halv_h != g.rep.halv_h || jobs [j].halv_v != g.rep.halv_v))
                 continue;
-            if (g.k == KC_TILE && jobs [j].tile_rows != g.rep.tile_rows)
+            if (g.k == KC_TILE && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl))
                 continue;
             if (g.count == 65535)
                 break;

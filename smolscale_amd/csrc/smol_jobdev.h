@@ -33,6 +33,8 @@ struct JobDev
     /* k_tile geometry (filled by tile_setup) */
     uint8_t tile_aligned4;         /* every staged pixel sits on a 4-byte LDS boundary   */
     uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
+    uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
+    uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
@@ -55,7 +57,7 @@ enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr uint32_t TILE_LDS_BUDGET = 16 * 1024;     /* bytes of LDS per 64-lane workgroup */
+constexpr uint32_t TILE_LDS_BUDGET = 8 * 1024;      /* bytes of LDS per staging buffer (two per 64-lane workgroup) */
 
 inline bool
 tile_ok (const JobDev &d)
@@ -74,11 +76,17 @@ tile_setup (JobDev &d)
     if (!tile_ok (d))
         return;
 
+    /* few taps per column (COPY/ONE/one sample) and a wide enough image: a lane
+     * takes 4 adjacent columns, which amortises the wave's scalar bookkeeping and
+     * turns its stores into 16-byte ones */
+    d.tile_cpl = ((d.filter_h != F_BILINEAR || d.halv_h == 0) && d.w_out >= 256) ? 4 : 1;
+    const uint64_t cols = 64u * d.tile_cpl;
+
     uint64_t span_px;
     if (d.filter_h == F_BILINEAR)
-        span_px = ((((uint64_t) 64 << d.halv_h) * d.step_x) >> 32) + 3;
+        span_px = (((cols << d.halv_h) * d.step_x) >> 32) + 3;
     else
-        span_px = (d.filter_h == F_ONE) ? 1 : 64;
+        span_px = (d.filter_h == F_ONE) ? 1 : cols;
     if (span_px > d.w_in)
         span_px = d.w_in;
 
@@ -117,12 +125,13 @@ tile_setup (JobDev &d)
         out = 2;
 
     d.tile_variant = (uint8_t) ((tapsel << 4) | (hm << 2) | out);
+    d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
 }
 
 inline uint32_t
 tile_lds_bytes (const JobDev &d)
 {
-    return d.group_rows * d.span_chunks * 16 + 32;
+    return 2 * d.group_rows * d.span_chunks * 16 + 32;
 }
 
 inline void

@@ -132,9 +132,9 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
     }
 }
 
-/* packed pair -> destination pixel (packers of smolscale-generic.c:758-906) */
+/* packed pair -> destination pixel word (packers of smolscale-generic.c:758-906) */
 template <int OUT>
-__device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint32_t x, Px2 v)
+__device__ __forceinline__ uint32_t tile_pack (const JobDev &J, Px2 v)
 {
     uint32_t w = v.lo | (v.hi << 8);             /* bytes in INPUT memory order */
 
@@ -153,7 +153,13 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
         w = o;
     }
 
-    w = __builtin_amdgcn_perm (w, w, J.out_perm);
+    return __builtin_amdgcn_perm (w, w, J.out_perm);
+}
+
+template <int OUT>
+__device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint32_t x, Px2 v)
+{
+    const uint32_t w = tile_pack<OUT> (J, v);
 
     if (OUT != OUT_ANY)
     {
@@ -171,6 +177,46 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
     }
 }
 
+/* CPL adjacent output pixels of one lane; one 16-byte store when possible */
+template <int OUT, int CPL>
+__device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp, uint32_t xl, uint32_t xn,
+                                                 const Px2 (&o) [CPL])
+{
+    if (CPL == 4 && OUT != OUT_ANY)
+    {
+        if (J.out_vec16_ok && xl + 4 <= xn)
+        {
+            uint32_t w [4];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                w [c] = tile_pack<OUT> (J, o [c]);
+            u32x4 v = { w [0], w [1], w [2], w [3] };
+            *reinterpret_cast<u32x4 *> (rowp + (size_t) xl * 4) = v;
+            return;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        if (xl + c < xn)
+            tile_store<OUT> (J, rowp, xl + c, o [c]);
+}
+
+#ifndef SMOL_KERNEL_EMU
+/* memory -> LDS, 16 bytes per lane, no VGPR destination: LDS address = wave-uniform
+ * base + 16 * lane (cdna_hip_programming.md section 5, global_load_lds) */
+__device__ __forceinline__ void smol_global_load_lds16 (const void *gptr, uint8_t *lds_wave_base, uint32_t)
+{
+    __builtin_amdgcn_global_load_lds (
+        reinterpret_cast<const __attribute__ ((address_space (1))) void *> (reinterpret_cast<uintptr_t> (gptr)),
+        (__attribute__ ((address_space (3))) void *) lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void smol_wait_vmcnt0 ()
+{
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#endif
+
 /* vertical sample schedule: (row of the top tap, weight) for sample index jy */
 __device__ __forceinline__ void tile_vsample (const JobDev &J, uint32_t jy, uint32_t &oy, uint32_t &F)
 {
@@ -187,19 +233,88 @@ __device__ __forceinline__ void tile_vsample (const JobDev &J, uint32_t jy, uint
 
 constexpr int TILE_STAGE_UNROLL = 8;
 
-/* TAP: see above. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples per
- * output column. STAGE_PREMUL: premultiply 32-bit unassociated pixels while
- * staging (only with TAP_A4). */
-template <int TAP, int HM, int OUT, bool STAGE_PREMUL>
+/* Bring source rows [gfirst, gfirst + nrows) of the tile's column span into the
+ * LDS buffer `buf' as 16-byte chunks (chunk c of the group lands at buf + 16*c,
+ * row i starts at chunk i * span_chunks).
+ *   DMA = true : global_load_lds_dwordx4 -- memory -> LDS without passing through
+ *                registers; asynchronous, retired by the caller's vmcnt(0) wait.
+ *   DMA = false: through registers, optionally premultiplying 32-bit unassociated
+ *                pixels on the way (PREMUL). */
+template <bool DMA, bool PREMUL>
+__device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint32_t lane,
+                                            uint32_t gfirst, uint32_t nrows, uint32_t g0, uint32_t g1)
+{
+    const uint32_t total = nrows * J.span_chunks;
+    const uintptr_t src_base = (uintptr_t) J.src;
+    const size_t src_stride = J.src_stride;
+    const uint32_t ain = J.pos_in [3];
+
+    for (uint32_t c0 = 0; c0 < total; c0 += TILE_COLS * TILE_STAGE_UNROLL)
+    {
+        u32x4 v [TILE_STAGE_UNROLL];
+        bool ok [TILE_STAGE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TILE_STAGE_UNROLL; u++)
+        {
+            const uint32_t cu = c0 + (uint32_t) u * TILE_COLS;      /* wave-uniform */
+            const uint32_t c = cu + lane;
+            const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
+            const uint32_t k = c - i * J.span_chunks;
+            const uintptr_t rb = src_base + (size_t) (gfirst + i) * src_stride;
+            const uintptr_t a0 = (rb + g0) & ~(uintptr_t) 15;
+            const uint32_t nch = (uint32_t) ((rb + g1 - a0 + 15) >> 4);
+
+            ok [u] = (c < total) && (k < nch);
+            if (DMA)
+            {
+                if (cu < total && ok [u])
+                    smol_global_load_lds16 (reinterpret_cast<const void *> (a0 + (uintptr_t) k * 16),
+                                            buf + (size_t) cu * 16, lane);
+            }
+            else if (ok [u])
+            {
+                v [u] = *reinterpret_cast<const u32x4 *> (a0 + (uintptr_t) k * 16);
+            }
+        }
+        if (!DMA)
+        {
+#pragma unroll
+            for (int u = 0; u < TILE_STAGE_UNROLL; u++)
+            {
+                const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
+                if (ok [u])
+                {
+                    if (PREMUL)
+                    {
+                        v [u].x = premul_word (v [u].x, ain);
+                        v [u].y = premul_word (v [u].y, ain);
+                        v [u].z = premul_word (v [u].z, ain);
+                        v [u].w = premul_word (v [u].w, ain);
+                    }
+                    *reinterpret_cast<u32x4 *> (buf + (size_t) c * 16) = v [u];
+                }
+            }
+        }
+    }
+}
+
+/* TAP: how taps are read. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples
+ * per output column. STAGE_PREMUL: premultiply while staging (TAP_A4 only; uses
+ * the register path, single LDS buffer). CPL: adjacent output columns per lane
+ * (a tile is 64*CPL columns wide) -- amortises the wave's scalar bookkeeping
+ * when there is little vector work per column (magnification). */
+template <int TAP, int HM, int OUT, bool STAGE_PREMUL, int CPL>
 __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 {
     constexpr bool HPAIR = (HM != 0);
     constexpr uint32_t NSX = (HM == 0) ? 1u : (1u << (HM - 1));
     constexpr uint32_t HX = (HM == 0) ? 0u : (uint32_t) (HM - 1);
     constexpr uint32_t BPP = (TAP == TAP_U3) ? 3u : 4u;
+    constexpr uint32_t TW = TILE_COLS * CPL;
+    constexpr bool DMA = !STAGE_PREMUL;
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+    const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
     const uint32_t tx = blockIdx.x % tiles_x;
     const uint32_t ty = blockIdx.x / tiles_x;
     const uint32_t yrel0 = ty * J.tile_rows;
@@ -208,24 +323,27 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         return;
 
     const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
-    const uint32_t x0 = tx * TILE_COLS;
-    const uint32_t xn = (x0 + TILE_COLS < J.w_out) ? x0 + TILE_COLS : J.w_out;   /* one past last column */
-    const uint32_t x = x0 + lane;
-    const bool active = x < xn;
-    const uint32_t xc = active ? x : xn - 1;
+    const uint32_t x0 = tx * TW;
+    const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;   /* one past last column */
+    const uint32_t xl = x0 + lane * CPL;                           /* this lane's first column */
 
-    /* ---- horizontal taps of this lane (same for every row) ----------------- */
-    uint32_t tap_ofs [NSX], tap_f [NSX];
+    /* ---- horizontal taps of this lane's columns (same for every row) ---------- */
+    uint32_t tap_ofs [CPL][NSX], tap_f [CPL][NSX];
     uint32_t sx0, sx1;
 
     if (HPAIR)
     {
-        uint64_t pos = J.frac0_x + (uint64_t) (xc << HX) * J.step_x;
 #pragma unroll
-        for (uint32_t s = 0; s < NSX; s++)
+        for (int c = 0; c < CPL; c++)
         {
-            bilin_tap (pos, J.w_in, tap_ofs [s], tap_f [s]);
-            pos += J.step_x;
+            const uint32_t xc = (xl + c < xn) ? xl + c : xn - 1;
+            uint64_t pos = J.frac0_x + (uint64_t) (xc << HX) * J.step_x;
+#pragma unroll
+            for (uint32_t s = 0; s < NSX; s++)
+            {
+                bilin_tap (pos, J.w_in, tap_ofs [c][s], tap_f [c][s]);
+                pos += J.step_x;
+            }
         }
         uint32_t f_unused;
         bilin_tap (J.frac0_x + (uint64_t) (x0 << HX) * J.step_x, J.w_in, sx0, f_unused);
@@ -234,8 +352,13 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     }
     else
     {
-        tap_ofs [0] = (J.filter_h == F_ONE) ? 0u : xc;
-        tap_f [0] = 256u;
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+        {
+            const uint32_t xc = (xl + c < xn) ? xl + c : xn - 1;
+            tap_ofs [c][0] = (J.filter_h == F_ONE) ? 0u : xc;
+            tap_f [c][0] = 256u;
+        }
         sx0 = (J.filter_h == F_ONE) ? 0u : x0;
         sx1 = (J.filter_h == F_ONE) ? 0u : xn - 1;
     }
@@ -243,11 +366,14 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     const uint32_t g0 = sx0 * BPP;                      /* first byte of the span in a row */
     const uint32_t g1 = (sx1 + 1) * BPP;                /* one past the last byte          */
     const uint32_t row_pitch = J.span_chunks * 16u;     /* LDS bytes per staged row        */
+    const uint32_t buf_bytes = J.group_rows * row_pitch;
 #pragma unroll
-    for (uint32_t s = 0; s < NSX; s++)
-        tap_ofs [s] = (tap_ofs [s] - sx0) * BPP;        /* byte offset inside the span     */
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+            tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * BPP;   /* byte offset inside the span */
 
-    /* ---- vertical schedule ---------------------------------------------------- */
+    /* ---- vertical schedule (all wave-uniform) ----------------------------------- */
     const bool vpair = (J.filter_v == F_BILINEAR);
     const uint32_t hv = vpair ? J.halv_v : 0u;
     const uint32_t nsy = 1u << hv;
@@ -255,149 +381,170 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     uint32_t y = J.first_row + yrel0;                   /* absolute output row being built */
     const uint32_t y_end = J.first_row + yrel1;
     uint32_t s_y = 0;                                   /* sample within the output row    */
+    uint32_t jy = y << hv;                              /* running vertical sample index   */
     uint32_t oy, Fy;
     uint32_t row_first, row_last, f_unused2;
 
-    tile_vsample (J, y << hv, oy, Fy);
+    tile_vsample (J, jy, oy, Fy);
     row_first = oy;
     tile_vsample (J, (y_end << hv) - 1, row_last, f_unused2);
     row_last += vlag;
 
-    Px2 hprev = { 0, 0 }, acc = { 0, 0 };
-    const size_t src_stride = J.src_stride;
+    Px2 hprev [CPL], acc [CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+    {
+        hprev [c].lo = hprev [c].hi = 0;
+        acc [c].lo = acc [c].hi = 0;
+    }
     const uintptr_t src_base = (uintptr_t) J.src;
     uint8_t *out_row = J.dst + (size_t) yrel0 * J.dst_stride;
-    const uint32_t ain = J.pos_in [3];
 
-    for (uint32_t gfirst = row_first; gfirst <= row_last; gfirst += J.group_rows)
+    uint32_t gfirst = row_first;
+    uint32_t nrows = (row_last - gfirst + 1 < J.group_rows) ? row_last - gfirst + 1 : J.group_rows;
+    uint32_t cur = 0;
+
+    if (DMA)
+        tile_stage<true, false> (J, sbuf, lane, gfirst, nrows, g0, g1);
+
+    while (true)
     {
-        const uint32_t nrows = (row_last - gfirst + 1 < J.group_rows) ? row_last - gfirst + 1 : J.group_rows;
-        const uint32_t total = nrows * J.span_chunks;
+        uint8_t *buf = sbuf + cur * buf_bytes;
 
-        __syncthreads ();                               /* previous group fully consumed */
-
-        /* ---- stage: aligned 16-byte chunks, TILE_STAGE_UNROLL loads in flight per lane */
-        for (uint32_t c0 = 0; c0 < total; c0 += TILE_COLS * TILE_STAGE_UNROLL)
+        if (DMA)
         {
-            u32x4 v [TILE_STAGE_UNROLL];
-            bool ok [TILE_STAGE_UNROLL];
-#pragma unroll
-            for (int u = 0; u < TILE_STAGE_UNROLL; u++)
+            /* this group has landed; start the next one into the other buffer so it
+             * streams in while this one is consumed */
+            smol_wait_vmcnt0 ();
+            __syncthreads ();
+            const uint32_t nfirst = gfirst + nrows;
+            if (nfirst <= row_last)
             {
-                const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
-                const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
-                const uint32_t k = c - i * J.span_chunks;
-                const uintptr_t rb = src_base + (size_t) (gfirst + i) * src_stride;
-                const uintptr_t a0 = (rb + g0) & ~(uintptr_t) 15;
-                const uint32_t nch = (uint32_t) ((rb + g1 - a0 + 15) >> 4);
-
-                ok [u] = (c < total) && (k < nch);
-                if (ok [u])
-                    v [u] = *reinterpret_cast<const u32x4 *> (a0 + (uintptr_t) k * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < TILE_STAGE_UNROLL; u++)
-            {
-                const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
-                if (ok [u])
-                {
-                    if (STAGE_PREMUL)
-                    {
-                        v [u].x = premul_word (v [u].x, ain);
-                        v [u].y = premul_word (v [u].y, ain);
-                        v [u].z = premul_word (v [u].z, ain);
-                        v [u].w = premul_word (v [u].w, ain);
-                    }
-                    *reinterpret_cast<u32x4 *> (sbuf + (size_t) c * 16) = v [u];
-                }
+                const uint32_t nn = (row_last - nfirst + 1 < J.group_rows) ? row_last - nfirst + 1 : J.group_rows;
+                tile_stage<true, false> (J, sbuf + (cur ^ 1u) * buf_bytes, lane, nfirst, nn, g0, g1);
             }
         }
-
-        __syncthreads ();
+        else
+        {
+            __syncthreads ();                           /* previous group fully consumed */
+            tile_stage<false, STAGE_PREMUL> (J, buf, lane, gfirst, nrows, g0, g1);
+            __syncthreads ();
+        }
 
         /* ---- consume the staged rows in order ------------------------------------- */
         for (uint32_t i = 0; i < nrows; i++)
         {
             const uint32_t r = gfirst + i;
-            const uint32_t mis = (uint32_t) ((src_base + (size_t) r * src_stride + g0) & 15);
-            const uint8_t *rowb = sbuf + i * row_pitch + mis;
+            const uint32_t mis = (uint32_t) ((src_base + (size_t) r * J.src_stride + g0) & 15);
+            const uint8_t *rowb = buf + i * row_pitch + mis;
 
-            /* horizontal result for this lane's column */
-            Px2 h;
-            if (HM == 0)
-            {
-                uint32_t wp, wq;
-                tile_read_pair<TAP, false> (J, rowb, tap_ofs [0], wp, wq);
-                h = px2_from_word (wp);
-            }
-            else
-            {
-                h.lo = 0; h.hi = 0;
+            Px2 h [CPL];
 #pragma unroll
-                for (uint32_t s = 0; s < NSX; s++)
+            for (int c = 0; c < CPL; c++)
+            {
+                if (HM == 0)
                 {
                     uint32_t wp, wq;
-                    tile_read_pair<TAP, true> (J, rowb, tap_ofs [s], wp, wq);
-                    const Px2 t = tap2 (px2_from_word (wp), px2_from_word (wq), tap_f [s]);
-                    h.lo += t.lo;
-                    h.hi += t.hi;
+                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0], wp, wq);
+                    h [c] = px2_from_word (wp);
                 }
-                if (HX)
+                else
                 {
-                    h.lo = (h.lo >> HX) & PAIR_MASK;
-                    h.hi = (h.hi >> HX) & PAIR_MASK;
+                    h [c].lo = 0; h [c].hi = 0;
+#pragma unroll
+                    for (uint32_t s = 0; s < NSX; s++)
+                    {
+                        uint32_t wp, wq;
+                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s], wp, wq);
+                        const Px2 t = tap2 (px2_from_word (wp), px2_from_word (wq), tap_f [c][s]);
+                        h [c].lo += t.lo;
+                        h [c].hi += t.hi;
+                    }
+                    if (HX)
+                    {
+                        h [c].lo = (h [c].lo >> HX) & PAIR_MASK;
+                        h [c].hi = (h [c].hi >> HX) & PAIR_MASK;
+                    }
                 }
             }
 
             /* vertical: emit every sample whose last row is r */
             while (y < y_end && oy + vlag == r)
             {
-                Px2 t = h;
-                if (vpair)
-                    t = tap2 (hprev, h, Fy);
-                acc.lo += t.lo;
-                acc.hi += t.hi;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                {
+                    Px2 t = h [c];
+                    if (vpair)
+                        t = tap2 (hprev [c], h [c], Fy);
+                    acc [c].lo += t.lo;
+                    acc [c].hi += t.hi;
+                }
                 s_y++;
+                jy++;
                 if (s_y == nsy)
                 {
-                    Px2 o;
-                    o.lo = (acc.lo >> hv) & PAIR_MASK;
-                    o.hi = (acc.hi >> hv) & PAIR_MASK;
-                    if (active)
-                        tile_store<OUT> (J, out_row, x, o);
-                    acc.lo = 0; acc.hi = 0;
+                    Px2 o [CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; c++)
+                    {
+                        o [c].lo = (acc [c].lo >> hv) & PAIR_MASK;
+                        o [c].hi = (acc [c].hi >> hv) & PAIR_MASK;
+                        acc [c].lo = 0; acc [c].hi = 0;
+                    }
+                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn, o);
                     s_y = 0;
                     y++;
                     out_row += J.dst_stride;
                 }
                 if (y < y_end)
-                    tile_vsample (J, (y << hv) + s_y, oy, Fy);
+                    tile_vsample (J, jy, oy, Fy);
             }
-            hprev = h;
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                hprev [c] = h [c];
         }
+
+        gfirst += nrows;
+        if (gfirst > row_last)
+            break;
+        nrows = (row_last - gfirst + 1 < J.group_rows) ? row_last - gfirst + 1 : J.group_rows;
+        cur ^= 1u;
     }
 }
 
-template <int TAP, int HM, bool STAGE_PREMUL>
+template <int TAP, int HM, bool STAGE_PREMUL, int CPL>
 __device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf)
 {
     switch (J.tile_variant & 3u)
     {
-        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL> (J, sbuf); break;
-        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL> (J, sbuf); break;
-        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL> (J, sbuf); break;
+        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL, CPL> (J, sbuf); break;
+        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL, CPL> (J, sbuf); break;
+        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL, CPL> (J, sbuf); break;
     }
 }
 
 template <int TAP, bool STAGE_PREMUL>
 __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf)
 {
-    switch ((J.tile_variant >> 2) & 3u)
+    const uint32_t hm = (J.tile_variant >> 2) & 3u;
+
+    if (J.tile_cpl == 4)
     {
-        case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL> (J, sbuf); break;
-        case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL> (J, sbuf); break;
-        case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL> (J, sbuf); break;
-        default: tile_dispatch_out<TAP, 3, STAGE_PREMUL> (J, sbuf); break;
+        /* wide tiles only where a column needs few taps (COPY/ONE, one sample) */
+        if (hm == 0)
+            tile_dispatch_out<TAP, 0, STAGE_PREMUL, 4> (J, sbuf);
+        else
+            tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4> (J, sbuf);
+        return;
+    }
+
+    switch (hm)
+    {
+        case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL, 1> (J, sbuf); break;
+        case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1> (J, sbuf); break;
+        case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1> (J, sbuf); break;
+        default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1> (J, sbuf); break;
     }
 }
 

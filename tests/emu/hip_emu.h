@@ -48,3 +48,11 @@ static inline void __syncthreads (void) { pthread_barrier_wait (&emu_block_barri
 #define smol_dyn_lds emu_dyn_lds_ptr
 
 static inline uint32_t __umul24 (uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+
+/* LDS-DMA stand-ins: synchronous copy of this lane's 16 bytes */
+#include <string.h>
+static inline void smol_global_load_lds16 (const void *gptr, uint8_t *lds_wave_base, uint32_t lane)
+{
+    memcpy (lds_wave_base + 16 * lane, gptr, 16);
+}
+static inline void smol_wait_vmcnt0 (void) {}
