@@ -6,6 +6,7 @@
 
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "smol_hip.h"
 
@@ -35,6 +36,7 @@ struct JobDev
     uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
     uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
+    uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
@@ -95,7 +97,12 @@ tile_setup (JobDev &d)
     d.span_chunks = (bytes + 15) / 16;
     d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / d.span_chunks) + 1;
 
-    uint32_t rows = TILE_LDS_BUDGET / (d.span_chunks * 16);
+    uint32_t budget = TILE_LDS_BUDGET;
+    if (const char *e = getenv ("SMOL_TILE_LDS_BUDGET"))
+        budget = (uint32_t) atoi (e);
+    if (const char *e = getenv ("SMOL_TILE_DBG"))
+        d.dbg = (uint8_t) atoi (e);
+    uint32_t rows = budget / (d.span_chunks * 16);
     if (rows < 1) rows = 1;
     if (rows > 16) rows = 16;
     d.group_rows = (uint16_t) rows;
@@ -105,6 +112,12 @@ tile_setup (JobDev &d)
         th = (d.step_y < ((uint64_t) 1 << 32)) ? 32 : (16u >> d.halv_v);
     else
         th = (d.filter_v == F_ONE) ? 32 : 16;
+    if (const char *e = getenv ("SMOL_TILE_ROWS"))
+        th = (uint32_t) atoi (e);
+    if (th > (128u >> (d.filter_v == F_BILINEAR ? d.halv_v : 0)))
+        th = 128u >> (d.filter_v == F_BILINEAR ? d.halv_v : 0);     /* <= 128 vertical samples per tile */
+    if (th < 1)
+        th = 1;
     d.tile_rows = (uint16_t) th;
     d.tile_aligned4 = (d.bpp_in == 4 && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0);
 

@@ -41,13 +41,41 @@ __device__ __forceinline__ Px2 px2_from_word (uint32_t w)
     return r;
 }
 
-/* (p*F + q*(256-F)) >> 8 per 16-bit lane; products stay below 2^16 per lane */
+/* Two 16-bit lanes per register; the compiler maps these to v_pk_*_u16. */
+typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
+
+__device__ __forceinline__ u16x2 as_u16x2 (uint32_t v) { return __builtin_bit_cast (u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32 (u16x2 v) { return __builtin_bit_cast (uint32_t, v); }
+
+/* (p*F + q*(256-F)) >> 8 per 16-bit lane. For 8-bit p, q and F in 0..256 the sum
+ * is at most 255*256 < 2^16, so 16-bit lane arithmetic is exact and the result
+ * needs no mask. */
 __device__ __forceinline__ Px2 tap2 (Px2 p, Px2 q, uint32_t F)
 {
-    const uint32_t G = 256u - F;
+    const unsigned short f = (unsigned short) F, g = (unsigned short) (256u - F);
+    const u16x2 F2 = { f, f }, G2 = { g, g };
     Px2 r;
-    r.lo = ((__umul24 (p.lo, F) + __umul24 (q.lo, G)) >> 8) & PAIR_MASK;
-    r.hi = ((__umul24 (p.hi, F) + __umul24 (q.hi, G)) >> 8) & PAIR_MASK;
+    r.lo = as_u32 ((as_u16x2 (p.lo) * F2 + as_u16x2 (q.lo) * G2) >> 8);
+    r.hi = as_u32 ((as_u16x2 (p.hi) * F2 + as_u16x2 (q.hi) * G2) >> 8);
+    return r;
+}
+
+/* lane-wise a + b and a >> n on both halves (sums of at most 4 taps: <= 1020) */
+__device__ __forceinline__ Px2 px2_add (Px2 a, Px2 b)
+{
+    Px2 r;
+    r.lo = as_u32 (as_u16x2 (a.lo) + as_u16x2 (b.lo));
+    r.hi = as_u32 (as_u16x2 (a.hi) + as_u16x2 (b.hi));
+    return r;
+}
+
+__device__ __forceinline__ Px2 px2_shr (Px2 a, uint32_t n)
+{
+    const unsigned short s = (unsigned short) n;
+    const u16x2 S2 = { s, s };
+    Px2 r;
+    r.lo = as_u32 (as_u16x2 (a.lo) >> S2);
+    r.hi = as_u32 (as_u16x2 (a.hi) >> S2);
     return r;
 }
 
@@ -180,11 +208,13 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
 /* CPL adjacent output pixels of one lane; one 16-byte store when possible */
 template <int OUT, int CPL>
 __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp, uint32_t xl, uint32_t xn,
-                                                 const Px2 (&o) [CPL])
+                                                 bool interior, const Px2 (&o) [CPL])
 {
     if (CPL == 4 && OUT != OUT_ANY)
     {
-        if (J.out_vec16_ok && xl + 4 <= xn)
+        /* `interior' is wave-uniform: a full-width tile on a 16-byte aligned
+         * destination stores without touching the exec mask */
+        if (interior || (J.out_vec16_ok && xl + 4 <= xn))
         {
             uint32_t w [4];
 #pragma unroll
@@ -214,6 +244,12 @@ __device__ __forceinline__ void smol_global_load_lds16 (const void *gptr, uint8_
 __device__ __forceinline__ void smol_wait_vmcnt0 ()
 {
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+/* value of `v' in lane `idx' (idx wave-uniform) */
+__device__ __forceinline__ uint32_t smol_readlane (uint32_t v, uint32_t idx)
+{
+    return (uint32_t) __builtin_amdgcn_readlane ((int) v, (int) idx);
 }
 #endif
 
@@ -373,22 +409,39 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         for (uint32_t s = 0; s < NSX; s++)
             tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * BPP;   /* byte offset inside the span */
 
-    /* ---- vertical schedule (all wave-uniform) ----------------------------------- */
+    /* ---- vertical schedule ------------------------------------------------------
+     * (source row of the top tap, weight) for every vertical sample of the tile,
+     * computed once by the lanes (sample k of the tile lives in lane k & 63 of
+     * sched[k >> 6]) and fetched with v_readlane in the row loop: the wave's
+     * scalar unit, shared by the whole CU, stays out of the 64-bit position
+     * arithmetic. */
     const bool vpair = (J.filter_v == F_BILINEAR);
     const uint32_t hv = vpair ? J.halv_v : 0u;
     const uint32_t nsy = 1u << hv;
     const uint32_t vlag = vpair ? 1u : 0u;
     uint32_t y = J.first_row + yrel0;                   /* absolute output row being built */
     const uint32_t y_end = J.first_row + yrel1;
-    uint32_t s_y = 0;                                   /* sample within the output row    */
-    uint32_t jy = y << hv;                              /* running vertical sample index   */
-    uint32_t oy, Fy;
-    uint32_t row_first, row_last, f_unused2;
-
-    tile_vsample (J, jy, oy, Fy);
-    row_first = oy;
-    tile_vsample (J, (y_end << hv) - 1, row_last, f_unused2);
-    row_last += vlag;
+    const uint32_t jy0 = y << hv;
+    const uint32_t n_samples = (y_end - y) << hv;       /* <= 128 (tile_setup)             */
+    uint32_t sched [2];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++)
+    {
+        uint32_t k = q * 64u + lane;
+        if (k >= n_samples)
+            k = n_samples - 1;
+        uint32_t o, f;
+        tile_vsample (J, jy0 + k, o, f);
+        sched [q] = o | (f << 16);
+    }
+    uint32_t ks = 0;                                    /* running sample index in the tile */
+    uint32_t s_y = 0;                                   /* sample within the output row     */
+    uint32_t e = smol_readlane (sched [0], 0);
+    uint32_t oy = e & 0xffffu, Fy = e >> 16;
+    const uint32_t row_first = oy;
+    const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
+    const uint32_t row_last = (e_last & 0xffffu) + vlag;
+    const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
 
     Px2 hprev [CPL], acc [CPL];
 #pragma unroll
@@ -397,6 +450,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         hprev [c].lo = hprev [c].hi = 0;
         acc [c].lo = acc [c].hi = 0;
     }
+    (void) y;
     const uintptr_t src_base = (uintptr_t) J.src;
     uint8_t *out_row = J.dst + (size_t) yrel0 * J.dst_stride;
 
@@ -404,7 +458,9 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     uint32_t nrows = (row_last - gfirst + 1 < J.group_rows) ? row_last - gfirst + 1 : J.group_rows;
     uint32_t cur = 0;
 
-    if (DMA)
+    const bool dbg_notaps = J.dbg & 1, dbg_nostage = J.dbg & 2, dbg_nostore = J.dbg & 4;
+
+    if (DMA && !dbg_nostage)
         tile_stage<true, false> (J, sbuf, lane, gfirst, nrows, g0, g1);
 
     while (true)
@@ -418,7 +474,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
             smol_wait_vmcnt0 ();
             __syncthreads ();
             const uint32_t nfirst = gfirst + nrows;
-            if (nfirst <= row_last)
+            if (nfirst <= row_last && !dbg_nostage)
             {
                 const uint32_t nn = (row_last - nfirst + 1 < J.group_rows) ? row_last - nfirst + 1 : J.group_rows;
                 tile_stage<true, false> (J, sbuf + (cur ^ 1u) * buf_bytes, lane, nfirst, nn, g0, g1);
@@ -427,7 +483,8 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         else
         {
             __syncthreads ();                           /* previous group fully consumed */
-            tile_stage<false, STAGE_PREMUL> (J, buf, lane, gfirst, nrows, g0, g1);
+            if (!dbg_nostage)
+                tile_stage<false, STAGE_PREMUL> (J, buf, lane, gfirst, nrows, g0, g1);
             __syncthreads ();
         }
 
@@ -436,16 +493,24 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         {
             const uint32_t r = gfirst + i;
             const uint32_t mis = (uint32_t) ((src_base + (size_t) r * J.src_stride + g0) & 15);
-            const uint8_t *rowb = buf + i * row_pitch + mis;
+            /* TAP_A4: mis is a multiple of 4, fold it into the row base. Otherwise keep
+             * the base 16-byte aligned and add mis to each tap's byte offset, so the
+             * unaligned reader's dword loads stay 4-byte aligned in LDS. */
+            const uint8_t *rowb = buf + i * row_pitch + ((TAP == TAP_A4) ? mis : 0u);
+            const uint32_t tmis = (TAP == TAP_A4) ? 0u : mis;
 
             Px2 h [CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++)
             {
-                if (HM == 0)
+                if (dbg_notaps)
+                {
+                    h [c].lo = tap_ofs [c][0] + r; h [c].hi = tap_f [c][0];
+                }
+                else if (HM == 0)
                 {
                     uint32_t wp, wq;
-                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0], wp, wq);
+                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, wp, wq);
                     h [c] = px2_from_word (wp);
                 }
                 else
@@ -455,21 +520,16 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     for (uint32_t s = 0; s < NSX; s++)
                     {
                         uint32_t wp, wq;
-                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s], wp, wq);
-                        const Px2 t = tap2 (px2_from_word (wp), px2_from_word (wq), tap_f [c][s]);
-                        h [c].lo += t.lo;
-                        h [c].hi += t.hi;
+                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, wp, wq);
+                        h [c] = px2_add (h [c], tap2 (px2_from_word (wp), px2_from_word (wq), tap_f [c][s]));
                     }
                     if (HX)
-                    {
-                        h [c].lo = (h [c].lo >> HX) & PAIR_MASK;
-                        h [c].hi = (h [c].hi >> HX) & PAIR_MASK;
-                    }
+                        h [c] = px2_shr (h [c], HX);
                 }
             }
 
             /* vertical: emit every sample whose last row is r */
-            while (y < y_end && oy + vlag == r)
+            while (ks < n_samples && oy + vlag == r)
             {
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
@@ -477,28 +537,27 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     Px2 t = h [c];
                     if (vpair)
                         t = tap2 (hprev [c], h [c], Fy);
-                    acc [c].lo += t.lo;
-                    acc [c].hi += t.hi;
+                    acc [c] = (s_y == 0) ? t : px2_add (acc [c], t);
                 }
                 s_y++;
-                jy++;
+                ks++;
                 if (s_y == nsy)
                 {
                     Px2 o [CPL];
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
-                    {
-                        o [c].lo = (acc [c].lo >> hv) & PAIR_MASK;
-                        o [c].hi = (acc [c].hi >> hv) & PAIR_MASK;
-                        acc [c].lo = 0; acc [c].hi = 0;
-                    }
-                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn, o);
+                        o [c] = px2_shr (acc [c], hv);
+                    if (!dbg_nostore || o [0].lo == 0x12345678u)
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn, interior, o);
                     s_y = 0;
-                    y++;
                     out_row += J.dst_stride;
                 }
-                if (y < y_end)
-                    tile_vsample (J, jy, oy, Fy);
+                if (ks < n_samples)
+                {
+                    e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
+                    oy = e & 0xffffu;
+                    Fy = e >> 16;
+                }
             }
 #pragma unroll
             for (int c = 0; c < CPL; c++)

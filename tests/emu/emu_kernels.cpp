@@ -10,6 +10,7 @@
 
 pthread_barrier_t emu_block_barrier;
 uint8_t *emu_dyn_lds_ptr;
+uint32_t emu_lane_xchg [64];
 
 /* cooperative kernels: the 64 lanes of a block run as real threads, blocks in turn */
 template <typename F>

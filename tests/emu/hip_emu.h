@@ -56,3 +56,14 @@ static inline void smol_global_load_lds16 (const void *gptr, uint8_t *lds_wave_b
     memcpy (lds_wave_base + 16 * lane, gptr, 16);
 }
 static inline void smol_wait_vmcnt0 (void) {}
+
+/* v_readlane: every lane of the block calls this with the same idx */
+extern uint32_t emu_lane_xchg [64];
+static inline uint32_t smol_readlane (uint32_t v, uint32_t idx)
+{
+    emu_lane_xchg [threadIdx.x] = v;
+    __syncthreads ();
+    uint32_t r = emu_lane_xchg [idx];
+    __syncthreads ();
+    return r;
+}
