@@ -39,9 +39,9 @@ void
 launch_pow2_one (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
 {
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (256), 0, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (64, 16), 0, s, jobs_dev);
     else
-        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (256), 0, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (64, 16), 0, s, rep);
 }
 
 template <int HX>
@@ -67,7 +67,7 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         const uint32_t rx = 2u << rep.halv_h;
         const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
         const uint32_t tcols = max_w_out / opt;
-        dim3 grid (((tcols + 255) / 256) * max_rows, n_jobs);
+        dim3 grid (((tcols + 63) / 64) * ((max_rows + 15) / 16), n_jobs);
 
         switch (rep.halv_h)
         {
@@ -81,7 +81,7 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
     if (k == KC_TILE)
     {
         /* groups share tile_rows and LDS size (see smol_hip_batch_create) */
-        const uint32_t tw = smolhip::TILE_COLS * rep.tile_cpl;
+        const uint32_t tw = smolhip::TILE_COLS * rep.tile_cpl / rep.tile_lpc;
         const uint32_t tiles_x = (max_w_out + tw - 1) / tw;
         const uint32_t tiles_y = (max_rows + rep.tile_rows - 1) / rep.tile_rows;
         dim3 grid (tiles_x * tiles_y, n_jobs);
@@ -359,7 +359,8 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2 && (jobs [j].halv_h != g.rep.halv_h || jobs [j].halv_v != g.rep.halv_v))
                 continue;
-            if (g.k == KC_TILE && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl))
+            if (g.k == KC_TILE && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl
+                                  || jobs [j].tile_lpc != g.rep.tile_lpc))
                 continue;
             if (g.count == 65535)
                 break;

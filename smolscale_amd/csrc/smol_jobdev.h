@@ -35,12 +35,14 @@ struct JobDev
     uint8_t tile_aligned4;         /* every staged pixel sits on a 4-byte LDS boundary   */
     uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
     uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
+    uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8)              */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
     uint32_t span_chunks_inv;      /* floor(2^32 / span_chunks) + 1                      */
+    uint32_t box_nmax;             /* horizontal box: most interior pixels any column has */
 };
 
 namespace dispatch {
@@ -64,9 +66,7 @@ constexpr uint32_t TILE_LDS_BUDGET = 8 * 1024;      /* bytes of LDS per staging 
 inline bool
 tile_ok (const JobDev &d)
 {
-    if (d.wide)
-        return false;
-    return d.filter_h != F_BOX && d.filter_v != F_BOX;
+    return !d.wide;     /* 64bpp-class math: bilinear 0-2H, copy, one and box (ratio <= 255) */
 }
 
 /* Geometry of k_tile for this job: how many source pixels a 64-column tile can
@@ -81,11 +81,21 @@ tile_setup (JobDev &d)
     /* few taps per column (COPY/ONE/one sample) and a wide enough image: a lane
      * takes 4 adjacent columns, which amortises the wave's scalar bookkeeping and
      * turns its stores into 16-byte ones */
-    d.tile_cpl = ((d.filter_h != F_BILINEAR || d.halv_h == 0) && d.w_out >= 256) ? 4 : 1;
-    const uint64_t cols = 64u * d.tile_cpl;
+    d.tile_cpl = (d.filter_h != F_BOX && d.filter_v != F_BOX
+                  && (d.filter_h != F_BILINEAR || d.halv_h == 0) && d.w_out >= 256) ? 4 : 1;
+    uint64_t cols = 64u * d.tile_cpl;
+    uint32_t box_lpc = 1;
 
     uint64_t span_px;
-    if (d.filter_h == F_BILINEAR)
+    if (d.filter_h == F_BOX)
+    {
+        /* narrow boxes: one lane per column; wide ones: 8 lanes per column, 8 columns per tile */
+        box_lpc = (d.step_x > ((uint64_t) 24 << 16)) ? 8 : 1;
+        cols = 64u / box_lpc;
+        span_px = ((cols * d.step_x) >> 16) + 2;
+        d.box_nmax = (uint32_t) (d.step_x >> 16) + 1;
+    }
+    else if (d.filter_h == F_BILINEAR)
         span_px = (((cols << d.halv_h) * d.step_x) >> 32) + 3;
     else
         span_px = (d.filter_h == F_ONE) ? 1 : cols;
@@ -108,7 +118,13 @@ tile_setup (JobDev &d)
     d.group_rows = (uint16_t) rows;
 
     uint32_t th;
-    if (d.filter_v == F_BILINEAR)
+    if (d.filter_v == F_BOX)
+    {
+        /* about 64 source rows per tile */
+        th = (uint32_t) (((uint64_t) 64 << 16) / d.step_y);
+        if (th > 16) th = 16;
+    }
+    else if (d.filter_v == F_BILINEAR)
         th = (d.step_y < ((uint64_t) 1 << 32)) ? 32 : (16u >> d.halv_v);
     else
         th = (d.filter_v == F_ONE) ? 32 : 16;
@@ -129,7 +145,10 @@ tile_setup (JobDev &d)
     else
         tapsel = d.unassoc_in ? 1 : 0;
 
-    const uint32_t hm = (d.filter_h == F_BILINEAR) ? 1u + d.halv_h : 0u;
+    uint32_t hm = (d.filter_h == F_BILINEAR) ? 1u + d.halv_h : 0u;
+    if (d.filter_h == F_BOX)
+        hm = (box_lpc == 8) ? 5 : 4;
+    d.tile_lpc = (uint8_t) box_lpc;
 
     uint32_t out;
     if (d.bpp_out == 4 && d.out_dword_ok)
@@ -137,7 +156,7 @@ tile_setup (JobDev &d)
     else
         out = 2;
 
-    d.tile_variant = (uint8_t) ((tapsel << 4) | (hm << 2) | out);
+    d.tile_variant = (uint8_t) ((tapsel << 5) | (hm << 2) | out);
     d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
 }
 

@@ -79,6 +79,32 @@ __device__ __forceinline__ Px2 px2_shr (Px2 a, uint32_t n)
     return r;
 }
 
+/* (v * w) >> 8 per 16-bit lane, w in 0..256: edge weights of the box filter
+ * (weight_pixel_64bpp smolscale-generic.c:1177-1182, weight_edge_row_64bpp :2026-2040) */
+__device__ __forceinline__ Px2 px2_mulw (Px2 v, uint32_t w)
+{
+    const unsigned short ws = (unsigned short) w;
+    const u16x2 W2 = { ws, ws };
+    Px2 r;
+    r.lo = as_u32 ((as_u16x2 (v.lo) * W2) >> 8);
+    r.hi = as_u32 ((as_u16x2 (v.hi) * W2) >> 8);
+    return r;
+}
+
+/* box normalisation of the four 16-bit sums: scale_64bpp smolscale-generic.c:1231-1245 */
+__device__ __forceinline__ uint32_t box_scale16 (uint32_t c, uint32_t mul)
+{
+    return (uint32_t) (((uint64_t) c * mul + (1u << 23)) >> 24) & 0xffu;
+}
+
+__device__ __forceinline__ Px2 px2_box_scale (Px2 a, uint32_t mul)
+{
+    Px2 r;
+    r.lo = box_scale16 (a.lo & 0xffffu, mul) | (box_scale16 (a.lo >> 16, mul) << 16);
+    r.hi = box_scale16 (a.hi & 0xffffu, mul) | (box_scale16 (a.hi >> 16, mul) << 16);
+    return r;
+}
+
 /* unassociated -> premultiplied on a whole pixel word; ain = alpha byte index */
 __device__ __forceinline__ uint32_t premul_word (uint32_t w, uint32_t ain)
 {
@@ -251,6 +277,12 @@ __device__ __forceinline__ uint32_t smol_readlane (uint32_t v, uint32_t idx)
 {
     return (uint32_t) __builtin_amdgcn_readlane ((int) v, (int) idx);
 }
+
+/* butterfly exchange inside the wave */
+__device__ __forceinline__ uint32_t smol_shfl_xor (uint32_t v, uint32_t mask)
+{
+    return (uint32_t) __shfl_xor ((int) v, (int) mask, 64);
+}
 #endif
 
 /* vertical sample schedule: (row of the top tap, weight) for sample index jy */
@@ -335,18 +367,23 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
 }
 
 /* TAP: how taps are read. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples
- * per output column. STAGE_PREMUL: premultiply while staging (TAP_A4 only; uses
+ * per output column, 4 = box with one lane per column, 5 = box with 8 lanes per
+ * column (their partial sums meet through wave shuffles; for wide spans, so that
+ * 64 lanes still read consecutive LDS words). STAGE_PREMUL: premultiply while staging (TAP_A4 only; uses
  * the register path, single LDS buffer). CPL: adjacent output columns per lane
  * (a tile is 64*CPL columns wide) -- amortises the wave's scalar bookkeeping
  * when there is little vector work per column (magnification). */
 template <int TAP, int HM, int OUT, bool STAGE_PREMUL, int CPL>
 __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 {
-    constexpr bool HPAIR = (HM != 0);
-    constexpr uint32_t NSX = (HM == 0) ? 1u : (1u << (HM - 1));
-    constexpr uint32_t HX = (HM == 0) ? 0u : (uint32_t) (HM - 1);
+    constexpr bool HBOX = (HM >= 4);
+    constexpr uint32_t LPC = (HM == 5) ? 8u : 1u;            /* lanes per column (box only) */
+    constexpr bool HPAIR = (HM >= 1 && HM <= 3);
+    constexpr uint32_t NSX = HPAIR ? (1u << (HM - 1)) : 1u;
+    constexpr uint32_t HX = HPAIR ? (uint32_t) (HM - 1) : 0u;
     constexpr uint32_t BPP = (TAP == TAP_U3) ? 3u : 4u;
-    constexpr uint32_t TW = TILE_COLS * CPL;
+    constexpr uint32_t TW = TILE_COLS * CPL / LPC;
+    static_assert (!HBOX || CPL == 1, "box columns are one per lane group");
     constexpr bool DMA = !STAGE_PREMUL;
 
     const uint32_t lane = threadIdx.x;
@@ -361,13 +398,30 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
     const uint32_t x0 = tx * TW;
     const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;   /* one past last column */
-    const uint32_t xl = x0 + lane * CPL;                           /* this lane's first column */
+    const uint32_t xl = x0 + (lane / LPC) * CPL;                   /* this lane's first column */
+    const uint32_t sub = lane % LPC;                               /* position inside a column's lane group */
 
     /* ---- horizontal taps of this lane's columns (same for every row) ---------- */
     uint32_t tap_ofs [CPL][NSX], tap_f [CPL][NSX];
     uint32_t sx0, sx1;
 
-    if (HPAIR)
+    uint32_t box_n = 0, box_wl = 0, box_fr = 0, box_last = 0;     /* HBOX: interior count, edge weights */
+
+    if (HBOX)
+    {
+        /* column k covers source pixels o0..o1 (horizontal box, smolscale-generic.c:
+         * 1427-1479): left edge weighted wl, right edge weighted fr, interior in full */
+        const uint32_t xc = (xl < xn) ? xl : xn - 1;
+        uint32_t o0, o1, a, b, c2, d2;
+        box_span (J.step_x, J.w_in, xc, o0, o1, box_fr, box_wl);
+        box_n = o1 - o0 - 1;
+        tap_ofs [0][0] = o0;
+        tap_f [0][0] = 0;
+        box_last = o1;
+        box_span (J.step_x, J.w_in, x0, sx0, a, b, c2);
+        box_span (J.step_x, J.w_in, xn - 1, a, sx1, b, d2);
+    }
+    else if (HPAIR)
     {
 #pragma unroll
         for (int c = 0; c < CPL; c++)
@@ -408,6 +462,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 #pragma unroll
         for (uint32_t s = 0; s < NSX; s++)
             tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * BPP;   /* byte offset inside the span */
+    box_last = (box_last - sx0) * BPP;
 
     /* ---- vertical schedule ------------------------------------------------------
      * (source row of the top tap, weight) for every vertical sample of the tile,
@@ -415,6 +470,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
      * sched[k >> 6]) and fetched with v_readlane in the row loop: the wave's
      * scalar unit, shared by the whole CU, stays out of the 64-bit position
      * arithmetic. */
+    const bool vbox = (J.filter_v == F_BOX);
     const bool vpair = (J.filter_v == F_BILINEAR);
     const uint32_t hv = vpair ? J.halv_v : 0u;
     const uint32_t nsy = 1u << hv;
@@ -431,17 +487,33 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         if (k >= n_samples)
             k = n_samples - 1;
         uint32_t o, f;
-        tile_vsample (J, jy0 + k, o, f);
+        if (vbox)
+        {
+            /* one entry per output row: last source row of its box and that row's weight */
+            uint32_t o0, wl;
+            box_span (J.step_y, J.h_in, jy0 + k, o0, o, f, wl);
+        }
+        else
+        {
+            tile_vsample (J, jy0 + k, o, f);
+        }
         sched [q] = o | (f << 16);
     }
     uint32_t ks = 0;                                    /* running sample index in the tile */
     uint32_t s_y = 0;                                   /* sample within the output row     */
     uint32_t e = smol_readlane (sched [0], 0);
     uint32_t oy = e & 0xffffu, Fy = e >> 16;
-    const uint32_t row_first = oy;
+    uint32_t vy0 = 0, vw1 = 0;                          /* vbox: first row of the current box, its weight */
+    if (vbox)
+    {
+        uint32_t o1, f;
+        box_span (J.step_y, J.h_in, jy0, vy0, o1, f, vw1);
+    }
+    const uint32_t row_first = vbox ? vy0 : oy;
     const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
     const uint32_t row_last = (e_last & 0xffffu) + vlag;
     const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
+    const uint32_t xn_store = (sub == 0) ? xn : 0u;    /* only the first lane of a column group stores */
 
     Px2 hprev [CPL], acc [CPL];
 #pragma unroll
@@ -507,6 +579,39 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 {
                     h [c].lo = tap_ofs [c][0] + r; h [c].hi = tap_f [c][0];
                 }
+                else if (HBOX)
+                {
+                    uint32_t wp, wq;
+                    Px2 a = { 0, 0 };
+                    if (sub == 0)
+                    {
+                        tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis, wp, wq);
+                        a = px2_mulw (px2_from_word (wp), box_wl);
+                        tile_read_pair<TAP, false> (J, rowb, box_last + tmis, wp, wq);
+                        a = px2_add (a, px2_mulw (px2_from_word (wp), box_fr));
+                    }
+                    /* interior pixels: lane `sub' of the group takes every LPC-th one */
+                    for (uint32_t ii = sub; ii < J.box_nmax; ii += LPC)
+                    {
+                        if (ii < box_n)
+                        {
+                            tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis + (ii + 1) * BPP, wp, wq);
+                            a = px2_add (a, px2_from_word (wp));
+                        }
+                    }
+                    if (LPC > 1)
+                    {
+#pragma unroll
+                        for (uint32_t m = 1; m < LPC; m <<= 1)
+                        {
+                            Px2 o2;
+                            o2.lo = smol_shfl_xor (a.lo, m);
+                            o2.hi = smol_shfl_xor (a.hi, m);
+                            a = px2_add (a, o2);
+                        }
+                    }
+                    h [c] = px2_box_scale (a, J.span_mul_x);
+                }
                 else if (HM == 0)
                 {
                     uint32_t wp, wq;
@@ -528,6 +633,36 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 }
             }
 
+            if (vbox)
+            {
+                /* vertical box (smolscale-generic.c:2026-2161): rows arrive in order;
+                 * the box's first row is weighted vw1, interior rows count in full, its
+                 * last row (oy) is weighted Fy and, weighted 255 - Fy, also opens the
+                 * next box. Sums stay below 2^16 per lane, as in the reference. */
+                if (r == vy0)
+                    acc [0] = px2_mulw (h [0], vw1);
+                else if (r < oy)
+                    acc [0] = px2_add (acc [0], h [0]);
+                if (r == oy && ks < n_samples)
+                {
+                    Px2 o [CPL];
+                    o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
+                    if (!dbg_nostore || o [0].lo == 0x12345678u)
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, o);
+                    out_row += J.dst_stride;
+                    ks++;
+                    vy0 = oy;
+                    vw1 = 255u - Fy;
+                    acc [0] = px2_mulw (h [0], vw1);
+                    if (ks < n_samples)
+                    {
+                        e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
+                        oy = e & 0xffffu;
+                        Fy = e >> 16;
+                    }
+                }
+            }
+            else
             /* vertical: emit every sample whose last row is r */
             while (ks < n_samples && oy + vlag == r)
             {
@@ -548,7 +683,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     for (int c = 0; c < CPL; c++)
                         o [c] = px2_shr (acc [c], hv);
                     if (!dbg_nostore || o [0].lo == 0x12345678u)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn, interior, o);
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, o);
                     s_y = 0;
                     out_row += J.dst_stride;
                 }
@@ -586,7 +721,7 @@ __device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbu
 template <int TAP, bool STAGE_PREMUL>
 __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf)
 {
-    const uint32_t hm = (J.tile_variant >> 2) & 3u;
+    const uint32_t hm = (J.tile_variant >> 2) & 7u;
 
     if (J.tile_cpl == 4)
     {
@@ -603,15 +738,17 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
         case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL, 1> (J, sbuf); break;
         case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1> (J, sbuf); break;
         case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1> (J, sbuf); break;
-        default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1> (J, sbuf); break;
+        case 3:  tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1> (J, sbuf); break;
+        case 4:  tile_dispatch_out<TAP, 4, STAGE_PREMUL, 1> (J, sbuf); break;
+        default: tile_dispatch_out<TAP, 5, STAGE_PREMUL, 1> (J, sbuf); break;
     }
 }
 
-/* tile_variant = tapsel << 4 | HM << 2 | OUT; tapsel: 0 A4, 1 A4 + premultiply
+/* tile_variant = tapsel << 5 | HM << 2 | OUT; tapsel: 0 A4, 1 A4 + premultiply
  * while staging, 2 U4, 3 U3 (smol_jobdev.h: tile_setup) */
 __device__ __forceinline__ void tile_dispatch (const JobDev &J, uint8_t *sbuf)
 {
-    switch (J.tile_variant >> 4)
+    switch (J.tile_variant >> 5)
     {
         case 0:  tile_dispatch_hm<TAP_A4, false> (J, sbuf); break;
         case 1:  tile_dispatch_hm<TAP_A4, true> (J, sbuf); break;

@@ -54,14 +54,29 @@ static void run_grid (unsigned gx, unsigned gy, unsigned bx, F body)
             }
 }
 
+template <typename F>
+static void run_grid_2d (unsigned gx, unsigned bx, unsigned by, F body)
+{
+    gridDim = { gx, 1, 1 };
+    blockDim = { bx, by, 1 };
+    for (unsigned b = 0; b < gx; b++)
+        for (unsigned ty = 0; ty < by; ty++)
+            for (unsigned t = 0; t < bx; t++)
+            {
+                blockIdx = { b, 0, 0 };
+                threadIdx = { t, ty, 0 };
+                body ();
+            }
+}
+
 template <int HX>
 static void run_pow2_hy (const JobDev &J, unsigned gx)
 {
     switch (J.halv_v)
     {
-        case 0: run_grid (gx, 1, 256, [&] { k_pow2_one<HX, 0> (J); }); break;
-        case 1: run_grid (gx, 1, 256, [&] { k_pow2_one<HX, 1> (J); }); break;
-        default: run_grid (gx, 1, 256, [&] { k_pow2_one<HX, 2> (J); }); break;
+        case 0: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 0> (J); }); break;
+        case 1: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 1> (J); }); break;
+        default: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 2> (J); }); break;
     }
 }
 
@@ -85,7 +100,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
         const uint32_t rx = 2u << J.halv_h;
         const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
         const uint32_t tcols = J.w_out / opt;
-        unsigned gx = ((tcols + 255) / 256) * n_rows;
+        unsigned gx = ((tcols + 63) / 64) * ((n_rows + 15) / 16);
         switch (J.halv_h)
         {
             case 0: run_pow2_hy<0> (J, gx); break;
@@ -97,7 +112,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
 
     if (k == KC_TILE)
     {
-        const uint32_t tw = TILE_COLS * J.tile_cpl;
+        const uint32_t tw = TILE_COLS * J.tile_cpl / J.tile_lpc;
         const uint32_t tiles_x = (J.w_out + tw - 1) / tw;
         const uint32_t tiles_y = (n_rows + J.tile_rows - 1) / J.tile_rows;
         run_grid_coop (tiles_x * tiles_y, 64, tile_lds_bytes (J), [&] { k_tile_one (J); });

@@ -67,3 +67,12 @@ static inline uint32_t smol_readlane (uint32_t v, uint32_t idx)
     __syncthreads ();
     return r;
 }
+
+static inline uint32_t smol_shfl_xor (uint32_t v, uint32_t mask)
+{
+    emu_lane_xchg [threadIdx.x] = v;
+    __syncthreads ();
+    uint32_t r = emu_lane_xchg [threadIdx.x ^ mask];
+    __syncthreads ();
+    return r;
+}
