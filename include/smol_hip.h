@@ -127,6 +127,10 @@ typedef struct SmolHipBatch SmolHipBatch;
 int smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device,
                            SmolHipBatch **batch_out);
 int smol_hip_batch_launch (SmolHipBatch *batch, void *hip_stream);
+/* enable != 0: submit the batch as a hipGraph holding one kernel node per image
+ * (captured once, replayed by smol_hip_batch_launch) instead of one launch per
+ * kernel class over a device-resident descriptor table. Same results; for A/B. */
+int smol_hip_batch_use_graph (SmolHipBatch *batch, int enable);
 /* Number of kernel launches one smol_hip_batch_launch() issues, and the name of
  * the dominant kernel (for matching against rocprofv3 --stats). */
 int smol_hip_batch_info (const SmolHipBatch *batch, uint32_t *n_launches, const char **kernel_name);

@@ -98,6 +98,7 @@ EXPORTS = {
     "smol_hip_scale_rows_device": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp]),
     "smol_hip_batch_create": (_int, [ctypes.POINTER(SmolHipImage), _u32, _int, ctypes.POINTER(_vp)]),
     "smol_hip_batch_launch": (_int, [_vp, _vp]),
+    "smol_hip_batch_use_graph": (_int, [_vp, _int]),
     "smol_hip_batch_info": (_int, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_char_p)]),
     "smol_hip_batch_destroy": (None, [_vp]),
     "smol_hip_batch_time": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
@@ -224,6 +225,9 @@ class HipBatch:
 
     def launch(self, stream=None):
         check(lib().smol_hip_batch_launch(self._h, stream), "smol_hip_batch_launch")
+
+    def use_graph(self, enable=True):
+        check(lib().smol_hip_batch_use_graph(self._h, int(enable)), "smol_hip_batch_use_graph")
 
     def time(self, warmup, iters):
         ms = ctypes.c_float(0)

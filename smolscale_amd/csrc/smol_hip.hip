@@ -180,6 +180,10 @@ struct SmolHipBatch
     std::vector<Group> groups;
     uint64_t dominant_units = 0;
     const char *dominant_name = "";
+    std::vector<JobDev> jobs_host;         /* same order as jobs_dev */
+    hipGraph_t graph = nullptr;            /* optional: one kernel node per image */
+    hipGraphExec_t graph_exec = nullptr;
+    bool use_graph = false;
 };
 
 extern "C" {
@@ -393,7 +397,49 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
         return -(int) e;
     }
 
+    b->jobs_host = sorted;
     *batch_out = b;
+    return 0;
+}
+
+/* Alternative submission form for the same batch: every image becomes its own
+ * kernel node (descriptor by value) of a hipGraph captured once and replayed by
+ * smol_hip_batch_launch(). Exists to measure BASELINE config 5's "hipGraph-captured
+ * per-image launches" against the default one-launch-per-kernel-class form. */
+int
+smol_hip_batch_use_graph (SmolHipBatch *batch, int enable)
+{
+    if (!batch)
+        return SMOL_HIP_E_INVALID;
+    if (!enable)
+    {
+        batch->use_graph = false;
+        return 0;
+    }
+    HIP_TRY (hipSetDevice (batch->device));
+    if (!batch->graph_exec)
+    {
+        hipStream_t cs;
+        HIP_TRY (hipStreamCreateWithFlags (&cs, hipStreamNonBlocking));
+        HIP_TRY (hipStreamBeginCapture (cs, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipSuccess;
+        for (const JobDev &jd : batch->jobs_host)
+        {
+            if (jd.n_rows == 0)
+                continue;
+            e = launch_class (classify (jd), nullptr, 1, jd, jd.w_out, jd.n_rows, cs);
+            if (e != hipSuccess)
+                break;
+        }
+        hipError_t e2 = hipStreamEndCapture (cs, &batch->graph);
+        (void) hipStreamDestroy (cs);
+        if (e != hipSuccess)
+            return -(int) e;
+        if (e2 != hipSuccess)
+            return -(int) e2;
+        HIP_TRY (hipGraphInstantiate (&batch->graph_exec, batch->graph, nullptr, nullptr, 0));
+    }
+    batch->use_graph = true;
     return 0;
 }
 
@@ -406,6 +452,11 @@ smol_hip_batch_launch (SmolHipBatch *batch, void *hip_stream)
     hipStream_t s = static_cast<hipStream_t> (hip_stream);
 
     HIP_TRY (hipSetDevice (batch->device));
+    if (batch->use_graph)
+    {
+        HIP_TRY (hipGraphLaunch (batch->graph_exec, s));
+        return 0;
+    }
     for (const SmolHipBatch::Group &g : batch->groups)
         HIP_TRY (launch_class (g.k, batch->jobs_dev + g.first, g.count, g.rep, g.max_w_out, g.max_rows, s, g.max_lds));
     return 0;
@@ -428,8 +479,15 @@ smol_hip_batch_destroy (SmolHipBatch *batch)
 {
     if (!batch)
         return;
-    if (hipSetDevice (batch->device) == hipSuccess && batch->jobs_dev)
-        (void) hipFree (batch->jobs_dev);
+    if (hipSetDevice (batch->device) == hipSuccess)
+    {
+        if (batch->jobs_dev)
+            (void) hipFree (batch->jobs_dev);
+        if (batch->graph_exec)
+            (void) hipGraphExecDestroy (batch->graph_exec);
+        if (batch->graph)
+            (void) hipGraphDestroy (batch->graph);
+    }
     delete batch;
 }
 

@@ -14,6 +14,7 @@
  * library reports why on stderr and abort()s -- the reference's own reaction to
  * an unusable configuration (smolscale.c:779-780, 812-813). No CPU fallback. */
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -22,6 +23,8 @@
 #include "smol_hip.h"
 
 typedef struct SmolBackend SmolBackend;
+
+#define SMOL_MAX_DEVICES 16
 
 struct SmolScaleCtx
 {
@@ -36,7 +39,9 @@ struct SmolScaleCtx
     void *user_data;
 
     const SmolBackend *backend;
-    void *backend_state;
+    void *backend_state;            /* SmolHipPlan * of the first device        */
+    void *more_plans [SMOL_MAX_DEVICES - 1];   /* further devices (row sharding) */
+    int n_plans;
 };
 
 /* The seam. init() plans the job and acquires backend resources; batch() must
@@ -52,19 +57,68 @@ struct SmolBackend
 
 /* ---- HIP backend ------------------------------------------------------------ */
 
+/* Which GPUs a context uses. SMOL_HIP_DEVICES="0,1,2,3" or "all": output rows of
+ * every batch are split into one strip per listed device (the reference's own
+ * strip rule for its worker threads, test.c:870-877) and the strips run
+ * concurrently, each on its device's stream -- rows are independent, so there is
+ * no exchange between devices. A device may be listed more than once.
+ * Without it, SMOL_HIP_DEVICE=<n> (default 0) selects a single GPU. */
 static int
-hip_device_from_env (void)
+hip_devices_from_env (int *devices)
 {
-    const char *e = getenv ("SMOL_HIP_DEVICE");
-    return e ? atoi (e) : 0;
+    const char *e = getenv ("SMOL_HIP_DEVICES");
+    int n = 0;
+
+    if (e && *e)
+    {
+        if (!strcmp (e, "all"))
+        {
+            int count = smol_hip_device_count ();
+            for (n = 0; n < count && n < SMOL_MAX_DEVICES; n++)
+                devices [n] = n;
+        }
+        else
+        {
+            const char *p = e;
+            while (*p && n < SMOL_MAX_DEVICES)
+            {
+                devices [n++] = atoi (p);
+                while (*p && *p != ',')
+                    p++;
+                if (*p == ',')
+                    p++;
+            }
+        }
+    }
+
+    if (n == 0)
+    {
+        e = getenv ("SMOL_HIP_DEVICE");
+        devices [0] = e ? atoi (e) : 0;
+        n = 1;
+    }
+    return n;
+}
+
+static void
+hip_backend_fini (SmolScaleCtx *ctx)
+{
+    int i;
+
+    if (ctx->backend_state)
+        smol_hip_plan_destroy ((SmolHipPlan *) ctx->backend_state);
+    for (i = 0; i + 1 < ctx->n_plans; i++)
+        smol_hip_plan_destroy ((SmolHipPlan *) ctx->more_plans [i]);
+    ctx->backend_state = NULL;
+    ctx->n_plans = 0;
 }
 
 static int
 hip_backend_init (SmolScaleCtx *ctx)
 {
     SmolHipJob job;
-    SmolHipPlan *plan = NULL;
-    int rc;
+    int devices [SMOL_MAX_DEVICES];
+    int n, i, rc;
 
     rc = smol_hip_plan_job (ctx->pixel_type_in, ctx->width_in, ctx->height_in,
                             ctx->pixel_type_out, ctx->width_out, ctx->height_out,
@@ -72,27 +126,89 @@ hip_backend_init (SmolScaleCtx *ctx)
     if (rc)
         return rc;
 
-    rc = smol_hip_plan_create (&job, hip_device_from_env (), &plan);
-    if (rc)
-        return rc;
+    n = hip_devices_from_env (devices);
+    ctx->n_plans = 0;
+    for (i = 0; i < n; i++)
+    {
+        SmolHipPlan *plan = NULL;
 
-    ctx->backend_state = plan;
+        rc = smol_hip_plan_create (&job, devices [i], &plan);
+        if (rc)
+        {
+            hip_backend_fini (ctx);
+            return rc;
+        }
+        if (i == 0)
+            ctx->backend_state = plan;
+        else
+            ctx->more_plans [i - 1] = plan;
+        ctx->n_plans = i + 1;
+    }
     return 0;
+}
+
+typedef struct
+{
+    const SmolScaleCtx *ctx;
+    SmolHipPlan *plan;
+    void *dest;
+    uint32_t first, n;
+    int rc;
+}
+HipStrip;
+
+static void *
+hip_strip_worker (void *arg)
+{
+    HipStrip *s = arg;
+
+    s->rc = smol_hip_scale_rows_host (s->plan, s->ctx->pixels_in, s->ctx->rowstride_in,
+                                      s->dest, s->ctx->rowstride_out, s->first, s->n);
+    return NULL;
 }
 
 static int
 hip_backend_batch (const SmolScaleCtx *ctx, void *dest, uint32_t first, uint32_t n)
 {
-    return smol_hip_scale_rows_host ((SmolHipPlan *) ctx->backend_state,
-                                     ctx->pixels_in, ctx->rowstride_in,
-                                     dest, ctx->rowstride_out, first, n);
-}
+    HipStrip strips [SMOL_MAX_DEVICES];
+    pthread_t tids [SMOL_MAX_DEVICES];
+    uint32_t rows, done = 0;
+    int n_strips = 0, i, rc = 0;
 
-static void
-hip_backend_fini (SmolScaleCtx *ctx)
-{
-    smol_hip_plan_destroy ((SmolHipPlan *) ctx->backend_state);
-    ctx->backend_state = NULL;
+    if (ctx->n_plans <= 1 || n < (uint32_t) ctx->n_plans)
+        return smol_hip_scale_rows_host ((SmolHipPlan *) ctx->backend_state,
+                                         ctx->pixels_in, ctx->rowstride_in,
+                                         dest, ctx->rowstride_out, first, n);
+
+    rows = (n + (uint32_t) ctx->n_plans - 1) / (uint32_t) ctx->n_plans;
+    for (i = 0; i < ctx->n_plans && done < n; i++)
+    {
+        HipStrip *s = &strips [n_strips];
+
+        s->ctx = ctx;
+        s->plan = (SmolHipPlan *) (i == 0 ? ctx->backend_state : ctx->more_plans [i - 1]);
+        s->first = first + done;
+        s->n = (n - done < rows) ? n - done : rows;
+        s->dest = (char *) dest + (size_t) ctx->rowstride_out * done;
+        s->rc = 0;
+        done += s->n;
+        if (pthread_create (&tids [n_strips], NULL, hip_strip_worker, s) != 0)
+        {
+            hip_strip_worker (s);          /* no thread available: run it here */
+            tids [n_strips] = (pthread_t) 0;
+            if (s->rc && !rc)
+                rc = s->rc;
+            continue;
+        }
+        n_strips++;
+    }
+    for (i = 0; i < n_strips; i++)
+    {
+        pthread_join (tids [i], NULL);
+        if (strips [i].rc && !rc)
+            rc = strips [i].rc;
+    }
+    return rc;
 }
 
 static const SmolBackend hip_backend =

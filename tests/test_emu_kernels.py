@@ -23,10 +23,13 @@ def test_emulated_general_kernels_match_oracle():
         first = rng.randint(0, h_out - 1)
         n = rng.randint(1, h_out - first)
         want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
-        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        # force_general=1 keeps the per-pixel backstop kernels under test now that
+        # k_tile takes every 64bpp-class job
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n,
+                             force_general=it & 1)
         seen.add(k)
         assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb, first, n, k)
-    assert {0, 1} <= seen
+    assert {0, 1, 3} <= seen
 
 
 def test_emulated_pow2_kernel_matches_oracle():
@@ -55,3 +58,86 @@ def test_emulated_kernels_match_golden_subset():
         src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)
         got, _ = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
         assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+
+
+def _fuzz_tile(rng, dims_fn, n_cases, want_class=3, allow_box=True, max_in=400_000, max_out=8000):
+    import helpers as H
+    done = 0
+    it = 0
+    while done < n_cases:
+        it += 1
+        w_in, w_out = dims_fn(rng)
+        h_in, h_out = dims_fn(rng)
+        if w_in * h_in > max_in or w_out * h_out > max_out:
+            continue
+        t_in, t_out = rng.randrange(10), rng.randrange(10)
+        if 4 <= t_in <= 7 and 4 <= t_out <= 7:
+            continue                                   # premul16 -> wide class, not k_tile
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+        if job.wide:
+            continue
+        done += 1
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 3, 4, 16])
+        sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 5, 8])
+        raw = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=32)
+        src = H.aligned_copy(np.concatenate([np.zeros(rng.choice([0, 0, 1, 2, 4]), np.uint8), raw]))
+        src = src[src.size - raw.size:]                # random misalignment of the base
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n, force_general=2)
+        assert k == want_class
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, first, n, sin, sout)
+
+
+def test_emulated_tile_kernel_bilinear_family():
+    def dims(rng):
+        cls = rng.choice(["one", "copy", "up", "0h", "1h", "2h", "wideup", "widedown"])
+        if cls == "one":
+            return 1, rng.randint(1, 200)
+        if cls == "copy":
+            d = rng.randint(1, 300)
+            return d, d
+        if cls == "up":
+            i = rng.randint(2, 60)
+            return i, rng.randint(i + 1, 6 * i + 3)
+        if cls == "0h":
+            o = rng.randint(1, 150)
+            return rng.randint(o + 1, 2 * o), o
+        if cls == "1h":
+            o = rng.randint(1, 100)
+            return rng.randint(2 * o + 1, 4 * o), o
+        if cls == "2h":
+            o = rng.randint(1, 70)
+            return rng.randint(4 * o + 1, 8 * o), o
+        if cls == "wideup":
+            i = rng.randint(40, 120)
+            return i, rng.randint(300, 700)
+        o = rng.randint(65, 200)
+        return rng.randint(o + 1, 8 * o), o
+    _fuzz_tile(random.Random(2024), dims, 60)
+
+
+def test_emulated_tile_kernel_box_filters():
+    def dims(rng):
+        cls = rng.choice(["box", "box", "boxbig", "copy", "0h", "1h", "up", "one"])
+        if cls == "box":
+            o = rng.randint(1, 80)
+            return rng.randint(8 * o + 1, min(24 * o, 4000)), o
+        if cls == "boxbig":
+            o = rng.randint(1, 12)
+            return rng.randint(24 * o + 1, min(255 * o, 3000)), o
+        if cls == "copy":
+            d = rng.randint(1, 100)
+            return d, d
+        if cls == "one":
+            return 1, rng.randint(1, 80)
+        if cls == "up":
+            i = rng.randint(2, 40)
+            return i, rng.randint(i + 1, 4 * i)
+        if cls == "0h":
+            o = rng.randint(1, 80)
+            return rng.randint(o + 1, 2 * o), o
+        o = rng.randint(1, 60)
+        return rng.randint(2 * o + 1, 4 * o), o
+    _fuzz_tile(random.Random(77), dims, 60)

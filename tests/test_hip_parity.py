@@ -85,6 +85,27 @@ def test_pow2_fast_path_vs_oracle():
         assert np.array_equal(got, want), (hx, hy, w_out, h_out, t_in, t_out)
 
 
+def test_tile_kernel_wide_images_and_box_shapes():
+    """Geometries that select every k_tile layout: 4 columns per lane (wide, few taps),
+    one column per lane, box with 1 and with 8 lanes per column, box on one axis only."""
+    shapes = [
+        (4, 480, 270, 0, 1920, 1080), (0, 1000, 700, 1, 1000, 300), (8, 1, 37, 2, 900, 37),
+        (0, 3000, 900, 0, 1700, 500), (9, 2000, 300, 0, 300, 100), (1, 2500, 1000, 5, 330, 330),
+        (0, 4096, 1024, 0, 448, 112), (2, 4000, 120, 3, 20, 120), (8, 3000, 600, 0, 100, 7),
+        (0, 640, 4000, 4, 320, 40), (5, 900, 901, 0, 100, 450), (0, 5000, 64, 8, 25, 64),
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out) in enumerate(shapes):
+        for (sin_pad, mis) in ((0, 0), (3, 1)):
+            sin = w_in * H.bpp(t_in) + sin_pad
+            src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=32)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "host", sin_pad)
+            got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin,
+                                     src_misalign=mis, dst_misalign=mis)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
+
+
 def test_strip_split_determinism():
     """Any partition of the output rows gives the one-shot bytes."""
     rng = random.Random(9)
@@ -174,9 +195,16 @@ def test_batched_images_mixed_types_single_call():
     assert 1 <= n_launches <= 3 and name
     batch.launch()
     sm.check(lib.smol_hip_device_synchronize(0))
-    for (t_in, t_out), src, (dsrc, ddst) in zip(specs, srcs, dbufs):
-        want = H.oracle_scale(src, t_in, 256, 256, t_out, 64, 64)
-        assert np.array_equal(ddst.download(), want), (t_in, t_out)
+    wants = [H.oracle_scale(src, t_in, 256, 256, t_out, 64, 64) for (t_in, t_out), src in zip(specs, srcs)]
+    for want, (dsrc, ddst), spec in zip(wants, dbufs, specs):
+        assert np.array_equal(ddst.download(), want), spec
+        ddst.fill(0)
+    # the same batch as a hipGraph of per-image kernel nodes
+    batch.use_graph(True)
+    batch.launch()
+    sm.check(lib.smol_hip_device_synchronize(0))
+    for want, (dsrc, ddst), spec in zip(wants, dbufs, specs):
+        assert np.array_equal(ddst.download(), want), spec
         dsrc.free()
         ddst.free()
     batch.destroy()
@@ -222,6 +250,21 @@ def test_concurrent_batches_on_one_context():
         t.join()
     ctx.destroy()
     assert np.array_equal(dst, H.oracle_scale(src, 0, 1600, 1200, 0, 400, 300))
+
+
+def test_rows_sharded_over_several_device_entries(monkeypatch):
+    """SMOL_HIP_DEVICES splits every batch into one strip per listed device, run
+    concurrently; listing device 0 three times exercises the sharding on one GPU."""
+    monkeypatch.setenv("SMOL_HIP_DEVICES", "0,0,0")
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
+            (0, 1024, 1024, 0, 256, 256, 0), (4, 300, 200, 1, 777, 501, 0), (0, 2000, 1500, 0, 100, 77, 0),
+            (6, 128, 128, 7, 32, 32, 1), (8, 513, 2, 2, 64, 2, 0)):
+        src = H.make_input(t_in, w_in, h_in, seed=12, valid=True, pad=16)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)), (t_in, w_in, t_out, w_out)
+        part = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, first=h_out // 3, n=h_out - h_out // 3)
+        stride = w_out * H.bpp(t_out)
+        assert np.array_equal(part, got[(h_out // 3) * stride:])
 
 
 def test_edge_sizes():

@@ -40,7 +40,7 @@ def bpp(t):
     return sm.bytes_per_pixel(t)
 
 
-def run_config(name, iters, warmup, check):
+def run_config(name, iters, warmup, check, graph=False):
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = CONFIGS[name]
     rng = np.random.default_rng(12345)
     images, bufs, specs = [], [], []
@@ -78,6 +78,9 @@ def run_config(name, iters, warmup, check):
 
     batch = sm.HipBatch(images)
     n_launches, kname = batch.info()
+    if graph:
+        batch.use_graph(True)
+        kname += " (hipGraph: one kernel node per image)"
     ms = batch.time(warmup, iters)
     per_step_ms = ms / iters
     algo = total_in + total_out
@@ -112,9 +115,10 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="submit each batch as a hipGraph of per-image launches")
     args = ap.parse_args()
     for name in args.configs.split(","):
-        print(json.dumps(run_config(name, args.iters, args.warmup, args.check)), flush=True)
+        print(json.dumps(run_config(name, args.iters, args.warmup, args.check, args.graph)), flush=True)
 
 
 if __name__ == "__main__":
