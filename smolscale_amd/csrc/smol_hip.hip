@@ -78,7 +78,7 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         return hipGetLastError ();
     }
 
-    if (k == KC_TILE)
+    if (k == KC_TILE || k == KC_WTILE)
     {
         /* groups share tile_rows and LDS size (see smol_hip_batch_create) */
         const uint32_t tw = smolhip::TILE_COLS * rep.tile_cpl / rep.tile_lpc;
@@ -87,7 +87,14 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         dim3 grid (tiles_x * tiles_y, n_jobs);
         const uint32_t lds = max_lds ? max_lds : tile_lds_bytes (rep);
 
-        if (jobs_dev)
+        if (k == KC_WTILE)
+        {
+            if (jobs_dev)
+                hipLaunchKernelGGL (smolhip::k_wtile_batch, grid, dim3 (64), lds, s, jobs_dev);
+            else
+                hipLaunchKernelGGL (smolhip::k_wtile_one, grid, dim3 (64), lds, s, rep);
+        }
+        else if (jobs_dev)
             hipLaunchKernelGGL (smolhip::k_tile_batch, grid, dim3 (64), lds, s, jobs_dev);
         else
             hipLaunchKernelGGL (smolhip::k_tile_one, grid, dim3 (64), lds, s, rep);
@@ -363,7 +370,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2 && (jobs [j].halv_h != g.rep.halv_h || jobs [j].halv_v != g.rep.halv_v))
                 continue;
-            if (g.k == KC_TILE && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl
+            if ((g.k == KC_TILE || g.k == KC_WTILE) && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl
                                   || jobs [j].tile_lpc != g.rep.tile_lpc))
                 continue;
             if (g.count == 65535)
@@ -373,7 +380,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             g.count++;
             if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
             if (jobs [j].n_rows > g.max_rows) g.max_rows = jobs [j].n_rows;
-            if (g.k == KC_TILE && tile_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = tile_lds_bytes (jobs [j]);
+            if ((g.k == KC_TILE || g.k == KC_WTILE) && tile_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = tile_lds_bytes (jobs [j]);
             units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
         }
 

@@ -43,6 +43,7 @@ struct JobDev
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
     uint32_t span_chunks_inv;      /* floor(2^32 / span_chunks) + 1                      */
     uint32_t box_nmax;             /* horizontal box: most interior pixels any column has */
+    uint32_t span_px;              /* k_wtile: most source pixels a tile's span can hold  */
 };
 
 namespace dispatch {
@@ -57,7 +58,7 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -69,19 +70,33 @@ tile_ok (const JobDev &d)
     return !d.wide;     /* 64bpp-class math: bilinear 0-2H, copy, one and box (ratio <= 255) */
 }
 
+/* 128bpp-class jobs without a box axis go to k_wtile */
+inline bool
+wtile_ok (const JobDev &d)
+{
+    if (!d.wide || d.filter_h == F_BOX || d.filter_v == F_BOX || getenv ("SMOL_NO_WTILE"))
+        return false;
+    /* Measured (profiles/r01b_wide_kernels.log): converting each staged pixel once
+     * pays when pixels or rows are re-used -- magnification (2.2-3x over k_general)
+     * -- and loses ~25-60 % when every source pixel feeds a single tap. */
+    const bool h_reuse = d.filter_h != F_BILINEAR || d.step_x < ((uint64_t) 1 << 32);
+    const bool v_reuse = d.filter_v == F_ONE || (d.filter_v == F_BILINEAR && d.step_y < ((uint64_t) 1 << 32));
+    return h_reuse || v_reuse;
+}
+
 /* Geometry of k_tile for this job: how many source pixels a 64-column tile can
  * span (bound from the closed-form sampling positions), how many source rows fit
  * one LDS phase, how many output rows a tile produces. */
 inline void
 tile_setup (JobDev &d)
 {
-    if (!tile_ok (d))
+    if (!tile_ok (d) && !wtile_ok (d))
         return;
 
     /* few taps per column (COPY/ONE/one sample) and a wide enough image: a lane
      * takes 4 adjacent columns, which amortises the wave's scalar bookkeeping and
      * turns its stores into 16-byte ones */
-    d.tile_cpl = (d.filter_h != F_BOX && d.filter_v != F_BOX
+    d.tile_cpl = (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX
                   && (d.filter_h != F_BILINEAR || d.halv_h == 0) && d.w_out >= 256) ? 4 : 1;
     uint64_t cols = 64u * d.tile_cpl;
     uint32_t box_lpc = 1;
@@ -107,7 +122,8 @@ tile_setup (JobDev &d)
     d.span_chunks = (bytes + 15) / 16;
     d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / d.span_chunks) + 1;
 
-    uint32_t budget = TILE_LDS_BUDGET;
+    d.span_px = (uint32_t) span_px;
+    uint32_t budget = d.wide ? TILE_LDS_BUDGET / 2 : TILE_LDS_BUDGET;
     if (const char *e = getenv ("SMOL_TILE_LDS_BUDGET"))
         budget = (uint32_t) atoi (e);
     if (const char *e = getenv ("SMOL_TILE_DBG"))
@@ -163,7 +179,10 @@ tile_setup (JobDev &d)
 inline uint32_t
 tile_lds_bytes (const JobDev &d)
 {
-    return 2 * d.group_rows * d.span_chunks * 16 + 32;
+    uint32_t bytes = 2 * d.group_rows * d.span_chunks * 16 + 32;
+    if (d.wide)
+        bytes += d.group_rows * d.span_px * ((d.p16 && d.linear) ? 16 : 8);   /* converted rows (k_wtile) */
+    return bytes;
 }
 
 inline void
@@ -244,6 +263,8 @@ classify (const JobDev &d)
         return KC_POW2;
     if (tile_ok (d))
         return KC_TILE;
+    if (wtile_ok (d))
+        return KC_WTILE;
     return d.wide ? KC_GENERAL_WIDE : KC_GENERAL;
 }
 
@@ -254,6 +275,7 @@ kclass_name (KClass k, const JobDev &d)
     {
         case KC_POW2: return "k_pow2_batch";
         case KC_TILE: return "k_tile_batch";
+        case KC_WTILE: return "k_wtile_batch";
         case KC_GENERAL_WIDE: return "k_general_batch<true>";
         default: return "k_general_batch<false>";
     }

@@ -122,6 +122,13 @@ __device__ __forceinline__ uint32_t premul_word (uint32_t w, uint32_t ain)
     return (r & ~am) | (w & am);
 }
 
+/* 4 bytes starting at an arbitrary LDS byte offset, through 4-byte aligned reads */
+__device__ __forceinline__ uint32_t lds_load_unaligned (const uint8_t *sb, uint32_t off)
+{
+    const uint32_t *pp = reinterpret_cast<const uint32_t *> (sb + (off & ~3u));
+    return __builtin_amdgcn_alignbyte (pp [1], pp [0], off & 3u);
+}
+
 /* How a lane reads its taps from the staged row */
 enum : int
 {
@@ -379,7 +386,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     constexpr bool HBOX = (HM >= 4);
     constexpr uint32_t LPC = (HM == 5) ? 8u : 1u;            /* lanes per column (box only) */
     constexpr bool HPAIR = (HM >= 1 && HM <= 3);
-    constexpr uint32_t NSX = HPAIR ? (1u << (HM - 1)) : 1u;
+    constexpr uint32_t NSX = HPAIR ? (1u << (HPAIR ? HM - 1 : 0)) : 1u;
     constexpr uint32_t HX = HPAIR ? (uint32_t) (HM - 1) : 0u;
     constexpr uint32_t BPP = (TAP == TAP_U3) ? 3u : 4u;
     constexpr uint32_t TW = TILE_COLS * CPL / LPC;

@@ -81,36 +81,17 @@ __device__ __forceinline__ uint32_t box_scale (uint32_t acc, uint32_t mul)
  *   64bpp-class: smolscale-generic.c:353-464                                *
  *   128bpp-class: :470-752                                                  *
  * ------------------------------------------------------------------------- */
+/* raw pixel word (bytes in memory order; only 3 valid bytes for 24bpp) ->
+ * internal premultiplied channels c[0..2] = R,G,B, c[3] = alpha lane */
 template <bool WIDE>
-__device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, uint32_t x,
-                                          uint32_t (&c) [4])
+__device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32_t (&c) [4])
 {
     uint32_t a;
 
-    if (J.bpp_in == 4)
-    {
-        const uint8_t *p = rowp + (size_t) x * 4;
-        uint32_t w;
-
-        if (J.in_dword_ok)
-            w = *reinterpret_cast<const uint32_t *> (p);
-        else
-            w = (uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t) p [2] << 16) | ((uint32_t) p [3] << 24);
-
-        c [0] = (w >> (8 * J.pos_in [0])) & 0xffu;
-        c [1] = (w >> (8 * J.pos_in [1])) & 0xffu;
-        c [2] = (w >> (8 * J.pos_in [2])) & 0xffu;
-        a = (w >> (8 * J.pos_in [3])) & 0xffu;
-    }
-    else
-    {
-        const uint8_t *p = rowp + (size_t) x * 3;
-
-        c [0] = p [J.pos_in [0]];
-        c [1] = p [J.pos_in [1]];
-        c [2] = p [J.pos_in [2]];
-        a = 0xffu;
-    }
+    c [0] = (w >> (8 * J.pos_in [0])) & 0xffu;
+    c [1] = (w >> (8 * J.pos_in [1])) & 0xffu;
+    c [2] = (w >> (8 * J.pos_in [2])) & 0xffu;
+    a = (J.bpp_in == 4) ? (w >> (8 * J.pos_in [3])) & 0xffu : 0xffu;
 
     if (WIDE && J.p16)
     {
@@ -145,6 +126,31 @@ __device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, 
     }
 
     c [3] = a;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, uint32_t x,
+                                          uint32_t (&c) [4])
+{
+    uint32_t w;
+
+    if (J.bpp_in == 4)
+    {
+        const uint8_t *p = rowp + (size_t) x * 4;
+
+        if (J.in_dword_ok)
+            w = *reinterpret_cast<const uint32_t *> (p);
+        else
+            w = (uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t) p [2] << 16) | ((uint32_t) p [3] << 24);
+    }
+    else
+    {
+        const uint8_t *p = rowp + (size_t) x * 3;
+
+        w = (uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t) p [2] << 16);
+    }
+
+    unpack_word<WIDE> (J, w, c);
 }
 
 /* ------------------------------------------------------------------------- *
@@ -607,3 +613,4 @@ k_pow2_one (const JobDev J)
 } /* namespace smolhip */
 
 #include "smol_kernel_tile.hip.h"
+#include "smol_kernel_wtile.hip.h"

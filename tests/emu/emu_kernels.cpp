@@ -88,7 +88,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
     JobDev J;
     fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
     KClass k = classify (J);
-    if (force_general && (k == KC_POW2 || k == KC_TILE))
+    if (force_general && (k == KC_POW2 || k == KC_TILE || k == KC_WTILE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
     if (force_general == 2 && tile_ok (J))
         k = KC_TILE;                      /* force the tiled kernel where the fast path would win */
@@ -107,6 +107,14 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
             case 1: run_pow2_hy<1> (J, gx); break;
             default: run_pow2_hy<2> (J, gx); break;
         }
+        return 0;
+    }
+
+    if (k == KC_WTILE)
+    {
+        const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+        const uint32_t tiles_y = (n_rows + J.tile_rows - 1) / J.tile_rows;
+        run_grid_coop (tiles_x * tiles_y, 64, tile_lds_bytes (J), [&] { k_wtile_one (J); });
         return 0;
     }
 

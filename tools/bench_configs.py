@@ -33,6 +33,13 @@ CONFIGS = {
     "C5": (0, 256, 256, None, 0, 64, 64, 10000, "10000 thumbnails 256^2->64^2 RGBA8 premul (1H/1H), one batch"),
     "C5mix": (-1, 256, 256, None, -1, 64, 64, 10000, "10000 thumbnails 256^2->64^2, pixel types drawn uniformly from the 10x10 table"),
     "BOX": (0, 4096, 4096, None, 0, 448, 448, 8, "4096^2->448^2 RGBA8 premul (BOX/BOX 64bpp), 8 frames per launch"),
+    # 128bpp-class rows: premul16 and sRGB-linear internal formats
+    "P16": (4, 4096, 4096, None, 4, 1024, 1024, 4, "4096^2->1024^2 RGBA8 unassociated->unassociated (premul16, 128bpp class), 4 frames"),
+    "SRGB": (0, 4096, 4096, None, 0, 1024, 1024, 4, "4096^2->1024^2 RGBA8 premul with_srgb=1 (linear, 128bpp class), 4 frames", 1),
+    "P16UP": (4, 1920, 1080, None, 4, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 unassociated->unassociated (premul16 magnify), 2 frames"),
+    "SRGBUP": (0, 1920, 1080, None, 0, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 premul with_srgb=1 (linear magnify), 2 frames", 1),
+    "P16HALF": (4, 4096, 4096, None, 4, 2731, 2731, 2, "4096^2->2731^2 unassociated->unassociated (premul16, ratio 1.5), 2 frames"),
+    "BOX128": (0, 8192, 8192, None, 0, 30, 30, 2, "8192^2->30^2 RGBA8 premul (BOX ratio 273 > 255: 128bpp class), 2 frames"),
 }
 
 
@@ -41,7 +48,9 @@ def bpp(t):
 
 
 def run_config(name, iters, warmup, check, graph=False):
-    t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = CONFIGS[name]
+    cfg = CONFIGS[name]
+    t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
+    srgb = cfg[9] if len(cfg) > 9 else 0
     rng = np.random.default_rng(12345)
     images, bufs, specs = [], [], []
     total_in = total_out = 0
@@ -66,7 +75,7 @@ def run_config(name, iters, warmup, check, graph=False):
         if i == 0:
             host_src_kept = host[:n_in].copy()
         im = sm.SmolHipImage()
-        im.job = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+        im.job = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
         im.src, im.dst = dsrc.ptr, ddst.ptr
         im.rowstride_in, im.rowstride_out = s_in, s_out
         im.first_row, im.n_rows = 0, h_out
@@ -100,7 +109,7 @@ def run_config(name, iters, warmup, check, graph=False):
         got = bufs[0][1].download(h_out * s_out)
         src = np.concatenate([host_src_kept, np.zeros(16, np.uint8)])
         rows = min(h_out, 96)
-        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, s_in, s_out, first=0, n=rows)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, s_in, s_out, first=0, n=rows)
         line["bit_exact_first_rows_vs_oracle"] = bool(np.array_equal(got[:rows * s_out], want))
     batch.destroy()
     for a, b in bufs:

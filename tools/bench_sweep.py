@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""The reference's own proportional benchmark matrix (bench.sh:39-43, test.c:993-1053)
+run against this library, emitted in the reference's text formats so that results
+can be laid beside smolscale's own `results/resize-*-{samples,average}.txt`:
+
+    samples : "<w_out> <h_out> <elapsed_s> <pps>"            (test.c:343-355)
+    average : "<mean pps> <5th percentile> <95th percentile>" (test.c:357-382)
+    pps     = (w_in*h_in + w_out*h_out) / elapsed_s          (test.c:219-224)
+
+Tests: reps-w-h-scale_min-scale_max-steps = 5-1920-1080-0.01-2-200, 5-3840-2160-0.01-2-200,
+5-7680-4320-0.01-1-200; ARGB8 premultiplied in and out, no sRGB (test.c:20, 785-807).
+Two rows per test:
+    smol-hip       host pointers through smol_scale_new + smol_scale_batch
+                   (PCIe-inclusive, like the reference's in-memory `smol' row)
+    smol-hip-dev   device-resident input/output, kernel time only (hipEvents)
+
+    python tools/bench_sweep.py [--out results] [--tests 5-1920-1080-0.01-2-200,...] [--steps N]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import smolscale_amd as sm  # noqa: E402
+
+ARGB_P = sm.SMOL_PIXEL_ARGB8_PREMULTIPLIED
+DEFAULT_TESTS = "5-1920-1080-0.01-2-200,5-3840-2160-0.01-2-200,5-7680-4320-0.01-1-200"
+
+
+def steps_of(w_in, h_in, smin, smax, n):
+    w0, w1 = int(w_in * smin), int(w_in * smax)
+    h0, h1 = int(h_in * smin), int(h_in * smax)
+    ws = (w1 - w0) / (n - 1.0) if n > 1 else 0.0
+    hs = (h1 - h0) / (n - 1.0) if n > 1 else 0.0
+    for s in range(n):
+        yield (min(max(int(w0 + s * ws), 1), 65535), min(max(int(h0 + s * hs), 1), 65535))
+
+
+def write_results(out_dir, test, name, samples):
+    pps = sorted(p for (_, _, _, p) in samples)
+    with open(os.path.join(out_dir, "resize-%s-samples.txt" % test), "a") as f:
+        f.write('"%s"\n' % name)
+        for (w, h, t, p) in samples:
+            f.write("%u %u %.6f %.1f\n" % (w, h, t, p))
+        f.write("\n\n")
+    with open(os.path.join(out_dir, "resize-%s-average.txt" % test), "a") as f:
+        f.write('"%s" %.1f %.1f %.1f\n' % (name, sum(pps) / len(pps), pps[int(len(pps) * 0.05)], pps[int(len(pps) * 0.95)]))
+    return sum(pps) / len(pps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "results"))
+    ap.add_argument("--tests", default=DEFAULT_TESTS)
+    ap.add_argument("--steps", type=int, default=0, help="override the number of steps (quick runs)")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    rng = np.random.default_rng(7)
+
+    for test in args.tests.split(","):
+        reps, w_in, h_in, smin, smax, n = test.split("-")
+        reps, w_in, h_in, n = int(reps), int(w_in), int(h_in), int(n)
+        smin, smax = float(smin), float(smax)
+        if args.steps:
+            n = args.steps
+        src = rng.integers(0, 256, w_in * h_in * 4, dtype=np.uint8)
+        dsrc = sm.DeviceBuffer(src.size + 64)
+        dsrc.upload(src)
+        host, dev = [], []
+        for (w_out, h_out) in steps_of(w_in, h_in, smin, smax, n):
+            dst = np.empty(w_out * h_out * 4, np.uint8)
+            # host-pointer row: fastest of `reps' (benchmark_postprocess, test.c:319-340)
+            best = 1e9
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                sm.smol_scale_simple(src, ARGB_P, w_in, h_in, w_in * 4, dst, ARGB_P, w_out, h_out, w_out * 4, 0)
+                best = min(best, time.perf_counter() - t0)
+            host.append((w_out, h_out, best, (w_in * h_in + w_out * h_out) / best))
+            # device-resident row
+            ddst = sm.DeviceBuffer(dst.size + 64)
+            im = sm.SmolHipImage()
+            im.job = sm.plan_job(ARGB_P, w_in, h_in, ARGB_P, w_out, h_out, 0)
+            im.src, im.dst = dsrc.ptr, ddst.ptr
+            im.rowstride_in, im.rowstride_out = w_in * 4, w_out * 4
+            im.first_row, im.n_rows = 0, h_out
+            batch = sm.HipBatch([im])
+            t = min(batch.time(1, reps) / reps for _ in range(2)) * 1e-3
+            dev.append((w_out, h_out, t, (w_in * h_in + w_out * h_out) / t))
+            batch.destroy()
+            ddst.free()
+        dsrc.free()
+        a = write_results(args.out, test, "smol-hip (host pointers, PCIe inclusive)", host)
+        b = write_results(args.out, test, "smol-hip-dev (device resident)", dev)
+        print("%s: mean pps host-path %.3e, device-resident %.3e" % (test, a, b), flush=True)
+
+
+if __name__ == "__main__":
+    main()
