@@ -19,7 +19,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmolscale_amd.so")
+LIB_PATH = os.environ.get("SMOLSCALE_AMD_LIB") or os.path.join(_HERE, "libsmolscale_amd.so")
 
 # SmolPixelType, include/smolscale.h
 SMOL_PIXEL_RGBA8_PREMULTIPLIED = 0

@@ -56,6 +56,55 @@ launch_pow2_hy (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_
     }
 }
 
+/* k_tile has one entry point per (tapsel, horizontal mode, columns per lane) */
+template <int TS, int HM, int CPL>
+void
+launch_tile_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL>), grid, dim3 (64), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, dim3 (64), lds, s, rep);
+}
+
+template <int TS>
+void
+launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    const uint32_t hm = (rep.tile_variant >> 2) & 7u;
+
+    if (rep.tile_cpl == 4)
+    {
+        switch (hm)
+        {
+            case 0:  launch_tile_k<TS, 0, 4> (jobs_dev, rep, grid, lds, s); break;
+            default: launch_tile_k<TS, 1, 4> (jobs_dev, rep, grid, lds, s); break;
+        }
+        return;
+    }
+    switch (hm)
+    {
+        case 0:  launch_tile_k<TS, 0, 1> (jobs_dev, rep, grid, lds, s); break;
+        case 1:  launch_tile_k<TS, 1, 1> (jobs_dev, rep, grid, lds, s); break;
+        case 2:  launch_tile_k<TS, 2, 1> (jobs_dev, rep, grid, lds, s); break;
+        case 3:  launch_tile_k<TS, 3, 1> (jobs_dev, rep, grid, lds, s); break;
+        case 4:  launch_tile_k<TS, 4, 1> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_tile_k<TS, 5, 1> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
+void
+launch_tile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (rep.tile_variant >> 5)
+    {
+        case 0:  launch_tile_ts<0> (jobs_dev, rep, grid, lds, s); break;
+        case 1:  launch_tile_ts<1> (jobs_dev, rep, grid, lds, s); break;
+        case 2:  launch_tile_ts<2> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_tile_ts<3> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
 /* Launch one kernel over `n_jobs' jobs that all share class k and (for k_pow2)
  * the same halvings as `rep'. max_* are maxima over the group. */
 hipError_t
@@ -94,10 +143,10 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
             else
                 hipLaunchKernelGGL (smolhip::k_wtile_one, grid, dim3 (64), lds, s, rep);
         }
-        else if (jobs_dev)
-            hipLaunchKernelGGL (smolhip::k_tile_batch, grid, dim3 (64), lds, s, jobs_dev);
         else
-            hipLaunchKernelGGL (smolhip::k_tile_one, grid, dim3 (64), lds, s, rep);
+        {
+            launch_tile (jobs_dev, rep, grid, lds, s);
+        }
         return hipGetLastError ();
     }
 
@@ -371,6 +420,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if (g.k == KC_POW2 && (jobs [j].halv_h != g.rep.halv_h || jobs [j].halv_v != g.rep.halv_v))
                 continue;
             if ((g.k == KC_TILE || g.k == KC_WTILE) && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl
+                                  || (jobs [j].tile_variant >> 2) != (g.rep.tile_variant >> 2)
                                   || jobs [j].tile_lpc != g.rep.tile_lpc))
                 continue;
             if (g.count == 65535)

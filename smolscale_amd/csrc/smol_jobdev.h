@@ -62,7 +62,7 @@ enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_CO
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr uint32_t TILE_LDS_BUDGET = 8 * 1024;      /* bytes of LDS per staging buffer (two per 64-lane workgroup) */
+constexpr uint32_t TILE_LDS_BUDGET = 4 * 1024;      /* bytes of LDS per staging buffer (two per 64-lane workgroup) */
 
 inline bool
 tile_ok (const JobDev &d)
@@ -98,6 +98,9 @@ tile_setup (JobDev &d)
      * turns its stores into 16-byte ones */
     d.tile_cpl = (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX
                   && (d.filter_h != F_BILINEAR || d.halv_h == 0) && d.w_out >= 256) ? 4 : 1;
+    if (const char *e = getenv ("SMOL_TILE_CPL"))
+        if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX && (d.filter_h != F_BILINEAR || d.halv_h == 0))
+            d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
     uint64_t cols = 64u * d.tile_cpl;
     uint32_t box_lpc = 1;
 
@@ -123,12 +126,14 @@ tile_setup (JobDev &d)
     d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / d.span_chunks) + 1;
 
     d.span_px = (uint32_t) span_px;
-    uint32_t budget = d.wide ? TILE_LDS_BUDGET / 2 : TILE_LDS_BUDGET;
+    uint32_t budget = TILE_LDS_BUDGET;
     if (const char *e = getenv ("SMOL_TILE_LDS_BUDGET"))
         budget = (uint32_t) atoi (e);
     if (const char *e = getenv ("SMOL_TILE_DBG"))
         d.dbg = (uint8_t) atoi (e);
     uint32_t rows = budget / (d.span_chunks * 16);
+    if (rows < 2 && 2 * d.span_chunks * 16 <= 8192)
+        rows = 2;                   /* one-row groups leave the wave waiting on every row */
     if (rows < 1) rows = 1;
     if (rows > 16) rows = 16;
     d.group_rows = (uint16_t) rows;
@@ -180,6 +185,8 @@ inline uint32_t
 tile_lds_bytes (const JobDev &d)
 {
     uint32_t bytes = 2 * d.group_rows * d.span_chunks * 16 + 32;
+    if (getenv ("SMOL_TILE_ONEBUF") && d.group_rows * d.span_chunks <= 512)
+        bytes = d.group_rows * d.span_chunks * 16 + 32;     /* experiment: register-pipelined staging */
     if (d.wide)
         bytes += d.group_rows * d.span_px * ((d.p16 && d.linear) ? 16 : 8);   /* converted rows (k_wtile) */
     return bytes;
