@@ -78,7 +78,9 @@ launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t l
         switch (hm)
         {
             case 0:  launch_tile_k<TS, 0, 4> (jobs_dev, rep, grid, lds, s); break;
-            default: launch_tile_k<TS, 1, 4> (jobs_dev, rep, grid, lds, s); break;
+            case 1:  launch_tile_k<TS, 1, 4> (jobs_dev, rep, grid, lds, s); break;
+            case 2:  launch_tile_k<TS, 2, 4> (jobs_dev, rep, grid, lds, s); break;
+            default: launch_tile_k<TS, 3, 4> (jobs_dev, rep, grid, lds, s); break;
         }
         return;
     }

@@ -99,7 +99,7 @@ tile_setup (JobDev &d)
     d.tile_cpl = (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX
                   && (d.filter_h != F_BILINEAR || d.halv_h == 0) && d.w_out >= 256) ? 4 : 1;
     if (const char *e = getenv ("SMOL_TILE_CPL"))
-        if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX && (d.filter_h != F_BILINEAR || d.halv_h == 0))
+        if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX)
             d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
     uint64_t cols = 64u * d.tile_cpl;
     uint32_t box_lpc = 1;

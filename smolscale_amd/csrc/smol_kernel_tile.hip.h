@@ -254,7 +254,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c]);
             u32x4 v = { w [0], w [1], w [2], w [3] };
-            *reinterpret_cast<u32x4 *> (rowp + (size_t) xl * 4) = v;
+            __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (rowp + (size_t) xl * 4));
             return;
         }
     }
@@ -277,6 +277,30 @@ __device__ __forceinline__ void smol_global_load_lds16 (const void *gptr, uint8_
 __device__ __forceinline__ void smol_wait_vmcnt0 ()
 {
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+/* Wait until at most n (wave-uniform, clamped to 7) of this wave's vector-memory
+ * operations are still outstanding. They retire in issue order, so after
+ * "DMA loads, then k stores" this waits for the loads and lets the stores fly. */
+__device__ __forceinline__ void smol_wait_vmcnt_le (uint32_t n)
+{
+    switch (n)
+    {
+        case 0:  asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1:  asm volatile ("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2:  asm volatile ("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3:  asm volatile ("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4:  asm volatile ("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5:  asm volatile ("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6:  asm volatile ("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile ("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    }
+}
+
+/* ordering point for a one-wave workgroup: compiler barrier only */
+__device__ __forceinline__ void smol_wave_sync ()
+{
+    asm volatile ("" ::: "memory");
 }
 
 /* value of `v' in lane `idx' (idx wave-uniform) */
@@ -598,6 +622,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     uint32_t cur = 0;
 
     const bool dbg_notaps = J.dbg & 1, dbg_nostage = J.dbg & 2, dbg_nostore = J.dbg & 4;
+    uint32_t stores_since_dma = 0;      /* output rows stored since the last DMA issue (>= 1 store each) */
 
 #ifdef SMOL_TILE_REGSTAGE
     /* register-pipelined staging, single LDS buffer */
@@ -635,10 +660,19 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 #endif
         if (DMA)
         {
-            /* this group has landed; start the next one into the other buffer so it
-             * streams in while this one is consumed */
-            smol_wait_vmcnt0 ();
-            __syncthreads ();
+            /* This group's DMA was issued before the previous group's pixel stores, and
+             * vector-memory operations retire in issue order: waiting until no more
+             * than `stores_since_dma' (a lower bound of the stores issued since) are
+             * outstanding retires the DMA without draining the stores. Then start the
+             * next group into the other buffer so it streams in during the consume. */
+            if (J.dbg & 8)
+                smol_wait_vmcnt0 ();
+            else
+                smol_wait_vmcnt_le (stores_since_dma);
+            /* the workgroup is a single wave: no s_barrier needed, and __syncthreads()
+             * would make hipcc drain every outstanding store (vmcnt(0)) */
+            smol_wave_sync ();
+            stores_since_dma = 0;
             const uint32_t nfirst = gfirst + nrows;
             if (nfirst <= row_last && !dbg_nostage)
             {
@@ -743,6 +777,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
                     if (!dbg_nostore || o [0].lo == 0x12345678u)
                         tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, o);
+                    stores_since_dma += dbg_nostore ? 0u : 1u;
                     out_row += J.dst_stride;
                     ks++;
                     vy0 = oy;
@@ -778,6 +813,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                         o [c] = px2_shr (acc [c], hv);
                     if (!dbg_nostore || o [0].lo == 0x12345678u)
                         tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, o);
+                    stores_since_dma += dbg_nostore ? 0u : 1u;
                     s_y = 0;
                     out_row += J.dst_stride;
                 }
@@ -822,7 +858,9 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
         switch (hm)
         {
             case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL, 4> (J, sbuf); break;
-            default: tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4> (J, sbuf); break;
+            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4> (J, sbuf); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 4> (J, sbuf); break;
+            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 4> (J, sbuf); break;
         }
         return;
     }
