@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="testing aid: rank r uses GPU r %% device_count (several ranks on one GPU; needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,12 +118,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the product has no CPU path to measure")
 
+    if args.share_devices:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if dist is not None:
@@ -173,7 +181,7 @@ def main():
 
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 

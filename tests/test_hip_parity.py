@@ -267,6 +267,43 @@ def test_rows_sharded_over_several_device_entries(monkeypatch):
         assert np.array_equal(part, got[(h_out // 3) * stride:])
 
 
+def test_row_shards_from_resident_slabs_with_virtual_row0():
+    """What bench.py --gpus N and a multi-GPU scatter do: a rank holds only the slab of
+    input rows its strip needs and passes the address of (virtual) input row 0."""
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
+            (0, 4096, 1024, 0, 1024, 256, 0), (4, 640, 360, 0, 1920, 1080, 0), (8, 3000, 900, 1, 370, 111, 0),
+            (0, 4096, 2048, 0, 448, 224, 0), (5, 512, 512, 6, 128, 128, 0)):
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        s_in, s_out = w_in * H.bpp(t_in), w_out * H.bpp(t_out)
+        full = H.make_input(t_in, w_in, h_in, seed=21, valid=True, pad=16)
+        want = H.oracle_scale(full, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        world = 3
+        images, bufs = [], []
+        for r in range(world):
+            first, n, r0, r1 = sm.shard(job, r, world)
+            slab = full[r0 * s_in:(r1 + 1) * s_in]
+            dsrc = sm.DeviceBuffer(slab.size + 64)
+            dsrc.upload(slab)
+            ddst = sm.DeviceBuffer(n * s_out + 64)
+            im = sm.SmolHipImage()
+            im.job = job
+            im.src = dsrc.ptr - r0 * s_in
+            im.dst = ddst.ptr
+            im.rowstride_in, im.rowstride_out = s_in, s_out
+            im.first_row, im.n_rows = first, n
+            images.append(im)
+            bufs.append((dsrc, ddst, first, n))
+        batch = sm.HipBatch(images)
+        batch.launch()
+        sm.check(sm.lib().smol_hip_device_synchronize(0))
+        for (dsrc, ddst, first, n) in bufs:
+            got = ddst.download(n * s_out)
+            assert np.array_equal(got, want[first * s_out:(first + n) * s_out]), (t_in, w_in, t_out, w_out, first, n)
+            dsrc.free()
+            ddst.free()
+        batch.destroy()
+
+
 def test_edge_sizes():
     for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
             (0, 1, 1, 0, 1, 1, 0), (8, 1, 1, 9, 65535, 1, 0), (0, 2, 1, 0, 1, 1, 1), (4, 65535, 1, 4, 1, 1, 1),
