@@ -188,7 +188,8 @@ tile_lds_bytes (const JobDev &d)
     if (getenv ("SMOL_TILE_ONEBUF") && d.group_rows * d.span_chunks <= 512)
         bytes = d.group_rows * d.span_chunks * 16 + 32;     /* experiment: register-pipelined staging */
     if (d.wide)
-        bytes += d.group_rows * d.span_px * ((d.p16 && d.linear) ? 16 : 8);   /* converted rows (k_wtile) */
+        bytes += d.group_rows * d.span_px * ((d.p16 && d.linear) ? 16 : 8) + 16   /* converted rows (k_wtile) */
+                 + (4 * 1024 + 512 + 2048);                                       /* + LDS copy of the tables */
     return bytes;
 }
 

@@ -110,6 +110,11 @@ __device__ __forceinline__ void wtile_body (const JobDev &J, uint8_t *sbuf)
     const bool wide32 = J.p16 && J.linear;
     const uint32_t conv_pitch = J.span_px * (wide32 ? 16u : 8u);
     uint8_t *conv = sbuf + 2u * raw_bytes;
+    /* workgroup-private copy of the parity tables, behind the converted rows */
+    uint8_t *lut_base = conv + ((J.group_rows * conv_pitch + 15u) & ~15u);
+    lut_fill_lds (lut_base, lane, TILE_COLS);
+    __syncthreads ();
+    const LutLds lut (lut_base);
 
     /* ---- vertical schedule (see k_tile) ------------------------------------------ */
     const bool vpair = (J.filter_v == F_BILINEAR);
@@ -176,7 +181,7 @@ __device__ __forceinline__ void wtile_body (const JobDev &J, uint8_t *sbuf)
             {
                 const uint32_t w = lds_load_unaligned (rowb, mis + p * bpp);
                 uint32_t c [4];
-                unpack_word<true> (J, w, c);
+                unpack_word<true> (J, w, c, lut);
                 if (wide32)
                 {
                     uint32_t *dstp = reinterpret_cast<uint32_t *> (crow + (size_t) p * 16);
@@ -238,7 +243,7 @@ __device__ __forceinline__ void wtile_body (const JobDev &J, uint8_t *sbuf)
                     for (int k = 0; k < 4; k++)
                         o [k] = acc.c [k] >> hv;
                     if (active)
-                        store_px<true> (J, out_row, x, o);
+                        store_px<true> (J, out_row, x, o, lut);
                     s_y = 0;
                     out_row += J.dst_stride;
                 }

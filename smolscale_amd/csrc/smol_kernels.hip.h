@@ -52,10 +52,74 @@ __device__ __forceinline__ uint32_t premul8l (uint32_t l, uint32_t a)
     return (((l + 1u) * ((a << 3) + 1u) - 1u) >> 11) & 0x7ffu;
 }
 
+/* Where the six parity tables are read from. LutConst: the __constant__ copies
+ * (vector loads through L1/L2 when the index differs per lane). LutLds: a
+ * workgroup-private copy in LDS, for the 128bpp-class kernels whose unpack/pack
+ * does several table lookups per pixel. */
+struct LutConst
+{
+    __device__ __forceinline__ uint32_t inv_p8 (uint32_t a) const { return smol_inv_p8_lut [a]; }
+    __device__ __forceinline__ uint32_t inv_p8l (uint32_t a) const { return smol_inv_p8l_lut [a]; }
+    __device__ __forceinline__ uint32_t inv_p16 (uint32_t a) const { return smol_inv_p16_lut [a]; }
+    __device__ __forceinline__ uint32_t inv_p16l (uint32_t a) const { return smol_inv_p16l_lut [a]; }
+    __device__ __forceinline__ uint32_t from_srgb (uint32_t v) const { return smol_from_srgb_lut [v]; }
+    __device__ __forceinline__ uint32_t to_srgb (uint32_t v) const { return smol_to_srgb_lut [v]; }
+};
+
+constexpr uint32_t LUT_LDS_BYTES = 4 * 1024 + 512 + 2048;
+
+struct LutLds
+{
+    const uint32_t *p8, *p8l, *p16, *p16l;
+    const uint16_t *fs;
+    const uint8_t *ts;
+
+    __device__ __forceinline__ explicit LutLds (const uint8_t *base)
+        : p8 (reinterpret_cast<const uint32_t *> (base)),
+          p8l (reinterpret_cast<const uint32_t *> (base + 1024)),
+          p16 (reinterpret_cast<const uint32_t *> (base + 2048)),
+          p16l (reinterpret_cast<const uint32_t *> (base + 3072)),
+          fs (reinterpret_cast<const uint16_t *> (base + 4096)),
+          ts (base + 4608) {}
+
+    __device__ __forceinline__ uint32_t inv_p8 (uint32_t a) const { return p8 [a]; }
+    __device__ __forceinline__ uint32_t inv_p8l (uint32_t a) const { return p8l [a]; }
+    __device__ __forceinline__ uint32_t inv_p16 (uint32_t a) const { return p16 [a]; }
+    __device__ __forceinline__ uint32_t inv_p16l (uint32_t a) const { return p16l [a]; }
+    __device__ __forceinline__ uint32_t from_srgb (uint32_t v) const { return fs [v]; }
+    __device__ __forceinline__ uint32_t to_srgb (uint32_t v) const { return ts [v]; }
+};
+
+/* cooperative copy of the tables into LDS (caller synchronises afterwards) */
+__device__ __forceinline__ void lut_fill_lds (uint8_t *base, uint32_t tid, uint32_t nthreads)
+{
+    uint32_t *d = reinterpret_cast<uint32_t *> (base);
+    for (uint32_t i = tid; i < 256; i += nthreads)
+    {
+        d [i] = smol_inv_p8_lut [i];
+        d [256 + i] = smol_inv_p8l_lut [i];
+        d [512 + i] = smol_inv_p16_lut [i];
+        d [768 + i] = smol_inv_p16l_lut [i];
+    }
+    uint16_t *f = reinterpret_cast<uint16_t *> (base + 4096);
+    for (uint32_t i = tid; i < 256; i += nthreads)
+        f [i] = smol_from_srgb_lut [i];
+    const uint32_t *tsrc = reinterpret_cast<const uint32_t *> (smol_to_srgb_lut);
+    uint32_t *t = reinterpret_cast<uint32_t *> (base + 4608);
+    for (uint32_t i = tid; i < 512; i += nthreads)
+        t [i] = tsrc [i];
+}
+
 /* premultiplied -> unassociated 8 bit via the inverse table: :227-236, 246-259 */
+template <typename L>
+__device__ __forceinline__ uint32_t unpremul8 (uint32_t c, uint32_t a, const L &lut)
+{
+    return (uint32_t) ((((uint64_t) c * lut.inv_p8 (a)) >> 13) & 0xffu);
+}
+
 __device__ __forceinline__ uint32_t unpremul8 (uint32_t c, uint32_t a)
 {
-    return (uint32_t) ((((uint64_t) c * smol_inv_p8_lut [a]) >> 13) & 0xffu);
+    return unpremul8 (c, a, LutConst ());
 }
 
 /* one bilinear tap: q + floor ((p - q) * F / 256): :1317, :1704.
@@ -83,8 +147,8 @@ __device__ __forceinline__ uint32_t box_scale (uint32_t acc, uint32_t mul)
  * ------------------------------------------------------------------------- */
 /* raw pixel word (bytes in memory order; only 3 valid bytes for 24bpp) ->
  * internal premultiplied channels c[0..2] = R,G,B, c[3] = alpha lane */
-template <bool WIDE>
-__device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32_t (&c) [4])
+template <bool WIDE, typename L>
+__device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32_t (&c) [4], const L &lut)
 {
     uint32_t a;
 
@@ -100,7 +164,7 @@ __device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32
         {
             uint32_t v = c [i];
             if (J.linear)
-                v = smol_from_srgb_lut [v];
+                v = lut.from_srgb (v);
             c [i] = v * a;
         }
         c [3] = (a << 8) | 0x80u;
@@ -114,8 +178,8 @@ __device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32
         {
             uint32_t v = c [i];
             if (!J.unassoc_in)
-                v = unpremul8 (v, a);
-            c [i] = premul8l (smol_from_srgb_lut [v], a);
+                v = unpremul8 (v, a, lut);
+            c [i] = premul8l (lut.from_srgb (v), a);
         }
     }
     else if (J.unassoc_in)
@@ -129,8 +193,14 @@ __device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32
 }
 
 template <bool WIDE>
+__device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32_t (&c) [4])
+{
+    unpack_word<WIDE> (J, w, c, LutConst ());
+}
+
+template <bool WIDE, typename L>
 __device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, uint32_t x,
-                                          uint32_t (&c) [4])
+                                          uint32_t (&c) [4], const L &lut)
 {
     uint32_t w;
 
@@ -150,16 +220,16 @@ __device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, 
         w = (uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t) p [2] << 16);
     }
 
-    unpack_word<WIDE> (J, w, c);
+    unpack_word<WIDE> (J, w, c, lut);
 }
 
 /* ------------------------------------------------------------------------- *
  * Pack internal channels into one destination pixel                         *
  *   64bpp-class: smolscale-generic.c:758-906; 128bpp-class: :912-1164       *
  * ------------------------------------------------------------------------- */
-template <bool WIDE>
+template <bool WIDE, typename L>
 __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32_t x,
-                                          const uint32_t (&v) [4])
+                                          const uint32_t (&v) [4], const L &lut)
 {
     uint32_t a, c [3];
 
@@ -175,29 +245,29 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
 
         if (!WIDE)
         {
-            c [i] = J.unassoc_out ? unpremul8 (s, a) : (s & 0xffu);
+            c [i] = J.unassoc_out ? unpremul8 (s, a, lut) : (s & 0xffu);
         }
         else if (J.p16)
         {
             if (J.linear)
-                c [i] = smol_to_srgb_lut [(uint32_t) (((uint64_t) s * smol_inv_p16l_lut [a]) >> 19) & 0x7ffu];
+                c [i] = lut.to_srgb ((uint32_t) (((uint64_t) s * lut.inv_p16l (a)) >> 19) & 0x7ffu);
             else
-                c [i] = (uint32_t) (((uint64_t) s * smol_inv_p16_lut [a]) >> 16) & 0xffu;
+                c [i] = (uint32_t) (((uint64_t) s * lut.inv_p16 (a)) >> 16) & 0xffu;
         }
         else if (!J.linear)
         {
-            c [i] = J.unassoc_out ? unpremul8 (s, a) : (s & 0xffu);
+            c [i] = J.unassoc_out ? unpremul8 (s, a, lut) : (s & 0xffu);
         }
         else
         {
-            uint32_t u = (uint32_t) (((uint64_t) s * smol_inv_p8l_lut [a]) >> 10) & 0x7ffu;
+            uint32_t u = (uint32_t) (((uint64_t) s * lut.inv_p8l (a)) >> 10) & 0x7ffu;
 
             if (J.bpp_out == 3)
-                c [i] = J.quirk24 ? smol_to_srgb_lut [s & 0x7ffu] : smol_to_srgb_lut [u];
+                c [i] = J.quirk24 ? lut.to_srgb (s & 0x7ffu) : lut.to_srgb (u);
             else if (J.unassoc_out)
-                c [i] = smol_to_srgb_lut [u];
+                c [i] = lut.to_srgb (u);
             else
-                c [i] = premul8 (smol_to_srgb_lut [u], a);
+                c [i] = premul8 (lut.to_srgb (u), a);
         }
     }
 
@@ -266,8 +336,8 @@ __device__ __forceinline__ void box_span (uint64_t step, uint32_t dim_in, uint32
  * its scaled row (smolscale-generic.c:1290-1611), computed on demand.       *
  * A single loop over "source taps" keeps one fetch_px call site.            *
  * ------------------------------------------------------------------------- */
-template <bool WIDE>
-__device__ void hsample (const JobDev &J, uint32_t row, uint32_t x, uint32_t (&out) [4])
+template <bool WIDE, typename L>
+__device__ void hsample (const JobDev &J, uint32_t row, uint32_t x, uint32_t (&out) [4], const L &lut)
 {
     const uint8_t *rowp = J.src + (size_t) row * J.src_stride;
     const uint32_t mask = WIDE ? 0x00ffffffu : 0xffu;
@@ -289,7 +359,7 @@ __device__ void hsample (const JobDev &J, uint32_t row, uint32_t x, uint32_t (&o
                 pos += J.step_x;
             }
 
-            fetch_px<WIDE> (J, rowp, ofs + (t & 1), px);
+            fetch_px<WIDE> (J, rowp, ofs + (t & 1), px, lut);
 
             if (t & 1)
             {
@@ -317,7 +387,7 @@ __device__ void hsample (const JobDev &J, uint32_t row, uint32_t x, uint32_t (&o
 
         for (uint32_t s = o0; s <= o1; s++)
         {
-            fetch_px<WIDE> (J, rowp, s, px);
+            fetch_px<WIDE> (J, rowp, s, px, lut);
 
             if (s == o0)
             {
@@ -345,7 +415,7 @@ __device__ void hsample (const JobDev &J, uint32_t row, uint32_t x, uint32_t (&o
     }
     else
     {
-        fetch_px<WIDE> (J, rowp, J.filter_h == F_ONE ? 0u : x, out);
+        fetch_px<WIDE> (J, rowp, J.filter_h == F_ONE ? 0u : x, out, lut);
     }
 }
 
@@ -355,8 +425,8 @@ __device__ void hsample (const JobDev &J, uint32_t row, uint32_t x, uint32_t (&o
  *   vertical box 64bpp: :2026-2161, 128bpp: :2163-2260                      *
  *   copy / one: :2262-2318                                                  *
  * ------------------------------------------------------------------------- */
-template <bool WIDE>
-__device__ void general_pixel (const JobDev &J, uint32_t x, uint32_t y)
+template <bool WIDE, typename L>
+__device__ void general_pixel (const JobDev &J, uint32_t x, uint32_t y, const L &lut)
 {
     const uint32_t mask = WIDE ? 0x00ffffffu : 0xffu;
     uint32_t acc [4] = { 0, 0, 0, 0 };
@@ -377,7 +447,7 @@ __device__ void general_pixel (const JobDev &J, uint32_t x, uint32_t y)
                 pos += J.step_y;
             }
 
-            hsample<WIDE> (J, oy + (t & 1), x, v);
+            hsample<WIDE> (J, oy + (t & 1), x, v, lut);
 
             if (t & 1)
             {
@@ -410,7 +480,7 @@ __device__ void general_pixel (const JobDev &J, uint32_t x, uint32_t y)
 
         for (uint32_t r = y0; r <= y_end; r++)
         {
-            hsample<WIDE> (J, r, x, v);
+            hsample<WIDE> (J, r, x, v, lut);
 
             if (r == y0)
             {
@@ -438,10 +508,10 @@ __device__ void general_pixel (const JobDev &J, uint32_t x, uint32_t y)
     }
     else
     {
-        hsample<WIDE> (J, J.filter_v == F_ONE ? 0u : y, x, v);
+        hsample<WIDE> (J, J.filter_v == F_ONE ? 0u : y, x, v, lut);
     }
 
-    store_px<WIDE> (J, J.dst + (size_t) (y - J.first_row) * J.dst_stride, x, v);
+    store_px<WIDE> (J, J.dst + (size_t) (y - J.first_row) * J.dst_stride, x, v, lut);
 }
 
 constexpr int GENERAL_BLOCK = 256;
@@ -453,10 +523,27 @@ __device__ __forceinline__ void general_body (const JobDev &J)
     const uint32_t row = blockIdx.x / tiles_x;
     const uint32_t x = (blockIdx.x % tiles_x) * GENERAL_BLOCK + threadIdx.x;
 
-    if (row >= J.n_rows || x >= J.w_out)
-        return;
-
-    general_pixel<WIDE> (J, x, J.first_row + row);
+    if (WIDE)
+    {
+        /* the 128bpp class looks tables up several times per pixel: workgroup copy in LDS */
+        __shared__ __attribute__ ((aligned (16))) uint8_t lut_lds [LUT_LDS_BYTES];
+        if (row >= J.n_rows)
+            return;                                 /* uniform for the whole workgroup */
+#ifdef SMOL_KERNEL_EMU
+        lut_fill_lds (lut_lds, 0, 1);               /* emulated lanes run one after the other */
+#else
+        lut_fill_lds (lut_lds, threadIdx.x, GENERAL_BLOCK);
+        __syncthreads ();
+#endif
+        if (x < J.w_out)
+            general_pixel<WIDE> (J, x, J.first_row + row, LutLds (lut_lds));
+    }
+    else
+    {
+        if (row >= J.n_rows || x >= J.w_out)
+            return;
+        general_pixel<WIDE> (J, x, J.first_row + row, LutConst ());
+    }
 }
 
 /* batch form: one descriptor per blockIdx.y, descriptors in device memory */
