@@ -152,6 +152,27 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         return hipGetLastError ();
     }
 
+    if (k == KC_WAVEPX || k == KC_WAVEPX_WIDE)
+    {
+        /* groups hold jobs of one output width (see smol_hip_batch_create) */
+        dim3 grid (rep.w_out * max_rows, n_jobs);
+        if (k == KC_WAVEPX_WIDE)
+        {
+            if (jobs_dev)
+                hipLaunchKernelGGL (smolhip::k_wavepx_batch<true>, grid, dim3 (64), 0, s, jobs_dev);
+            else
+                hipLaunchKernelGGL (smolhip::k_wavepx_one<true>, grid, dim3 (64), 0, s, rep);
+        }
+        else
+        {
+            if (jobs_dev)
+                hipLaunchKernelGGL (smolhip::k_wavepx_batch<false>, grid, dim3 (64), 0, s, jobs_dev);
+            else
+                hipLaunchKernelGGL (smolhip::k_wavepx_one<false>, grid, dim3 (64), 0, s, rep);
+        }
+        return hipGetLastError ();
+    }
+
     dim3 grid (((max_w_out + smolhip::GENERAL_BLOCK - 1) / smolhip::GENERAL_BLOCK) * max_rows, n_jobs);
     dim3 block (smolhip::GENERAL_BLOCK);
 
@@ -424,6 +445,8 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if ((g.k == KC_TILE || g.k == KC_WTILE) && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl
                                   || (jobs [j].tile_variant >> 2) != (g.rep.tile_variant >> 2)
                                   || jobs [j].tile_lpc != g.rep.tile_lpc))
+                continue;
+            if ((g.k == KC_WAVEPX || g.k == KC_WAVEPX_WIDE) && jobs [j].w_out != g.rep.w_out)
                 continue;
             if (g.count == 65535)
                 break;

@@ -58,7 +58,7 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -185,8 +185,6 @@ inline uint32_t
 tile_lds_bytes (const JobDev &d)
 {
     uint32_t bytes = 2 * d.group_rows * d.span_chunks * 16 + 32;
-    if (getenv ("SMOL_TILE_ONEBUF") && d.group_rows * d.span_chunks <= 512)
-        bytes = d.group_rows * d.span_chunks * 16 + 32;     /* experiment: register-pipelined staging */
     if (d.wide)
         bytes += d.group_rows * d.span_px * ((d.p16 && d.linear) ? 16 : 8) + 16   /* converted rows (k_wtile) */
                  + (4 * 1024 + 512 + 2048);                                       /* + LDS copy of the tables */
@@ -273,6 +271,10 @@ classify (const JobDev &d)
         return KC_TILE;
     if (wtile_ok (d))
         return KC_WTILE;
+    /* what is left is the 128bpp class with a box axis (or a minifying one). A tall
+     * vertical box over few output pixels: one wave per pixel instead of one lane */
+    if (d.filter_v == F_BOX && (d.step_y >> 16) >= 32 && (uint64_t) d.w_out * d.n_rows <= 262144)
+        return d.wide ? KC_WAVEPX_WIDE : KC_WAVEPX;
     return d.wide ? KC_GENERAL_WIDE : KC_GENERAL;
 }
 
@@ -284,6 +286,8 @@ kclass_name (KClass k, const JobDev &d)
         case KC_POW2: return "k_pow2_batch";
         case KC_TILE: return "k_tile_batch";
         case KC_WTILE: return "k_wtile_batch";
+        case KC_WAVEPX: return "k_wavepx_batch<false>";
+        case KC_WAVEPX_WIDE: return "k_wavepx_batch<true>";
         case KC_GENERAL_WIDE: return "k_general_batch<true>";
         default: return "k_general_batch<false>";
     }

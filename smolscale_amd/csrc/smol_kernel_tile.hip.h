@@ -397,66 +397,6 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
     }
 }
 
-/* Register-pipelined staging (one batch of at most 64 * TILE_STAGE_UNROLL chunks):
- * tile_stage_load issues the 16-byte loads of a row group into registers and
- * returns without waiting; tile_stage_write, called one phase later, moves them to
- * LDS (premultiplying on the way if asked). The landing zone of the loads in
- * flight is then the register file rather than LDS. */
-struct StageRegs
-{
-    u32x4 v [TILE_STAGE_UNROLL];
-    uint32_t ok;                        /* bit u: lane holds a valid chunk in v[u] */
-};
-
-__device__ __forceinline__ void tile_stage_load (const JobDev &J, uint32_t lane, uint32_t gfirst, uint32_t nrows,
-                                                 uint32_t g0, uint32_t g1, StageRegs &sr)
-{
-    const uint32_t total = nrows * J.span_chunks;
-    const uintptr_t src_base = (uintptr_t) J.src;
-    const size_t src_stride = J.src_stride;
-
-    sr.ok = 0;
-#pragma unroll
-    for (int u = 0; u < TILE_STAGE_UNROLL; u++)
-    {
-        const uint32_t c = (uint32_t) u * TILE_COLS + lane;
-        const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
-        const uint32_t k = c - i * J.span_chunks;
-        const uintptr_t rb = src_base + (size_t) (gfirst + i) * src_stride;
-        const uintptr_t a0 = (rb + g0) & ~(uintptr_t) 15;
-        const uint32_t nch = (uint32_t) ((rb + g1 - a0 + 15) >> 4);
-
-        if ((c < total) && (k < nch))
-        {
-            sr.v [u] = __builtin_nontemporal_load (reinterpret_cast<const u32x4 *> (a0 + (uintptr_t) k * 16));
-            sr.ok |= 1u << u;
-        }
-    }
-}
-
-template <bool PREMUL>
-__device__ __forceinline__ void tile_stage_write (const JobDev &J, uint8_t *buf, uint32_t lane, StageRegs &sr)
-{
-    const uint32_t ain = J.pos_in [3];
-#pragma unroll
-    for (int u = 0; u < TILE_STAGE_UNROLL; u++)
-    {
-        const uint32_t c = (uint32_t) u * TILE_COLS + lane;
-        if (sr.ok & (1u << u))
-        {
-            u32x4 v = sr.v [u];
-            if (PREMUL)
-            {
-                v.x = premul_word (v.x, ain);
-                v.y = premul_word (v.y, ain);
-                v.z = premul_word (v.z, ain);
-                v.w = premul_word (v.w, ain);
-            }
-            *reinterpret_cast<u32x4 *> (buf + (size_t) c * 16) = v;
-        }
-    }
-}
-
 /* TAP: how taps are read. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples
  * per output column, 4 = box with one lane per column, 5 = box with 8 lanes per
  * column (their partial sums meet through wave shuffles; for wide spans, so that
@@ -624,40 +564,13 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     const bool dbg_notaps = J.dbg & 1, dbg_nostage = J.dbg & 2, dbg_nostore = J.dbg & 4;
     uint32_t stores_since_dma = 0;      /* output rows stored since the last DMA issue (>= 1 store each) */
 
-#ifdef SMOL_TILE_REGSTAGE
-    /* register-pipelined staging, single LDS buffer */
-    const bool regpipe = (J.group_rows * J.span_chunks <= TILE_COLS * TILE_STAGE_UNROLL);
-    StageRegs sr;
-    sr.ok = 0;
-    if (regpipe && !dbg_nostage)
-        tile_stage_load (J, lane, gfirst, nrows, g0, g1, sr);
-#else
-    const bool regpipe = false;
     if (DMA && !dbg_nostage)
         tile_stage<true, false> (J, sbuf, lane, gfirst, nrows, g0, g1);
-#endif
 
     while (true)
     {
         uint8_t *buf = sbuf + cur * buf_bytes;
 
-#ifdef SMOL_TILE_REGSTAGE
-        if (regpipe)
-        {
-            buf = sbuf;
-            __syncthreads ();                           /* previous group fully consumed */
-            tile_stage_write<STAGE_PREMUL> (J, buf, lane, sr);
-            __syncthreads ();
-            const uint32_t nfirst = gfirst + nrows;
-            sr.ok = 0;
-            if (nfirst <= row_last && !dbg_nostage)
-            {
-                const uint32_t nn = (row_last - nfirst + 1 < J.group_rows) ? row_last - nfirst + 1 : J.group_rows;
-                tile_stage_load (J, lane, nfirst, nn, g0, g1, sr);
-            }
-        }
-        else
-#endif
         if (DMA)
         {
             /* This group's DMA was issued before the previous group's pixel stores, and

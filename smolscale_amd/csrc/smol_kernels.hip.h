@@ -564,6 +564,86 @@ k_general_one (const JobDev J)
 }
 
 /* ------------------------------------------------------------------------- *
+ * k_wavepx: one WAVE per output pixel, for vertical box filters whose output  *
+ * is too small to fill the chip with one lane per pixel (e.g. 8192^2 -> 30^2: *
+ * 900 pixels, each the sum of ~273 x 273 sources). The 64 lanes take the rows *
+ * of the pixel's vertical span in turn (each row's horizontal result is the   *
+ * reference's truncated per-row value, so the row sums are exact integers and *
+ * their order does not matter) and meet through a shuffle butterfly.          *
+ * ------------------------------------------------------------------------- */
+#ifndef SMOL_KERNEL_EMU
+__device__ __forceinline__ uint32_t wave_sum (uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += (uint32_t) __shfl_xor ((int) v, m, 64);
+    return v;
+}
+#endif
+
+template <bool WIDE>
+__device__ __forceinline__ void wavepx_body (const JobDev &J)
+{
+    const uint32_t mask = WIDE ? 0x00ffffffu : 0xffu;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = blockIdx.x;
+    const uint32_t row = idx / J.w_out;
+    const uint32_t x = idx - row * J.w_out;
+
+    __shared__ __attribute__ ((aligned (16))) uint8_t lut_lds [LUT_LDS_BYTES];
+    if (row >= J.n_rows)
+        return;
+    lut_fill_lds (lut_lds, lane, 64);
+    __syncthreads ();
+    const LutLds lut (lut_lds);
+
+    const uint32_t y = J.first_row + row;
+    uint32_t y0, y1, w2, w1;
+    box_span (J.step_y, J.h_in, y, y0, y1, w2, w1);
+    const uint32_t last_w = WIDE ? (w2 ? w2 - 1 : 0) : w2;          /* see general_pixel */
+    const uint32_t y_end = (WIDE && w2 == 0) ? y1 - 1 : y1;
+
+    uint32_t acc [4] = { 0, 0, 0, 0 };
+    uint32_t v [4];
+
+    for (uint32_t r = y0 + lane; r <= y_end; r += 64)
+    {
+        hsample<WIDE> (J, r, x, v, lut);
+        const uint32_t w = (r == y0) ? w1 : ((r == y1) ? last_w : 0x10000u);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            acc [i] += (w == 0x10000u) ? v [i] : (((v [i] * w) >> 8) & mask);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        acc [i] = wave_sum (acc [i]);
+
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            v [i] = box_scale<WIDE> (acc [i], J.span_mul_y);
+        store_px<WIDE> (J, J.dst + (size_t) row * J.dst_stride, x, v, lut);
+    }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__ (64)
+k_wavepx_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = jobs [blockIdx.y];
+    wavepx_body<WIDE> (J);
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__ (64)
+k_wavepx_one (const JobDev J)
+{
+    wavepx_body<WIDE> (J);
+}
+
+/* ------------------------------------------------------------------------- *
  * k_pow2: exact 2^n : 1 bilinear-with-halvings, 32-bit premultiplied pixels *
  *                                                                           *
  * With w_in == w_out << (HX+1) every horizontal sample j sits at offset 2j  *

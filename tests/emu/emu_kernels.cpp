@@ -88,7 +88,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
     JobDev J;
     fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
     KClass k = classify (J);
-    if (force_general && (k == KC_POW2 || k == KC_TILE || k == KC_WTILE))
+    if (force_general && (k == KC_POW2 || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
     if (force_general == 2 && tile_ok (J))
         k = KC_TILE;                      /* force the tiled kernel where the fast path would win */
@@ -107,6 +107,15 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
             case 1: run_pow2_hy<1> (J, gx); break;
             default: run_pow2_hy<2> (J, gx); break;
         }
+        return 0;
+    }
+
+    if (k == KC_WAVEPX || k == KC_WAVEPX_WIDE)
+    {
+        if (k == KC_WAVEPX_WIDE)
+            run_grid_coop (J.w_out * n_rows, 64, 0, [&] { k_wavepx_one<true> (J); });
+        else
+            run_grid_coop (J.w_out * n_rows, 64, 0, [&] { k_wavepx_one<false> (J); });
         return 0;
     }
 

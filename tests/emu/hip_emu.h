@@ -78,3 +78,10 @@ static inline uint32_t smol_shfl_xor (uint32_t v, uint32_t mask)
     __syncthreads ();
     return r;
 }
+
+static inline uint32_t wave_sum (uint32_t v)
+{
+    for (uint32_t m = 32; m >= 1; m >>= 1)
+        v += smol_shfl_xor (v, m);
+    return v;
+}

@@ -304,6 +304,17 @@ def test_row_shards_from_resident_slabs_with_virtual_row0():
         batch.destroy()
 
 
+def test_tall_vertical_box_with_few_output_pixels():
+    """128bpp-class vertical boxes over a handful of output pixels run one wave per pixel."""
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
+            (0, 2048, 2048, 0, 7, 7, 0), (4, 300, 9000, 5, 300, 20, 0), (0, 500, 4000, 0, 25, 50, 1),
+            (8, 40, 65535, 0, 40, 3, 1), (6, 64, 3000, 7, 2, 9, 0)):
+        src = H.make_input(t_in, w_in, h_in, seed=5, valid=True, pad=16)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)), \
+            (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+
+
 def test_edge_sizes():
     for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
             (0, 1, 1, 0, 1, 1, 0), (8, 1, 1, 9, 65535, 1, 0), (0, 2, 1, 0, 1, 1, 1), (4, 65535, 1, 4, 1, 1, 1),
