@@ -37,6 +37,7 @@ struct JobDev
     uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
     uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8)              */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
+    uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
@@ -163,8 +164,17 @@ tile_setup (JobDev &d)
         tapsel = 3;
     else if (!d.tile_aligned4)
         tapsel = 2;
+    else if (d.unassoc_in)
+    {
+        /* premultiply once per staged pixel when pixels are re-used (magnification);
+         * when every pixel feeds one tap, premultiply at the tap and keep the
+         * double-buffered DMA staging */
+        const bool reuse = d.filter_h != F_BILINEAR || d.step_x < ((uint64_t) 1 << 32)
+                           || getenv ("SMOL_TILE_PREMUL_STAGE");
+        tapsel = reuse ? 1 : 2;
+    }
     else
-        tapsel = d.unassoc_in ? 1 : 0;
+        tapsel = 0;
 
     uint32_t hm = (d.filter_h == F_BILINEAR) ? 1u + d.halv_h : 0u;
     if (d.filter_h == F_BOX)
@@ -179,6 +189,7 @@ tile_setup (JobDev &d)
 
     d.tile_variant = (uint8_t) ((tapsel << 5) | (hm << 2) | out);
     d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
+    d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);
 }
 
 inline uint32_t

@@ -129,6 +129,25 @@ __device__ __forceinline__ uint32_t lds_load_unaligned (const uint8_t *sb, uint3
     return __builtin_amdgcn_alignbyte (pp [1], pp [0], off & 3u);
 }
 
+/* unassociated word -> premultiplied Px2 directly, in packed 16-bit lanes:
+ * (c+1)*(a+1) reaches 2^16 only as 256*256, which wraps to 0 and the -1 then
+ * gives 0xffff -- the same value modulo 2^16 as the exact arithmetic. */
+__device__ __forceinline__ Px2 premul_px2 (uint32_t w, uint32_t ain)
+{
+    const uint32_t a = (w >> (8 * ain)) & 0xffu;
+    const unsigned short m = (unsigned short) (a + 1u);
+    const u16x2 M2 = { m, m }, ONE2 = { 1, 1 };
+    Px2 r;
+    r.lo = as_u32 (((as_u16x2 (w & PAIR_MASK) + ONE2) * M2 - ONE2) >> 8);
+    r.hi = as_u32 (((as_u16x2 ((w >> 8) & PAIR_MASK) + ONE2) * M2 - ONE2) >> 8);
+    const uint32_t sh = 16u * (ain >> 1);
+    if (ain & 1u)
+        r.hi = (r.hi & ~(0xffu << sh)) | (a << sh);
+    else
+        r.lo = (r.lo & ~(0xffu << sh)) | (a << sh);
+    return r;
+}
+
 /* How a lane reads its taps from the staged row */
 enum : int
 {
@@ -150,8 +169,10 @@ enum : int
  * (bilinear) or p itself (COPY / ONE). */
 template <int TAP, bool PAIR>
 __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *rowb, uint32_t off,
-                                                uint32_t &wp, uint32_t &wq)
+                                                Px2 &p, Px2 &q)
 {
+    uint32_t wp, wq;
+
     if (TAP == TAP_A4)
     {
         const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + off);
@@ -170,8 +191,9 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
             wq = wp;
         if (J.unassoc_in)
         {
-            wp = premul_word (wp, J.pos_in [3]);
-            wq = PAIR ? premul_word (wq, J.pos_in [3]) : wp;
+            p = premul_px2 (wp, J.pos_in [3]);
+            q = PAIR ? premul_px2 (wq, J.pos_in [3]) : p;
+            return;
         }
     }
     else
@@ -191,6 +213,9 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
             wq = wp;
         }
     }
+
+    p = px2_from_word (wp);
+    q = PAIR ? px2_from_word (wq) : p;
 }
 
 /* packed pair -> destination pixel word (packers of smolscale-generic.c:758-906) */
@@ -238,32 +263,6 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
     }
 }
 
-/* CPL adjacent output pixels of one lane; one 16-byte store when possible */
-template <int OUT, int CPL>
-__device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp, uint32_t xl, uint32_t xn,
-                                                 bool interior, const Px2 (&o) [CPL])
-{
-    if (CPL == 4 && OUT != OUT_ANY)
-    {
-        /* `interior' is wave-uniform: a full-width tile on a 16-byte aligned
-         * destination stores without touching the exec mask */
-        if (interior || (J.out_vec16_ok && xl + 4 <= xn))
-        {
-            uint32_t w [4];
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                w [c] = tile_pack<OUT> (J, o [c]);
-            u32x4 v = { w [0], w [1], w [2], w [3] };
-            __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (rowp + (size_t) xl * 4));
-            return;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CPL; c++)
-        if (xl + c < xn)
-            tile_store<OUT> (J, rowp, xl + c, o [c]);
-}
-
 #ifndef SMOL_KERNEL_EMU
 /* memory -> LDS, 16 bytes per lane, no VGPR destination: LDS address = wave-uniform
  * base + 16 * lane (cdna_hip_programming.md section 5, global_load_lds) */
@@ -309,12 +308,77 @@ __device__ __forceinline__ uint32_t smol_readlane (uint32_t v, uint32_t idx)
     return (uint32_t) __builtin_amdgcn_readlane ((int) v, (int) idx);
 }
 
+/* value of `v' in lane `src' (src may differ per lane) */
+__device__ __forceinline__ uint32_t smol_shfl_idx (uint32_t v, uint32_t src)
+{
+    return (uint32_t) __shfl ((int) v, (int) src, 64);
+}
+
 /* butterfly exchange inside the wave */
 __device__ __forceinline__ uint32_t smol_shfl_xor (uint32_t v, uint32_t mask)
 {
     return (uint32_t) __shfl_xor ((int) v, (int) mask, 64);
 }
 #endif
+
+/* CPL adjacent output pixels of one lane. Fast forms: one 16-byte store of four
+ * 32-bit pixels; for 24-bit output on a 4-byte aligned destination, 12 bytes per
+ * lane (4 pixels per lane) or -- one pixel per lane -- the wave's 64 pixels
+ * re-cut into 48 dwords through two in-wave shuffles. `interior'/`full' are
+ * wave-uniform. */
+struct __attribute__ ((packed, aligned (4))) U32x3 { uint32_t a, b, c; };   /* 12 bytes on a 4-byte boundary */
+
+template <int OUT, int CPL>
+__device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp, uint32_t xl, uint32_t xn,
+                                                 bool interior, bool full24, const Px2 (&o) [CPL])
+{
+    if (CPL == 4 && OUT != OUT_ANY)
+    {
+        /* a full-width tile on a 16-byte aligned destination stores without
+         * touching the exec mask */
+        if (interior || (J.out_vec16_ok && xl + 4 <= xn))
+        {
+            uint32_t w [4];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                w [c] = tile_pack<OUT> (J, o [c]);
+            u32x4 v = { w [0], w [1], w [2], w [3] };
+            __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (rowp + (size_t) xl * 4));
+            return;
+        }
+    }
+    if (OUT == OUT_ANY && full24)
+    {
+        if (CPL == 4)
+        {
+            uint32_t w [4];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                w [c] = tile_pack<OUT> (J, o [c]) & 0x00ffffffu;
+            const U32x3 v = { w [0] | (w [1] << 24), (w [1] >> 8) | (w [2] << 16), (w [2] >> 16) | (w [3] << 8) };
+            *reinterpret_cast<U32x3 *> (rowp + (size_t) xl * 3) = v;
+        }
+        else
+        {
+            /* dword j of the tile's 192 output bytes starts in pixel a = 4j/3 at byte b = 4j%3 */
+            const uint32_t j = threadIdx.x;
+            const uint32_t w = tile_pack<OUT> (J, o [0]) & 0x00ffffffu;
+            const uint32_t a = (j * 4u) / 3u;
+            const uint32_t b = (j * 4u) - a * 3u;
+            const uint32_t wa = smol_shfl_idx (w, a & 63u);
+            const uint32_t wb = smol_shfl_idx (w, (a + 1u) & 63u);
+            const uint32_t d = (wa >> (8u * b)) | (wb << (24u - 8u * b));
+            if (j < 48u)
+                *reinterpret_cast<uint32_t *> (rowp + (size_t) (xl - j) * 3 + (size_t) j * 4) = d;
+        }
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        if (xl + c < xn)
+            tile_store<OUT> (J, rowp, xl + c, o [c]);
+}
+
 
 /* vertical sample schedule: (row of the top tap, weight) for sample index jy */
 __device__ __forceinline__ void tile_vsample (const JobDev &J, uint32_t jy, uint32_t &oy, uint32_t &F)
@@ -343,9 +407,32 @@ template <bool DMA, bool PREMUL>
 __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint32_t lane,
                                             uint32_t gfirst, uint32_t nrows, uint32_t g0, uint32_t g1)
 {
-    const uint32_t total = nrows * J.span_chunks;
     const uintptr_t src_base = (uintptr_t) J.src;
     const size_t src_stride = J.src_stride;
+
+    if (DMA)
+    {
+        /* Row by row: the row's base, aligned start and chunk count are wave-uniform
+         * (scalar unit), a lane only adds 16 * its chunk index. */
+        for (uint32_t i = 0; i < nrows; i++)
+        {
+            const uintptr_t rb = src_base + (size_t) (gfirst + i) * src_stride;
+            const uintptr_t a0 = (rb + g0) & ~(uintptr_t) 15;
+            const uint32_t nch = (uint32_t) ((rb + g1 - a0 + 15) >> 4);
+            uint8_t *rowdst = buf + (size_t) i * J.span_chunks * 16;
+
+            for (uint32_t k0 = 0; k0 < nch; k0 += TILE_COLS)
+            {
+                const uint32_t k = k0 + lane;
+                if (k < nch)
+                    smol_global_load_lds16 (reinterpret_cast<const void *> (a0 + (uintptr_t) k * 16),
+                                            rowdst + (size_t) k0 * 16, lane);
+            }
+        }
+        return;
+    }
+
+    const uint32_t total = nrows * J.span_chunks;
     const uint32_t ain = J.pos_in [3];
 
     for (uint32_t c0 = 0; c0 < total; c0 += TILE_COLS * TILE_STAGE_UNROLL)
@@ -355,8 +442,7 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
 #pragma unroll
         for (int u = 0; u < TILE_STAGE_UNROLL; u++)
         {
-            const uint32_t cu = c0 + (uint32_t) u * TILE_COLS;      /* wave-uniform */
-            const uint32_t c = cu + lane;
+            const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
             const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
             const uint32_t k = c - i * J.span_chunks;
             const uintptr_t rb = src_base + (size_t) (gfirst + i) * src_stride;
@@ -364,34 +450,23 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
             const uint32_t nch = (uint32_t) ((rb + g1 - a0 + 15) >> 4);
 
             ok [u] = (c < total) && (k < nch);
-            if (DMA)
-            {
-                if (cu < total && ok [u])
-                    smol_global_load_lds16 (reinterpret_cast<const void *> (a0 + (uintptr_t) k * 16),
-                                            buf + (size_t) cu * 16, lane);
-            }
-            else if (ok [u])
-            {
+            if (ok [u])
                 v [u] = *reinterpret_cast<const u32x4 *> (a0 + (uintptr_t) k * 16);
-            }
         }
-        if (!DMA)
-        {
 #pragma unroll
-            for (int u = 0; u < TILE_STAGE_UNROLL; u++)
+        for (int u = 0; u < TILE_STAGE_UNROLL; u++)
+        {
+            const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
+            if (ok [u])
             {
-                const uint32_t c = c0 + (uint32_t) u * TILE_COLS + lane;
-                if (ok [u])
+                if (PREMUL)
                 {
-                    if (PREMUL)
-                    {
-                        v [u].x = premul_word (v [u].x, ain);
-                        v [u].y = premul_word (v [u].y, ain);
-                        v [u].z = premul_word (v [u].z, ain);
-                        v [u].w = premul_word (v [u].w, ain);
-                    }
-                    *reinterpret_cast<u32x4 *> (buf + (size_t) c * 16) = v [u];
+                    v [u].x = premul_word (v [u].x, ain);
+                    v [u].y = premul_word (v [u].y, ain);
+                    v [u].z = premul_word (v [u].z, ain);
+                    v [u].w = premul_word (v [u].w, ain);
                 }
+                *reinterpret_cast<u32x4 *> (buf + (size_t) c * 16) = v [u];
             }
         }
     }
@@ -544,6 +619,8 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
     const uint32_t row_last = (e_last & 0xffffu) + vlag;
     const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
+    /* 24-bit output, full-width tile, 4-byte aligned rows: dword-granular stores */
+    const bool full24 = (LPC == 1) && (xn == x0 + TW) && J.out3_ok;
     const uint32_t xn_store = (sub == 0) ? xn : 0u;    /* only the first lane of a column group stores */
 
     Px2 hprev [CPL], acc [CPL];
@@ -622,22 +699,22 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 }
                 else if (HBOX)
                 {
-                    uint32_t wp, wq;
+                    Px2 pp, qq;
                     Px2 a = { 0, 0 };
                     if (sub == 0)
                     {
-                        tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis, wp, wq);
-                        a = px2_mulw (px2_from_word (wp), box_wl);
-                        tile_read_pair<TAP, false> (J, rowb, box_last + tmis, wp, wq);
-                        a = px2_add (a, px2_mulw (px2_from_word (wp), box_fr));
+                        tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis, pp, qq);
+                        a = px2_mulw (pp, box_wl);
+                        tile_read_pair<TAP, false> (J, rowb, box_last + tmis, pp, qq);
+                        a = px2_add (a, px2_mulw (pp, box_fr));
                     }
                     /* interior pixels: lane `sub' of the group takes every LPC-th one */
                     for (uint32_t ii = sub; ii < J.box_nmax; ii += LPC)
                     {
                         if (ii < box_n)
                         {
-                            tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis + (ii + 1) * BPP, wp, wq);
-                            a = px2_add (a, px2_from_word (wp));
+                            tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis + (ii + 1) * BPP, pp, qq);
+                            a = px2_add (a, pp);
                         }
                     }
                     if (LPC > 1)
@@ -655,9 +732,9 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 }
                 else if (HM == 0)
                 {
-                    uint32_t wp, wq;
-                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, wp, wq);
-                    h [c] = px2_from_word (wp);
+                    Px2 pp, qq;
+                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, pp, qq);
+                    h [c] = pp;
                 }
                 else
                 {
@@ -665,9 +742,9 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 #pragma unroll
                     for (uint32_t s = 0; s < NSX; s++)
                     {
-                        uint32_t wp, wq;
-                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, wp, wq);
-                        h [c] = px2_add (h [c], tap2 (px2_from_word (wp), px2_from_word (wq), tap_f [c][s]));
+                        Px2 pp, qq;
+                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
+                        h [c] = px2_add (h [c], tap2 (pp, qq, tap_f [c][s]));
                     }
                     if (HX)
                         h [c] = px2_shr (h [c], HX);
@@ -689,7 +766,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     Px2 o [CPL];
                     o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
                     if (!dbg_nostore || o [0].lo == 0x12345678u)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, o);
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, full24, o);
                     stores_since_dma += dbg_nostore ? 0u : 1u;
                     out_row += J.dst_stride;
                     ks++;
@@ -725,7 +802,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     for (int c = 0; c < CPL; c++)
                         o [c] = px2_shr (acc [c], hv);
                     if (!dbg_nostore || o [0].lo == 0x12345678u)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, o);
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o);
                     stores_since_dma += dbg_nostore ? 0u : 1u;
                     s_y = 0;
                     out_row += J.dst_stride;

@@ -85,3 +85,12 @@ static inline uint32_t wave_sum (uint32_t v)
         v += smol_shfl_xor (v, m);
     return v;
 }
+
+static inline uint32_t smol_shfl_idx (uint32_t v, uint32_t src)
+{
+    emu_lane_xchg [threadIdx.x] = v;
+    __syncthreads ();
+    uint32_t r = emu_lane_xchg [src & 63u];
+    __syncthreads ();
+    return r;
+}

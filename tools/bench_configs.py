@@ -33,6 +33,12 @@ CONFIGS = {
     "C5": (0, 256, 256, None, 0, 64, 64, 10000, "10000 thumbnails 256^2->64^2 RGBA8 premul (1H/1H), one batch"),
     "C5mix": (-1, 256, 256, None, -1, 64, 64, 10000, "10000 thumbnails 256^2->64^2, pixel types drawn uniformly from the 10x10 table"),
     "BOX": (0, 4096, 4096, None, 0, 448, 448, 8, "4096^2->448^2 RGBA8 premul (BOX/BOX 64bpp), 8 frames per launch"),
+    # arbitrary (non power-of-two) ratios through k_tile
+    "R1.5": (0, 4096, 4096, None, 0, 2731, 2731, 6, "4096^2->2731^2 RGBA8 premul (0H, ratio 1.5), 6 frames"),
+    "R3": (0, 4096, 4096, None, 0, 1365, 1365, 8, "4096^2->1365^2 RGBA8 premul (1H, ratio 3), 8 frames"),
+    "R6": (0, 4096, 4096, None, 0, 683, 683, 8, "4096^2->683^2 RGBA8 premul (2H, ratio 6), 8 frames"),
+    "PHOTO": (8, 4000, 3000, None, 8, 1600, 1200, 12, "4000x3000 RGB8 -> 1600x1200 RGB8 (1H, ratio 2.5), 12 frames"),
+    "PNG": (4, 4000, 3000, None, 0, 1600, 1200, 10, "4000x3000 RGBA unassociated -> 1600x1200 RGBA premul (1H), 10 frames"),
     # 128bpp-class rows: premul16 and sRGB-linear internal formats
     "P16": (4, 4096, 4096, None, 4, 1024, 1024, 4, "4096^2->1024^2 RGBA8 unassociated->unassociated (premul16, 128bpp class), 4 frames"),
     "SRGB": (0, 4096, 4096, None, 0, 1024, 1024, 4, "4096^2->1024^2 RGBA8 premul with_srgb=1 (linear, 128bpp class), 4 frames", 1),
