@@ -2,8 +2,8 @@ import sys, random
 sys.path.insert(0, "tests")
 import numpy as np
 from helpers import *
-exec(open("/tmp/fuzz1.py").read().split("bad = 0")[0].split("def rand_dims")[0])
-src_code = open("/tmp/fuzz1.py").read()
+exec(open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "fuzz1.py")).read().split("bad = 0")[0].split("def rand_dims")[0])
+src_code = open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "fuzz1.py")).read()
 exec("def rand_dims" + src_code.split("def rand_dims")[1].split("bad = 0")[0])
 random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
