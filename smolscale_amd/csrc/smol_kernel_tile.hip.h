@@ -412,14 +412,18 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
 
     if (DMA)
     {
-        /* Row by row: the row's base, aligned start and chunk count are wave-uniform
-         * (scalar unit), a lane only adds 16 * its chunk index. */
+        /* Row by row with a running row address: everything per row is a handful of
+         * scalar operations (the CU's one scalar unit is shared by all its waves and
+         * was the busiest pipe of this kernel), a lane only adds 16 * its chunk index. */
+        uintptr_t ra = src_base + (size_t) gfirst * src_stride + g0;    /* first needed byte of the row */
+        const uint32_t span_bytes = g1 - g0;
+        const uint32_t pitch = J.span_chunks * 16u;
+        uint8_t *rowdst = buf;
+
         for (uint32_t i = 0; i < nrows; i++)
         {
-            const uintptr_t rb = src_base + (size_t) (gfirst + i) * src_stride;
-            const uintptr_t a0 = (rb + g0) & ~(uintptr_t) 15;
-            const uint32_t nch = (uint32_t) ((rb + g1 - a0 + 15) >> 4);
-            uint8_t *rowdst = buf + (size_t) i * J.span_chunks * 16;
+            const uint32_t nch = (((uint32_t) ra & 15u) + span_bytes + 15u) >> 4;
+            const uintptr_t a0 = ra & ~(uintptr_t) 15;
 
             for (uint32_t k0 = 0; k0 < nch; k0 += TILE_COLS)
             {
@@ -428,6 +432,8 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
                     smol_global_load_lds16 (reinterpret_cast<const void *> (a0 + (uintptr_t) k * 16),
                                             rowdst + (size_t) k0 * 16, lane);
             }
+            ra += src_stride;
+            rowdst += pitch;
         }
         return;
     }
@@ -679,14 +685,16 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         }
 
         /* ---- consume the staged rows in order ------------------------------------- */
-        for (uint32_t i = 0; i < nrows; i++)
+        uint32_t ra_lo = (uint32_t) (src_base + (size_t) gfirst * J.src_stride + g0);   /* low bits of the row's first byte */
+        const uint8_t *rowbase = buf;
+        for (uint32_t i = 0; i < nrows; i++, ra_lo += J.src_stride, rowbase += row_pitch)
         {
             const uint32_t r = gfirst + i;
-            const uint32_t mis = (uint32_t) ((src_base + (size_t) r * J.src_stride + g0) & 15);
+            const uint32_t mis = ra_lo & 15u;
             /* TAP_A4: mis is a multiple of 4, fold it into the row base. Otherwise keep
              * the base 16-byte aligned and add mis to each tap's byte offset, so the
              * unaligned reader's dword loads stay 4-byte aligned in LDS. */
-            const uint8_t *rowb = buf + i * row_pitch + ((TAP == TAP_A4) ? mis : 0u);
+            const uint8_t *rowb = rowbase + ((TAP == TAP_A4) ? mis : 0u);
             const uint32_t tmis = (TAP == TAP_A4) ? 0u : mis;
 
             Px2 h [CPL];
