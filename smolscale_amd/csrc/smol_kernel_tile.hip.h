@@ -249,16 +249,16 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
 
     if (OUT != OUT_ANY)
     {
-        *reinterpret_cast<uint32_t *> (rowp + (size_t) x * 4) = w;
+        *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4) = w;
     }
     else if (J.bpp_out == 4)
     {
-        uint8_t *p = rowp + (size_t) x * 4;
+        gbyte *p = gptr (rowp) + (size_t) x * 4;
         p [0] = (uint8_t) w; p [1] = (uint8_t) (w >> 8); p [2] = (uint8_t) (w >> 16); p [3] = (uint8_t) (w >> 24);
     }
     else
     {
-        uint8_t *p = rowp + (size_t) x * 3;
+        gbyte *p = gptr (rowp) + (size_t) x * 3;
         p [0] = (uint8_t) w; p [1] = (uint8_t) (w >> 8); p [2] = (uint8_t) (w >> 16);
     }
 }
@@ -326,7 +326,6 @@ __device__ __forceinline__ uint32_t smol_shfl_xor (uint32_t v, uint32_t mask)
  * lane (4 pixels per lane) or -- one pixel per lane -- the wave's 64 pixels
  * re-cut into 48 dwords through two in-wave shuffles. `interior'/`full' are
  * wave-uniform. */
-struct __attribute__ ((packed, aligned (4))) U32x3 { uint32_t a, b, c; };   /* 12 bytes on a 4-byte boundary */
 
 template <int OUT, int CPL>
 __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp, uint32_t xl, uint32_t xn,
@@ -343,7 +342,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c]);
             u32x4 v = { w [0], w [1], w [2], w [3] };
-            __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (rowp + (size_t) xl * 4));
+            __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (rowp) + (size_t) xl * 4));
             return;
         }
     }
@@ -355,8 +354,11 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
 #pragma unroll
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c]) & 0x00ffffffu;
-            const U32x3 v = { w [0] | (w [1] << 24), (w [1] >> 8) | (w [2] << 16), (w [2] >> 16) | (w [3] << 8) };
-            *reinterpret_cast<U32x3 *> (rowp + (size_t) xl * 3) = v;
+            /* three consecutive dwords (the backend merges them into one dwordx3 store) */
+            SMOL_AS_GLOBAL uint32_t *d3 = reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) xl * 3);
+            d3 [0] = w [0] | (w [1] << 24);
+            d3 [1] = (w [1] >> 8) | (w [2] << 16);
+            d3 [2] = (w [2] >> 16) | (w [3] << 8);
         }
         else
         {
@@ -369,7 +371,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             const uint32_t wb = smol_shfl_idx (w, (a + 1u) & 63u);
             const uint32_t d = (wa >> (8u * b)) | (wb << (24u - 8u * b));
             if (j < 48u)
-                *reinterpret_cast<uint32_t *> (rowp + (size_t) (xl - j) * 3 + (size_t) j * 4) = d;
+                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) (xl - j) * 3 + (size_t) j * 4) = d;
         }
         return;
     }
@@ -457,7 +459,7 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
 
             ok [u] = (c < total) && (k < nch);
             if (ok [u])
-                v [u] = *reinterpret_cast<const u32x4 *> (a0 + (uintptr_t) k * 16);
+                v [u] = *reinterpret_cast<const SMOL_AS_GLOBAL u32x4 *> (a0 + (uintptr_t) k * 16);
         }
 #pragma unroll
         for (int u = 0; u < TILE_STAGE_UNROLL; u++)
@@ -773,7 +775,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 {
                     Px2 o [CPL];
                     o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
-                    if (!dbg_nostore || o [0].lo == 0x12345678u)
+                    if (!dbg_nostore)
                         tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, full24, o);
                     stores_since_dma += dbg_nostore ? 0u : 1u;
                     out_row += J.dst_stride;
@@ -809,7 +811,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
                         o [c] = px2_shr (acc [c], hv);
-                    if (!dbg_nostore || o [0].lo == 0x12345678u)
+                    if (!dbg_nostore)
                         tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o);
                     stores_since_dma += dbg_nostore ? 0u : 1u;
                     s_y = 0;

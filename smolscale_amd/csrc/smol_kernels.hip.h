@@ -36,6 +36,27 @@
 
 namespace smolhip {
 
+/* Image pointers arrive inside a descriptor struct, so the compiler only knows
+ * them as generic ("flat") pointers and would emit flat_load / flat_store. They
+ * always point to device global memory: say so, and get global_load / global_store
+ * (scalar base + 32-bit lane offset forms, vmcnt-only accounting). */
+#ifdef SMOL_KERNEL_EMU
+#define SMOL_AS_GLOBAL
+#else
+#define SMOL_AS_GLOBAL __attribute__ ((address_space (1)))
+#endif
+typedef SMOL_AS_GLOBAL uint8_t gbyte;
+
+__device__ __forceinline__ gbyte *gptr (void *p)
+{
+    return reinterpret_cast<gbyte *> (reinterpret_cast<uintptr_t> (p));
+}
+
+__device__ __forceinline__ const gbyte *gptr (const void *p)
+{
+    return reinterpret_cast<const gbyte *> (reinterpret_cast<uintptr_t> (p));
+}
+
 /* ------------------------------------------------------------------------- *
  * Per-channel arithmetic                                                    *
  * ------------------------------------------------------------------------- */
@@ -206,16 +227,16 @@ __device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, 
 
     if (J.bpp_in == 4)
     {
-        const uint8_t *p = rowp + (size_t) x * 4;
+        const gbyte *p = gptr (rowp) + (size_t) x * 4;
 
         if (J.in_dword_ok)
-            w = *reinterpret_cast<const uint32_t *> (p);
+            w = *reinterpret_cast<const SMOL_AS_GLOBAL uint32_t *> (p);
         else
             w = (uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t) p [2] << 16) | ((uint32_t) p [3] << 24);
     }
     else
     {
-        const uint8_t *p = rowp + (size_t) x * 3;
+        const gbyte *p = gptr (rowp) + (size_t) x * 3;
 
         w = (uint32_t) p [0] | ((uint32_t) p [1] << 8) | ((uint32_t) p [2] << 16);
     }
@@ -273,13 +294,13 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
 
     if (J.bpp_out == 4)
     {
-        uint8_t *p = rowp + (size_t) x * 4;
+        gbyte *p = gptr (rowp) + (size_t) x * 4;
         uint32_t w = (c [0] << (8 * J.pos_out [0])) | (c [1] << (8 * J.pos_out [1]))
                    | (c [2] << (8 * J.pos_out [2])) | (a << (8 * J.pos_out [3]));
 
         if (J.out_dword_ok)
         {
-            *reinterpret_cast<uint32_t *> (p) = w;
+            *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (p) = w;
         }
         else
         {
@@ -291,7 +312,7 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
     }
     else
     {
-        uint8_t *p = rowp + (size_t) x * 3;
+        gbyte *p = gptr (rowp) + (size_t) x * 3;
 
         p [J.pos_out [0]] = (uint8_t) c [0];
         p [J.pos_out [1]] = (uint8_t) c [1];
@@ -712,7 +733,7 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
         return;
 
     const uint32_t y = J.first_row + row;
-    const uint8_t *sp = J.src + (size_t) y * C::RY * J.src_stride + (size_t) tc * (C::NLOAD * 16);
+    const gbyte *sp = gptr (J.src) + (size_t) y * C::RY * J.src_stride + (size_t) tc * (C::NLOAD * 16);
 
     /* Issue every load of the block first: RY * NLOAD independent 16-byte loads
      * in flight per lane. */
@@ -722,7 +743,7 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
 #pragma unroll
         for (int l = 0; l < C::NLOAD; l++)
             raw [r][l] = __builtin_nontemporal_load (
-                reinterpret_cast<const u32x4 *> (sp + (size_t) r * J.src_stride) + l);
+                reinterpret_cast<const SMOL_AS_GLOBAL u32x4 *> (sp + (size_t) r * J.src_stride) + l);
 
     uint32_t hres [C::OPT][C::RY];
 #pragma unroll
@@ -750,15 +771,15 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
         outv [o] = __builtin_amdgcn_perm (v, v, J.out_perm);
     }
 
-    uint8_t *dp = J.dst + (size_t) row * J.dst_stride + (size_t) tc * (C::OPT * 4);
+    gbyte *dp = gptr (J.dst) + (size_t) row * J.dst_stride + (size_t) tc * (C::OPT * 4);
     if (C::OPT == 1)
     {
-        __builtin_nontemporal_store (outv [0], reinterpret_cast<uint32_t *> (dp));
+        __builtin_nontemporal_store (outv [0], reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (dp));
     }
     else
     {
         const u32x2 v2 = { outv [0], outv [C::OPT - 1] };
-        __builtin_nontemporal_store (v2, reinterpret_cast<u32x2 *> (dp));
+        __builtin_nontemporal_store (v2, reinterpret_cast<SMOL_AS_GLOBAL u32x2 *> (dp));
     }
 }
 
