@@ -56,6 +56,31 @@ launch_pow2_hy (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_
     }
 }
 
+/* k_pow2x: one entry point per (halvings, input kind) */
+template <int H, int IN>
+void
+launch_pow2x_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_pow2x_batch<H, IN>), grid, dim3 (64, 16), 0, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_pow2x_one<H, IN>), grid, dim3 (64, 16), 0, s, rep);
+}
+
+template <int H>
+void
+launch_pow2x_h (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
+{
+    switch (rep.px_kind)
+    {
+        case smolhip::PX_N32: launch_pow2x_k<H, smolhip::PX_N32> (jobs_dev, rep, grid, s); break;
+        case smolhip::PX_N24: launch_pow2x_k<H, smolhip::PX_N24> (jobs_dev, rep, grid, s); break;
+        case smolhip::PX_W32: launch_pow2x_k<H, smolhip::PX_W32> (jobs_dev, rep, grid, s); break;
+        case smolhip::PX_W16: launch_pow2x_k<H, smolhip::PX_W16> (jobs_dev, rep, grid, s); break;
+        default:              launch_pow2x_k<H, smolhip::PX_W24> (jobs_dev, rep, grid, s); break;
+    }
+}
+
 /* k_tile has one entry point per (tapsel, horizontal mode, columns per lane) */
 template <int TS, int HM, int CPL>
 void
@@ -125,6 +150,20 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
             case 0: launch_pow2_hy<0> (jobs_dev, rep, grid, s); break;
             case 1: launch_pow2_hy<1> (jobs_dev, rep, grid, s); break;
             default: launch_pow2_hy<2> (jobs_dev, rep, grid, s); break;
+        }
+        return hipGetLastError ();
+    }
+
+    if (k == KC_POW2X)
+    {
+        /* groups share halvings and input kind; max_lds carries the group's largest block count */
+        dim3 grid (max_lds ? max_lds : pow2x_blocks (rep), n_jobs);
+
+        switch (rep.halv_h)
+        {
+            case 0: launch_pow2x_h<0> (jobs_dev, rep, grid, s); break;
+            case 1: launch_pow2x_h<1> (jobs_dev, rep, grid, s); break;
+            default: launch_pow2x_h<2> (jobs_dev, rep, grid, s); break;
         }
         return hipGetLastError ();
     }
@@ -448,6 +487,8 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if ((g.k == KC_WAVEPX || g.k == KC_WAVEPX_WIDE) && jobs [j].w_out != g.rep.w_out)
                 continue;
+            if (g.k == KC_POW2X && (jobs [j].halv_h != g.rep.halv_h || jobs [j].px_kind != g.rep.px_kind))
+                continue;
             if (g.count == 65535)
                 break;
             taken [j] = true;
@@ -456,6 +497,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
             if (jobs [j].n_rows > g.max_rows) g.max_rows = jobs [j].n_rows;
             if ((g.k == KC_TILE || g.k == KC_WTILE) && tile_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = tile_lds_bytes (jobs [j]);
+            if (g.k == KC_POW2X && pow2x_blocks (jobs [j]) > g.max_lds) g.max_lds = pow2x_blocks (jobs [j]);
             units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
         }
 
@@ -505,7 +547,7 @@ smol_hip_batch_use_graph (SmolHipBatch *batch, int enable)
         HIP_TRY (hipStreamCreateWithFlags (&cs, hipStreamNonBlocking));
         HIP_TRY (hipStreamBeginCapture (cs, hipStreamCaptureModeThreadLocal));
         hipError_t e = hipSuccess;
-        for (const JobDev &jd : batch->jobs_host)
+        for (JobDev &jd : batch->jobs_host)
         {
             if (jd.n_rows == 0)
                 continue;

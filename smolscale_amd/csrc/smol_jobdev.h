@@ -14,6 +14,9 @@ namespace smolhip {
 
 enum : uint8_t { F_COPY = 0, F_ONE = 1, F_BILINEAR = 2, F_BOX = 3 };
 
+/* k_pow2x input kinds: 32/24-bit input x 64bpp/128bpp-class math */
+enum : int { PX_N32 = 0, PX_N24 = 1, PX_W32 = 2, PX_W24 = 3, PX_W16 = 4 /* 32-bit in, premul16 without sRGB */ };
+
 /* One job as the kernels see it (device-resident for batches, by-value kernel
  * argument for single launches). Channel numbering: 0,1,2 = R,G,B, 3 = A. */
 struct JobDev
@@ -38,6 +41,8 @@ struct JobDev
     uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8)              */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
+    uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
+    uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
@@ -59,7 +64,7 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -279,11 +284,68 @@ pow2_ok (const JobDev &d)
     return true;
 }
 
+/* k_pow2x geometry: output pixels per lane for this job's kind and ratio */
+inline uint32_t
+pow2x_opt (const JobDev &d)
+{
+    const uint32_t r = 2u << d.halv_h;
+    return (r >= 4 ? r : 4u) / r;          /* a lane's load unit is 4 source pixels */
+}
+
+/* Exact 2:1/4:1/8:1 with the same ratio on both axes, any pixel types, either
+ * storage class; 16-byte aligned source rows, destination aligned for the lane's
+ * vector store. Fills px_kind / px_lpr_shift. */
+inline bool
+pow2x_setup (JobDev &d)
+{
+    if (d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR || d.halv_h != d.halv_v)
+        return false;
+    if (d.w_in != (d.w_out << (d.halv_h + 1)) || d.h_in != (d.h_out << (d.halv_v + 1)))
+        return false;
+    if (getenv ("SMOL_NO_POW2X"))
+        return false;
+
+    const uint32_t opt = pow2x_opt (d);
+
+    if (d.w_out % opt)
+        return false;
+    if ((((uintptr_t) d.src) | d.src_stride) & (d.bpp_in == 3 ? 3 : 15))
+        return false;
+    if (!d.wide)
+    {
+        const uint32_t dalign = (d.bpp_out == 4) ? (opt >= 4 ? 16u : opt * 4u)
+                                                 : (opt >= 4 ? 4u : (opt == 2 ? 2u : 1u));
+        if ((((uintptr_t) d.dst) | d.dst_stride) & (dalign - 1))
+            return false;
+    }
+
+    d.px_kind = (uint8_t) ((d.wide ? 2 : 0) + (d.bpp_in == 3 ? 1 : 0));
+    if (d.wide && d.bpp_in == 4 && d.p16 && !d.linear)
+        d.px_kind = PX_W16;
+    const uint32_t tcols = d.w_out / opt;
+    uint32_t shift = 0;
+    while (shift < 6 && (1u << shift) < tcols)
+        shift++;
+    d.px_lpr_shift = (uint8_t) shift;
+    return true;
+}
+
+inline uint32_t
+pow2x_blocks (const JobDev &d)
+{
+    const uint32_t tcols = d.w_out / pow2x_opt (d);
+    const uint32_t lpr = 1u << d.px_lpr_shift;
+    const uint32_t rows_per_block = 16u * (64u >> d.px_lpr_shift);
+    return ((tcols + lpr - 1) / lpr) * ((d.n_rows + rows_per_block - 1) / rows_per_block);
+}
+
 inline KClass
-classify (const JobDev &d)
+classify (JobDev &d)
 {
     if (pow2_ok (d))
         return KC_POW2;
+    if (pow2x_setup (d))
+        return KC_POW2X;
     if (tile_ok (d))
         return KC_TILE;
     if (wtile_ok (d))
@@ -301,6 +363,7 @@ kclass_name (KClass k, const JobDev &d)
     switch (k)
     {
         case KC_POW2: return "k_pow2_batch";
+        case KC_POW2X: return "k_pow2x_batch";
         case KC_TILE: return "k_tile_batch";
         case KC_WTILE: return "k_wtile_batch";
         case KC_WAVEPX: return "k_wavepx_batch<false>";

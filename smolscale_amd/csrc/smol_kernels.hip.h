@@ -16,6 +16,10 @@
  *                     Pure streaming: each lane issues 16-byte loads that are
  *                     contiguous across the wave (1 KiB per load instruction),
  *                     no LDS, no tables, every source byte read exactly once.
+ *   k_pow2x<H,IN>     the same streaming shape for every other pixel-type pair
+ *                     and for the 128bpp class (smol_kernel_pow2x.hip.h).
+ *   k_tile / k_wtile  LDS-tiled kernels for arbitrary ratios (smol_kernel_tile.hip.h,
+ *                     smol_kernel_wtile.hip.h).
  */
 
 #pragma once
@@ -802,3 +806,4 @@ k_pow2_one (const JobDev J)
 
 #include "smol_kernel_tile.hip.h"
 #include "smol_kernel_wtile.hip.h"
+#include "smol_kernel_pow2x.hip.h"

@@ -80,6 +80,19 @@ static void run_pow2_hy (const JobDev &J, unsigned gx)
     }
 }
 
+template <int H>
+static void run_pow2x_h (const JobDev &J, unsigned gx)
+{
+    switch (J.px_kind)
+    {
+        case PX_N32: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_N32> (J); }); break;
+        case PX_N24: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_N24> (J); }); break;
+        case PX_W32: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W32> (J); }); break;
+        case PX_W16: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W16> (J); }); break;
+        default:     run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W24> (J); }); break;
+    }
+}
+
 extern "C" int
 emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
                 void *dst, uint32_t stride_out, uint32_t first_row, uint32_t n_rows,
@@ -88,7 +101,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
     JobDev J;
     fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
     KClass k = classify (J);
-    if (force_general && (k == KC_POW2 || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
+    if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
     if (force_general == 2 && tile_ok (J))
         k = KC_TILE;                      /* force the tiled kernel where the fast path would win */
@@ -106,6 +119,18 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
             case 0: run_pow2_hy<0> (J, gx); break;
             case 1: run_pow2_hy<1> (J, gx); break;
             default: run_pow2_hy<2> (J, gx); break;
+        }
+        return 0;
+    }
+
+    if (k == KC_POW2X)
+    {
+        const unsigned gx = pow2x_blocks (J);
+        switch (J.halv_h)
+        {
+            case 0: run_pow2x_h<0> (J, gx); break;
+            case 1: run_pow2x_h<1> (J, gx); break;
+            default: run_pow2x_h<2> (J, gx); break;
         }
         return 0;
     }

@@ -53,6 +53,29 @@ def test_emulated_pow2_kernel_matches_oracle():
     assert hits >= 40
 
 
+def test_emulated_pow2x_kernel_every_type_pair_and_class():
+    """k_pow2x: exact 2:1/4:1/8:1 for all 10x10 type pairs, with and without sRGB
+    (64bpp class, premul16, linear), thumbnails narrower than a wave included."""
+    rng = random.Random(77)
+    hits, kinds = 0, set()
+    for it in range(160):
+        h = rng.randrange(3)
+        w_out = rng.choice([4, 8, 16, 24, 40, 64, 72, 128, 136, 264])
+        h_out = rng.randint(1, 36)
+        w_in, h_in = w_out << (h + 1), h_out << (h + 1)
+        t_in, t_out = (it // 10) % 10, it % 10              # every pair at least once
+        srgb = rng.choice([0, 0, 1])
+        src = H.aligned_copy(H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), pad=32))
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, None, None, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, None, None, first, n)
+        hits += (k == 7)
+        kinds.add((H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb).wide, H.bpp(t_in)))
+        assert np.array_equal(got, want), (h, w_out, h_out, t_in, t_out, srgb, first, n, k)
+    assert hits >= 120 and len(kinds) == 4
+
+
 def test_emulated_kernels_match_golden_subset():
     for (t_in, w_in, h_in, t_out, w_out, h_out, srgb, seed, valid), want in C.matrix_cases(stride=23):
         src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)

@@ -85,6 +85,29 @@ def test_pow2_fast_path_vs_oracle():
         assert np.array_equal(got, want), (hx, hy, w_out, h_out, t_in, t_out)
 
 
+def test_pow2x_every_type_pair_and_storage_class():
+    """k_pow2x (exact 2:1/4:1/8:1, any pixel types, 64bpp and 128bpp classes) through
+    the host-pointer API and from caller-owned device buffers."""
+    rng = random.Random(313)
+    for it in range(200):
+        h = rng.randrange(3)
+        w_out = rng.choice([4, 8, 16, 24, 64, 72, 136, 256, 300, 1024])
+        h_out = rng.randint(1, 70)
+        w_in, h_in = w_out << (h + 1), h_out << (h + 1)
+        t_in, t_out = (it // 10) % 10, it % 10
+        srgb = (it // 100) & 1
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), pad=32)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, want), ("host", h, w_out, h_out, t_in, t_out, srgb)
+        if it % 4 == 0:
+            first = rng.randint(0, h_out - 1)
+            n = rng.randint(1, h_out - first)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, None, None, first, n)
+            got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, None, None, first, n)
+            assert np.array_equal(got, want), ("device", h, w_out, h_out, t_in, t_out, srgb, first, n)
+
+
 def test_tile_kernel_wide_images_and_box_shapes():
     """Geometries that select every k_tile layout: 4 columns per lane (wide, few taps),
     one column per lane, box with 1 and with 8 lanes per column, box on one axis only."""

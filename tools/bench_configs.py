@@ -53,10 +53,18 @@ def bpp(t):
     return sm.bytes_per_pixel(t)
 
 
-def run_config(name, iters, warmup, check, graph=False):
+def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srgb_override=None):
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
     srgb = cfg[9] if len(cfg) > 9 else 0
+    if tin is not None:
+        t_in0, stride_in = tin, None
+    if tout is not None:
+        t_out0 = tout
+    if srgb_override is not None:
+        srgb = srgb_override
+    if tin is not None or tout is not None or srgb_override is not None:
+        desc += " [types overridden: in=%d out=%d srgb=%d]" % (t_in0, t_out0, srgb)
     rng = np.random.default_rng(12345)
     images, bufs, specs = [], [], []
     total_in = total_out = 0
@@ -131,9 +139,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--graph", action="store_true", help="submit each batch as a hipGraph of per-image launches")
+    ap.add_argument("--tin", type=int, default=None, help="override the input pixel type (0-9) of every config")
+    ap.add_argument("--tout", type=int, default=None, help="override the output pixel type (0-9)")
+    ap.add_argument("--srgb", type=int, default=None, help="override with_srgb")
     args = ap.parse_args()
     for name in args.configs.split(","):
-        print(json.dumps(run_config(name, args.iters, args.warmup, args.check, args.graph)), flush=True)
+        print(json.dumps(run_config(name, args.iters, args.warmup, args.check, args.graph,
+                                    args.tin, args.tout, args.srgb)), flush=True)
 
 
 if __name__ == "__main__":
