@@ -81,6 +81,29 @@ launch_pow2x_h (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_
     }
 }
 
+/* k_up: one entry point per (input alignment kind, output kind) */
+template <int INK, int OUT>
+void
+launch_up_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_up_batch<INK, OUT>), grid, dim3 (64), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_up_one<INK, OUT>), grid, dim3 (64), lds, s, rep);
+}
+
+template <int INK>
+void
+launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (rep.tile_variant & 3u)
+    {
+        case smolhip::OUT_P4: launch_up_k<INK, smolhip::OUT_P4> (jobs_dev, rep, grid, lds, s); break;
+        case smolhip::OUT_U4: launch_up_k<INK, smolhip::OUT_U4> (jobs_dev, rep, grid, lds, s); break;
+        default:              launch_up_k<INK, smolhip::OUT_ANY> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
 /* k_tile has one entry point per (tapsel, horizontal mode, columns per lane) */
 template <int TS, int HM, int CPL>
 void
@@ -165,6 +188,20 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
             case 1: launch_pow2x_h<1> (jobs_dev, rep, grid, s); break;
             default: launch_pow2x_h<2> (jobs_dev, rep, grid, s); break;
         }
+        return hipGetLastError ();
+    }
+
+    if (k == KC_UP)
+    {
+        /* groups share the input and output kinds; max_lds carries the largest block
+         * count, max_w_out (batches only) the largest LDS size */
+        dim3 grid (max_lds ? max_lds : up_blocks (rep), n_jobs);
+        const uint32_t lds = jobs_dev ? max_w_out : up_lds_bytes (rep);
+
+        if (rep.tile_aligned4)
+            launch_up_in<smolhip::UP_IN_A4> (jobs_dev, rep, grid, lds, s);
+        else
+            launch_up_in<smolhip::UP_IN_ANY> (jobs_dev, rep, grid, lds, s);
         return hipGetLastError ();
     }
 
@@ -489,15 +526,23 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2X && (jobs [j].halv_h != g.rep.halv_h || jobs [j].px_kind != g.rep.px_kind))
                 continue;
+            if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4
+                                 || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))
+                continue;
             if (g.count == 65535)
                 break;
             taken [j] = true;
             sorted.push_back (jobs [j]);
             g.count++;
-            if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
+            if (g.k == KC_UP)
+            {
+                if (up_lds_bytes (jobs [j]) > g.max_w_out) g.max_w_out = up_lds_bytes (jobs [j]);
+            }
+            else if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
             if (jobs [j].n_rows > g.max_rows) g.max_rows = jobs [j].n_rows;
             if ((g.k == KC_TILE || g.k == KC_WTILE) && tile_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = tile_lds_bytes (jobs [j]);
             if (g.k == KC_POW2X && pow2x_blocks (jobs [j]) > g.max_lds) g.max_lds = pow2x_blocks (jobs [j]);
+            if (g.k == KC_UP && up_blocks (jobs [j]) > g.max_lds) g.max_lds = up_blocks (jobs [j]);
             units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
         }
 

@@ -29,6 +29,7 @@ struct JobDev
     uint64_t frac0_x, step_x, frac0_y, step_y;
     uint32_t span_mul_x, span_mul_y;
     uint32_t out_perm;             /* v_perm selector, 32bpp -> 32bpp byte shuffle       */
+    uint32_t up_perm;              /* k_up: out_perm composed with the gather of the four result bytes */
     uint8_t filter_h, filter_v, halv_h, halv_v;
     uint8_t bpp_in, bpp_out;
     uint8_t pos_in [4], pos_out [4];   /* byte index of R,G,B,A; 0xff = no alpha         */
@@ -64,7 +65,7 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_UP, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -339,6 +340,58 @@ pow2x_blocks (const JobDev &d)
     return ((tcols + lpr - 1) / lpr) * ((d.n_rows + rows_per_block - 1) / rows_per_block);
 }
 
+/* k_up: bilinear magnification on both axes, 64bpp class. A tile of tile_rows
+ * output rows may touch at most UP_NSRC source rows (smol_kernel_up.hip.h):
+ * rows r = 0..TR-1 span floor ((TR-1) * step) + 3 source rows at most. */
+constexpr uint32_t UP_NSRC_HOST = 10;
+
+inline bool
+up_setup (JobDev &d)
+{
+    if (d.wide || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR || d.halv_h || d.halv_v)
+        return false;
+    if (d.step_x >= ((uint64_t) 1 << 32) || d.step_y >= ((uint64_t) 1 << 32) || d.step_x == 0 || d.step_y == 0)
+        return false;
+    if (d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_UP"))
+        return false;
+
+    uint64_t tr = (((uint64_t) (UP_NSRC_HOST - 3)) << 32) / d.step_y + 1;
+    if (tr > 64)
+        tr = 64;
+    if (const char *e = getenv ("SMOL_UP_ROWS"))
+        if ((uint64_t) atoi (e) >= 1 && (uint64_t) atoi (e) < tr)
+            tr = (uint64_t) atoi (e);
+    d.tile_rows = (uint16_t) tr;
+
+    /* source pixels a 256-column tile can reach: ofs (x0 + 255) + 1 - ofs (x0) + 1 */
+    uint64_t span = ((255u * d.step_x) >> 32) + 3;
+    if (span > d.w_in)
+        span = d.w_in;
+    d.span_px = (uint32_t) span;
+    d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / span) + 1;     /* i / span for i < 2^16 */
+
+    /* the four result bytes sit in the high byte of each 16-bit lane of {hi, lo}:
+     * in-order byte k is v_perm index {1, 5, 3, 7}[k]; compose with out_perm */
+    static const uint32_t gather [4] = { 1, 5, 3, 7 };
+    d.up_perm = 0;
+    for (int i = 0; i < 4; i++)
+        d.up_perm |= gather [(d.out_perm >> (8 * i)) & 3u] << (8 * i);
+    return true;
+}
+
+inline uint32_t
+up_lds_bytes (const JobDev &d)
+{
+    return UP_NSRC_HOST * d.span_px * 8u + 16u;
+}
+
+inline uint32_t
+up_blocks (const JobDev &d)
+{
+    const uint32_t n = ((d.w_out + 255u) / 256u) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
+    return (n + 7u) & ~7u;
+}
+
 inline KClass
 classify (JobDev &d)
 {
@@ -346,6 +399,8 @@ classify (JobDev &d)
         return KC_POW2;
     if (pow2x_setup (d))
         return KC_POW2X;
+    if (up_setup (d))
+        return KC_UP;
     if (tile_ok (d))
         return KC_TILE;
     if (wtile_ok (d))
@@ -364,6 +419,7 @@ kclass_name (KClass k, const JobDev &d)
     {
         case KC_POW2: return "k_pow2_batch";
         case KC_POW2X: return "k_pow2x_batch";
+        case KC_UP: return "k_up_batch";
         case KC_TILE: return "k_tile_batch";
         case KC_WTILE: return "k_wtile_batch";
         case KC_WAVEPX: return "k_wavepx_batch<false>";

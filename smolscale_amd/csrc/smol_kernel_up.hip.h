@@ -1,0 +1,286 @@
+/* smol_kernel_up.hip.h -- k_up: bilinear MAGNIFICATION on both axes, 64bpp class
+ * (BASELINE config 3 and every other upscale). Included at the end of
+ * smol_kernels.hip.h, after smol_kernel_tile.hip.h whose packed-lane helpers and
+ * pixel stores it shares.
+ *
+ * Magnification is write-bound: one source pixel feeds many outputs, so the
+ * kernel is organised around the stores. One wave owns a tile of 256 output
+ * columns x tile_rows output rows; a lane owns 4 adjacent columns (one 16-byte
+ * store per output row).
+ *
+ *   stage  With both steps below 1.0 a tile of up to 64 output rows touches at
+ *          most UP_NSRC source rows (the host sizes tile_rows for that) and a short
+ *          span of each. Every source pixel of the tile is loaded ONCE, premultiplied
+ *          if the input is unassociated (smolscale-generic.c:238-244, 415-464),
+ *          split into packed 16-bit lanes and parked in LDS (8 bytes per pixel).
+ *   H      a lane reads the two pixels under each of its 4 columns for every source
+ *          row and keeps the horizontal result (:1290-1361) as one pixel word per
+ *          (row, column) in registers.
+ *   V      output rows then leave in order: row r blends the register rows oy(r)
+ *          and oy(r)+1 with weight F(r) (:1648-1719) -- two packed multiply-adds and
+ *          one v_perm per pixel -- and is stored at once. oy/F come from a schedule
+ *          the lanes computed once (lane r holds row r's entry), fetched with
+ *          v_readlane. One wave per workgroup: no barriers, and nothing ever waits
+ *          for a store.
+ *
+ * Tap arithmetic is the packed 16-bit form of k_tile (tap2): for 8-bit values
+ * q + (((p - q) * F) >> 8) == (p * F + q * (256 - F)) >> 8. */
+
+#pragma once
+
+namespace smolhip {
+
+constexpr int UP_CPL = 4;           /* output columns per lane                   */
+constexpr int UP_NSRC = 10;         /* source rows a tile may touch (host: tile_setup_up) */
+
+enum : int
+{
+    UP_IN_A4 = 0,   /* 32-bit pixels at 4-byte aligned addresses */
+    UP_IN_ANY = 1   /* 24-bit pixels, or 32-bit ones at odd addresses */
+};
+
+/* one source pixel as a pixel word (24-bit input: alpha = 0xff) */
+template <int INK>
+__device__ __forceinline__ uint32_t up_load_px (const JobDev &J, const gbyte *rowp, uint32_t x)
+{
+    if (INK == UP_IN_A4)
+        return *reinterpret_cast<const SMOL_AS_GLOBAL uint32_t *> (rowp + (size_t) x * 4);
+
+    /* aligned dwords around the pixel; a dword holding at least one wanted byte
+     * never leaves the buffer's last page, one holding none is not touched */
+    const uint32_t nb = J.bpp_in;
+    const uintptr_t a = reinterpret_cast<uintptr_t> (rowp) + (size_t) x * nb;
+    const uint32_t sh = (uint32_t) a & 3u;
+    const SMOL_AS_GLOBAL uint32_t *d = reinterpret_cast<const SMOL_AS_GLOBAL uint32_t *> (a - sh);
+    const uint32_t d0 = d [0];
+    uint32_t d1 = 0;
+    if (sh + nb > 4u)
+        d1 = d [1];
+    const uint32_t w = __builtin_amdgcn_alignbyte (d1, d0, sh);
+    return (nb == 3) ? (w | 0xff000000u) : w;
+}
+
+constexpr int UP_STAGE_UNROLL = 8;
+constexpr uint32_t UP_SEL_HIBYTES = 0x07030501u;    /* v_perm: high byte of each 16-bit lane of {S0 = hi, S1 = lo} */
+
+typedef uint32_t u32x4a8 __attribute__ ((ext_vector_type (4), aligned (8)));
+typedef uint32_t u32x2a8 __attribute__ ((ext_vector_type (2), aligned (8)));
+
+/* d * F + b per 16-bit lane (modulo 2^16; exact here, see up_body) */
+__device__ __forceinline__ uint32_t up_mad (uint32_t d, uint32_t F2, uint32_t b)
+{
+    return as_u32 (as_u16x2 (d) * as_u16x2 (F2) + as_u16x2 (b));
+}
+
+template <int INK, int OUT>
+__device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
+{
+    constexpr uint32_t TW = TILE_COLS * UP_CPL;
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
+    /* each XCD (blocks go round-robin over the 8 of them) takes a contiguous band of
+     * tiles, so horizontally adjacent tiles are written from the same L2 at about
+     * the same time; the host rounds the grid up to a multiple of 8 */
+    const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t tx = bid % tiles_x;
+    const uint32_t ty = bid / tiles_x;
+    const uint32_t yrel0 = ty * J.tile_rows;
+
+    if (yrel0 >= J.n_rows)
+        return;
+
+    const uint32_t nrows = (yrel0 + J.tile_rows < J.n_rows) ? J.tile_rows : J.n_rows - yrel0;   /* <= 64 */
+    const uint32_t x0 = tx * TW;
+    const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;
+    const uint32_t xl = x0 + lane * UP_CPL;
+
+    /* ---- horizontal taps of this lane's columns ------------------------------- */
+    uint32_t tap_ofs [UP_CPL], tap_f2 [UP_CPL];
+#pragma unroll
+    for (int c = 0; c < UP_CPL; c++)
+    {
+        const uint32_t xc = (xl + c < xn) ? xl + c : xn - 1;
+        uint32_t f;
+        bilin_tap (J.frac0_x + (uint64_t) xc * J.step_x, J.w_in, tap_ofs [c], f);
+        tap_f2 [c] = f | (f << 16);
+    }
+    const uint32_t sx0 = smol_readlane (tap_ofs [0], 0);       /* first source pixel of the tile */
+
+    /* ---- vertical schedule: lane r holds (source row, weight) of tile row r ---- */
+    uint32_t my_oy, my_f;
+    {
+        const uint32_t r = (lane < nrows) ? lane : nrows - 1;
+        bilin_tap (J.frac0_y + (uint64_t) (J.first_row + yrel0 + r) * J.step_y, J.h_in, my_oy, my_f);
+    }
+    const uint32_t oy_first = smol_readlane (my_oy, 0);
+    const uint32_t oy_last = smol_readlane (my_oy, nrows - 1);
+    const uint32_t sched = (my_oy - oy_first) | (my_f << 16);
+    uint32_t n_src = oy_last - oy_first + 2;
+    if (n_src > (uint32_t) UP_NSRC)
+        n_src = UP_NSRC;                                /* cannot happen: up_setup sizes tile_rows */
+
+    /* ---- stage: every source pixel of the tile, once ------------------------------
+     * span_px pixels (host bound, >= what the taps reach) of each of the n_src rows:
+     * loaded, premultiplied if the input is unassociated, split into the two packed
+     * 16-bit-lane halves (bytes 0,2 | bytes 1,3) and written to LDS, 8 bytes per
+     * pixel; pixel k of row s sits at 8 * (s * span_px + k). */
+    {
+        const gbyte *srow0 = gptr (J.src) + (size_t) oy_first * J.src_stride;
+        const uint32_t ain = (J.bpp_in == 4) ? J.pos_in [3] : 3u;
+        const bool premul_in = J.unassoc_in;
+        const uint32_t span = J.span_px;
+        const uint32_t total = n_src * span;
+
+        for (uint32_t i0 = 0; i0 < total; i0 += 64u * UP_STAGE_UNROLL)
+        {
+            uint32_t w [UP_STAGE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < UP_STAGE_UNROLL; u++)
+            {
+                const uint32_t i = i0 + (uint32_t) u * 64u + lane;
+                const uint32_t srow = (uint32_t) (((uint64_t) i * J.span_chunks_inv) >> 32);   /* i / span */
+                const uint32_t k = i - srow * span;
+                uint32_t x = sx0 + k;
+                if (x > J.w_in - 1)
+                    x = J.w_in - 1;
+                w [u] = 0;
+                if (i < total)
+                    w [u] = up_load_px<INK> (J, srow0 + (size_t) srow * J.src_stride, x);
+            }
+#pragma unroll
+            for (int u = 0; u < UP_STAGE_UNROLL; u++)
+            {
+                const uint32_t i = i0 + (uint32_t) u * 64u + lane;
+                const Px2 v = premul_in ? premul_px2 (w [u], ain) : px2_from_word (w [u]);
+                const u32x2a8 pair = { v.lo, v.hi };
+                if (i < total)
+                    *reinterpret_cast<u32x2a8 *> (lds + (size_t) i * 8) = pair;
+            }
+        }
+    }
+    smol_wave_sync ();                                  /* one wave: LDS operations complete in order */
+
+    /* ---- H: horizontal result of every (source row, column), one word each -------
+     * (smolscale-generic.c:1290-1361). p * F + q * (256 - F) is at most 255 * 256,
+     * so the high byte of each 16-bit lane is the result and one v_perm gathers
+     * the four of them back into a pixel word. */
+    uint32_t hw [UP_NSRC][UP_CPL];
+#pragma unroll
+    for (int s = 0; s < UP_NSRC; s++)
+    {
+#pragma unroll
+        for (int c = 0; c < UP_CPL; c++)
+            hw [s][c] = 0;
+        if ((uint32_t) s < n_src)                       /* wave-uniform */
+        {
+#pragma unroll
+            for (int c = 0; c < UP_CPL; c++)
+            {
+                const uint32_t k = (uint32_t) s * J.span_px + (tap_ofs [c] - sx0);
+                const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (lds + (size_t) k * 8);
+                const uint32_t g2 = 0x01000100u - tap_f2 [c];
+                const uint32_t lo = up_mad (pq.x, tap_f2 [c], as_u32 (as_u16x2 (pq.z) * as_u16x2 (g2)));
+                const uint32_t hi = up_mad (pq.y, tap_f2 [c], as_u32 (as_u16x2 (pq.w) * as_u16x2 (g2)));
+                hw [s][c] = __builtin_amdgcn_perm (hi, lo, UP_SEL_HIBYTES);
+            }
+        }
+    }
+
+    /* ---- V: output rows in order (:1648-1719) ------------------------------------
+     * For the rows between source rows s and s+1:  top * F + bot * (256 - F)
+     *   == (top - bot) * F + (bot << 8)   modulo 2^16 per lane, and the true value
+     * fits 16 bits, so d = top - bot and b = bot << 8 are set up once per source
+     * row pair and an output pixel costs two packed multiply-adds and one v_perm
+     * (which also reorders the bytes for the destination type). */
+    const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
+    const bool full24 = (xn == x0 + TW) && J.out3_ok;
+    uint8_t *out_row = J.dst + (size_t) yrel0 * J.dst_stride;
+    uint32_t r = 0;
+    uint32_t e = smol_readlane (sched, 0);
+    const uint32_t M_HI = 0xff00ff00u;
+
+#pragma unroll
+    for (int s = 0; s + 1 < UP_NSRC; s++)
+    {
+        if (r >= nrows || (e & 0xffffu) != (uint32_t) s)
+            continue;                                   /* wave-uniform */
+
+        uint32_t d_lo [UP_CPL], d_hi [UP_CPL], b_lo [UP_CPL], b_hi [UP_CPL];
+#pragma unroll
+        for (int c = 0; c < UP_CPL; c++)
+        {
+            const uint32_t t = hw [s][c], b = hw [s + 1][c];
+            d_lo [c] = as_u32 (as_u16x2 (t & PAIR_MASK) - as_u16x2 (b & PAIR_MASK));
+            d_hi [c] = as_u32 (as_u16x2 ((t >> 8) & PAIR_MASK) - as_u16x2 ((b >> 8) & PAIR_MASK));
+            b_lo [c] = (b << 8) & M_HI;
+            b_hi [c] = b & M_HI;
+        }
+
+        while (r < nrows && (e & 0xffffu) == (uint32_t) s)
+        {
+            const uint32_t F = e >> 16;
+            const uint32_t F2 = F | (F << 16);
+            uint32_t lo [UP_CPL], hi [UP_CPL];
+#pragma unroll
+            for (int c = 0; c < UP_CPL; c++)
+            {
+                lo [c] = up_mad (d_lo [c], F2, b_lo [c]);
+                hi [c] = up_mad (d_hi [c], F2, b_hi [c]);
+            }
+
+            if (OUT == OUT_P4 && interior)
+            {
+                const u32x4 v = { __builtin_amdgcn_perm (hi [0], lo [0], J.up_perm), __builtin_amdgcn_perm (hi [1], lo [1], J.up_perm),
+                                  __builtin_amdgcn_perm (hi [2], lo [2], J.up_perm), __builtin_amdgcn_perm (hi [3], lo [3], J.up_perm) };
+                __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (out_row) + (size_t) xl * 4));
+            }
+            else
+            {
+                Px2 o [UP_CPL];
+#pragma unroll
+                for (int c = 0; c < UP_CPL; c++)
+                {
+                    o [c].lo = (lo [c] >> 8) & PAIR_MASK;
+                    o [c].hi = (hi [c] >> 8) & PAIR_MASK;
+                }
+                tile_store_cols<OUT, UP_CPL> (J, out_row, xl, xn, interior, full24, o);
+            }
+            out_row += J.dst_stride;
+            r++;
+            if (r < nrows)
+                e = smol_readlane (sched, r);
+        }
+    }
+}
+
+#ifdef SMOL_KERNEL_EMU
+/* host emulation: one entry that switches at run time */
+__global__ void k_up_one (const JobDev J)
+{
+    const bool a4 = J.tile_aligned4;
+    switch (J.tile_variant & 3u)
+    {
+        case OUT_P4: if (a4) up_body<UP_IN_A4, OUT_P4> (J, smol_dyn_lds); else up_body<UP_IN_ANY, OUT_P4> (J, smol_dyn_lds); break;
+        case OUT_U4: if (a4) up_body<UP_IN_A4, OUT_U4> (J, smol_dyn_lds); else up_body<UP_IN_ANY, OUT_U4> (J, smol_dyn_lds); break;
+        default:     if (a4) up_body<UP_IN_A4, OUT_ANY> (J, smol_dyn_lds); else up_body<UP_IN_ANY, OUT_ANY> (J, smol_dyn_lds); break;
+    }
+}
+#else
+template <int INK, int OUT>
+__global__ void __launch_bounds__ (64)
+k_up_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = jobs [blockIdx.y];
+    up_body<INK, OUT> (J, smol_dyn_lds);
+}
+
+template <int INK, int OUT>
+__global__ void __launch_bounds__ (64)
+k_up_one (const JobDev J)
+{
+    up_body<INK, OUT> (J, smol_dyn_lds);
+}
+#endif
+
+} /* namespace smolhip */

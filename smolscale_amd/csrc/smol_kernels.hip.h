@@ -18,6 +18,8 @@
  *                     no LDS, no tables, every source byte read exactly once.
  *   k_pow2x<H,IN>     the same streaming shape for every other pixel-type pair
  *                     and for the 128bpp class (smol_kernel_pow2x.hip.h).
+ *   k_up<IN,OUT>      bilinear magnification on both axes, organised around the
+ *                     stores (smol_kernel_up.hip.h).
  *   k_tile / k_wtile  LDS-tiled kernels for arbitrary ratios (smol_kernel_tile.hip.h,
  *                     smol_kernel_wtile.hip.h).
  */
@@ -807,3 +809,4 @@ k_pow2_one (const JobDev J)
 #include "smol_kernel_tile.hip.h"
 #include "smol_kernel_wtile.hip.h"
 #include "smol_kernel_pow2x.hip.h"
+#include "smol_kernel_up.hip.h"

@@ -76,6 +76,31 @@ def test_emulated_pow2x_kernel_every_type_pair_and_class():
     assert hits >= 120 and len(kinds) == 4
 
 
+def test_emulated_up_kernel_magnification():
+    """k_up: bilinear magnification on both axes, every 64bpp-class type pair, odd
+    strides, row slabs, tiny sources (2 pixels) and ratios from 1.01x to 9x."""
+    rng = random.Random(808)
+    hits = 0
+    for it in range(140):
+        w_in = rng.choice([2, 3, 5, 8, 17, 64, 100, 257])
+        h_in = rng.choice([2, 3, 4, 9, 30, 65])
+        w_out = rng.randint(w_in + 1, min(w_in * 9, 1300))
+        h_out = rng.randint(h_in + 1, min(h_in * 9, 300))
+        t_in, t_out = (it // 10) % 10, it % 10
+        if H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0).wide:
+            continue
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 3, 4, 16])
+        sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4, 16])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        hits += (k == 8)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
+    assert hits >= 80
+
+
 def test_emulated_kernels_match_golden_subset():
     for (t_in, w_in, h_in, t_out, w_out, h_out, srgb, seed, valid), want in C.matrix_cases(stride=23):
         src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)

@@ -108,6 +108,27 @@ def test_pow2x_every_type_pair_and_storage_class():
             assert np.array_equal(got, want), ("device", h, w_out, h_out, t_in, t_out, srgb, first, n)
 
 
+def test_up_kernel_magnification_shapes():
+    """k_up: magnification on both axes; shapes that make tiles of 8..64 rows, spans
+    from 2 to 258 source pixels, partial edge tiles, all output kinds, misaligned
+    device buffers and odd strides."""
+    shapes = [
+        (4, 480, 270, 0, 1920, 1080), (0, 1000, 700, 1, 1010, 707), (8, 2, 2, 2, 900, 37),
+        (0, 300, 200, 8, 2700, 1800), (9, 257, 65, 4, 1300, 300), (5, 64, 64, 5, 513, 511),
+        (1, 1279, 719, 3, 1280, 720), (8, 100, 100, 9, 777, 333), (6, 33, 17, 0, 259, 130),
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out) in enumerate(shapes):
+        for (sin_pad, mis) in ((0, 0), (3, 1), (16, 4)):
+            sin = w_in * H.bpp(t_in) + sin_pad
+            src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "host", sin_pad)
+            got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin,
+                                     src_misalign=mis, dst_misalign=mis)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
+
+
 def test_tile_kernel_wide_images_and_box_shapes():
     """Geometries that select every k_tile layout: 4 columns per lane (wide, few taps),
     one column per lane, box with 1 and with 8 lanes per column, box on one axis only."""
