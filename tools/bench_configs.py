@@ -53,7 +53,7 @@ def bpp(t):
     return sm.bytes_per_pixel(t)
 
 
-def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srgb_override=None):
+def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3):
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
     srgb = cfg[9] if len(cfg) > 9 else 0
@@ -104,7 +104,11 @@ def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srg
     if graph:
         batch.use_graph(True)
         kname += " (hipGraph: one kernel node per image)"
-    ms = batch.time(warmup, iters)
+    # The GPU clock governor needs a few hundred ms of load to settle; instruction-bound
+    # kernels measured right after start-up read 10-20 % slow. Warm up for `settle' seconds.
+    probe_ms = batch.time(warmup, 5) / 5
+    n_settle = int(settle * 1e3 / max(probe_ms, 1e-3))
+    ms = batch.time(max(warmup, n_settle), iters)
     per_step_ms = ms / iters
     algo = total_in + total_out
     line = {
@@ -142,10 +146,11 @@ def main():
     ap.add_argument("--tin", type=int, default=None, help="override the input pixel type (0-9) of every config")
     ap.add_argument("--tout", type=int, default=None, help="override the output pixel type (0-9)")
     ap.add_argument("--srgb", type=int, default=None, help="override with_srgb")
+    ap.add_argument("--settle", type=float, default=0.3, help="seconds of warm-up load before timing (clock settling)")
     args = ap.parse_args()
     for name in args.configs.split(","):
         print(json.dumps(run_config(name, args.iters, args.warmup, args.check, args.graph,
-                                    args.tin, args.tout, args.srgb)), flush=True)
+                                    args.tin, args.tout, args.srgb, args.settle)), flush=True)
 
 
 if __name__ == "__main__":
