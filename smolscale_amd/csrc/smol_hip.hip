@@ -96,6 +96,11 @@ template <int INK>
 void
 launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
+    if (rep.up_wide)
+    {
+        launch_up_k<INK, smolhip::OUT_W16> (jobs_dev, rep, grid, lds, s);
+        return;
+    }
     switch (rep.tile_variant & 3u)
     {
         case smolhip::OUT_P4: launch_up_k<INK, smolhip::OUT_P4> (jobs_dev, rep, grid, lds, s); break;
@@ -526,7 +531,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2X && (jobs [j].halv_h != g.rep.halv_h || jobs [j].px_kind != g.rep.px_kind))
                 continue;
-            if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4
+            if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4 || jobs [j].up_wide != g.rep.up_wide
                                  || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))
                 continue;
             if (g.count == 65535)

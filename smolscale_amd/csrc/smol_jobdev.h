@@ -44,6 +44,7 @@ struct JobDev
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
+    uint8_t up_wide;               /* k_up: premul16 flavour (unassociated in and out, no sRGB) */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
@@ -344,18 +345,23 @@ pow2x_blocks (const JobDev &d)
  * output rows may touch at most UP_NSRC source rows (smol_kernel_up.hip.h):
  * rows r = 0..TR-1 span floor ((TR-1) * step) + 3 source rows at most. */
 constexpr uint32_t UP_NSRC_HOST = 10;
+constexpr uint32_t UP_NSRC_W_HOST = 8;      /* premul16 flavour */
 
 inline bool
 up_setup (JobDev &d)
 {
-    if (d.wide || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR || d.halv_h || d.halv_v)
+    /* of the 128bpp class only premul16 without sRGB (32-bit unassociated in and out) */
+    const bool w16 = d.wide && d.p16 && !d.linear && d.bpp_in == 4 && d.bpp_out == 4;
+
+    if ((d.wide && !w16) || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR || d.halv_h || d.halv_v)
         return false;
     if (d.step_x >= ((uint64_t) 1 << 32) || d.step_y >= ((uint64_t) 1 << 32) || d.step_x == 0 || d.step_y == 0)
         return false;
     if (d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_UP"))
         return false;
 
-    uint64_t tr = (((uint64_t) (UP_NSRC_HOST - 3)) << 32) / d.step_y + 1;
+    d.up_wide = w16;
+    uint64_t tr = (((uint64_t) ((w16 ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
     if (tr > 64)
         tr = 64;
     if (const char *e = getenv ("SMOL_UP_ROWS"))
@@ -382,6 +388,8 @@ up_setup (JobDev &d)
 inline uint32_t
 up_lds_bytes (const JobDev &d)
 {
+    if (d.up_wide)
+        return UP_NSRC_W_HOST * d.span_px * 8u + 1024u + 16u;       /* + the inverse table */
     return UP_NSRC_HOST * d.span_px * 8u + 16u;
 }
 

@@ -254,11 +254,206 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
     }
 }
 
+/* ------------------------------------------------------------------------- *
+ * k_up, premul16 flavour: unassociated -> unassociated without sRGB, the       *
+ * 128bpp-class default for RGBA8 data (smolscale-generic.c:522-560 unpack,    *
+ * :1036-1100 pack). Same organisation; channels are 16 bit (c * a, and        *
+ * (a << 8) | 0x80 for alpha), two per register, taps are 24-bit multiplies:   *
+ *      q + (((p - q) * F) >> 8)  ==  (p * F + q * (256 - F)) >> 8             *
+ * (an integer identity, both sides below 2^24), and an output pixel is        *
+ * un-premultiplied through the inverse table (LDS copy) as it leaves.         *
+ * ------------------------------------------------------------------------- */
+constexpr int OUT_W16 = 3;          /* k_up<IN, OUT_W16>: the premul16 flavour */
+constexpr int UP_NSRC_W = 8;        /* source rows per tile (register budget: 2 words per row and column) */
+
+/* (p * F + q * G) >> 8 on both 16-bit halves of packed channel pairs */
+__device__ __forceinline__ uint32_t up16_tap (uint32_t p, uint32_t q, uint32_t F, uint32_t G)
+{
+    const uint32_t lo = (__umul24 (p & 0xffffu, F) + __umul24 (q & 0xffffu, G)) >> 8;
+    const uint32_t hi = (__umul24 (p >> 16, F) + __umul24 (q >> 16, G)) >> 8;
+    return lo | (hi << 16);
+}
+
+template <int INK>
+__device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
+{
+    constexpr uint32_t TW = TILE_COLS * UP_CPL;
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
+    const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);     /* see up_body */
+    const uint32_t tx = bid % tiles_x;
+    const uint32_t ty = bid / tiles_x;
+    const uint32_t yrel0 = ty * J.tile_rows;
+
+    if (yrel0 >= J.n_rows)
+        return;
+
+    const uint32_t nrows = (yrel0 + J.tile_rows < J.n_rows) ? J.tile_rows : J.n_rows - yrel0;
+    const uint32_t x0 = tx * TW;
+    const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;
+    const uint32_t xl = x0 + lane * UP_CPL;
+
+    uint32_t tap_ofs [UP_CPL], tap_f [UP_CPL];
+#pragma unroll
+    for (int c = 0; c < UP_CPL; c++)
+    {
+        const uint32_t xc = (xl + c < xn) ? xl + c : xn - 1;
+        bilin_tap (J.frac0_x + (uint64_t) xc * J.step_x, J.w_in, tap_ofs [c], tap_f [c]);
+    }
+    const uint32_t sx0 = smol_readlane (tap_ofs [0], 0);
+
+    uint32_t my_oy, my_f;
+    {
+        const uint32_t r = (lane < nrows) ? lane : nrows - 1;
+        bilin_tap (J.frac0_y + (uint64_t) (J.first_row + yrel0 + r) * J.step_y, J.h_in, my_oy, my_f);
+    }
+    const uint32_t oy_first = smol_readlane (my_oy, 0);
+    const uint32_t oy_last = smol_readlane (my_oy, nrows - 1);
+    const uint32_t sched = (my_oy - oy_first) | (my_f << 16);
+    uint32_t n_src = oy_last - oy_first + 2;
+    if (n_src > (uint32_t) UP_NSRC_W)
+        n_src = UP_NSRC_W;                              /* cannot happen: up_setup sizes tile_rows */
+
+    /* ---- stage: every source pixel of the tile once, as two words of 16-bit channels
+     * (R * a | G * a << 16,  B * a | ((a << 8) | 0x80) << 16), 8 bytes per pixel; the
+     * inverse table follows the pixels in LDS ------------------------------------- */
+    const uint32_t span = J.span_px;
+    uint32_t *inv_lut = reinterpret_cast<uint32_t *> (lds + (size_t) UP_NSRC_W * span * 8);
+    {
+        const gbyte *srow0 = gptr (J.src) + (size_t) oy_first * J.src_stride;
+        const uint32_t total = n_src * span;
+        const uint32_t sr = 8u * J.pos_in [0], sg = 8u * J.pos_in [1], sb = 8u * J.pos_in [2], sa = 8u * J.pos_in [3];
+
+        for (uint32_t i0 = 0; i0 < total; i0 += 64u * UP_STAGE_UNROLL)
+        {
+            uint32_t w [UP_STAGE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < UP_STAGE_UNROLL; u++)
+            {
+                const uint32_t i = i0 + (uint32_t) u * 64u + lane;
+                const uint32_t srow = (uint32_t) (((uint64_t) i * J.span_chunks_inv) >> 32);   /* i / span */
+                const uint32_t k = i - srow * span;
+                uint32_t x = sx0 + k;
+                if (x > J.w_in - 1)
+                    x = J.w_in - 1;
+                w [u] = 0;
+                if (i < total)
+                    w [u] = up_load_px<INK> (J, srow0 + (size_t) srow * J.src_stride, x);
+            }
+#pragma unroll
+            for (int u = 0; u < UP_STAGE_UNROLL; u++)
+            {
+                const uint32_t i = i0 + (uint32_t) u * 64u + lane;
+                const uint32_t a = (w [u] >> sa) & 0xffu;
+                const uint32_t rg = __umul24 ((w [u] >> sr) & 0xffu, a) | (__umul24 ((w [u] >> sg) & 0xffu, a) << 16);
+                const uint32_t ba = __umul24 ((w [u] >> sb) & 0xffu, a) | (((a << 8) | 0x80u) << 16);
+                const u32x2a8 pair = { rg, ba };
+                if (i < total)
+                    *reinterpret_cast<u32x2a8 *> (lds + (size_t) i * 8) = pair;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            inv_lut [u * 64 + lane] = smol_inv_p16_lut [u * 64 + lane];
+    }
+    smol_wave_sync ();
+
+    /* ---- H ---------------------------------------------------------------------------- */
+    uint32_t h_rg [UP_NSRC_W][UP_CPL], h_ba [UP_NSRC_W][UP_CPL];
+#pragma unroll
+    for (int s = 0; s < UP_NSRC_W; s++)
+    {
+#pragma unroll
+        for (int c = 0; c < UP_CPL; c++)
+            h_rg [s][c] = h_ba [s][c] = 0;
+        if ((uint32_t) s < n_src)                       /* wave-uniform */
+        {
+#pragma unroll
+            for (int c = 0; c < UP_CPL; c++)
+            {
+                const uint32_t k = (uint32_t) s * span + (tap_ofs [c] - sx0);
+                const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (lds + (size_t) k * 8);
+                const uint32_t F = tap_f [c], G = 256u - F;
+                h_rg [s][c] = up16_tap (pq.x, pq.z, F, G);
+                h_ba [s][c] = up16_tap (pq.y, pq.w, F, G);
+            }
+        }
+    }
+
+    /* ---- V + un-premultiply + store -------------------------------------------------------- */
+    const bool fast = (xn == x0 + TW) && J.out_vec16_ok;
+    const uint32_t dr = 8u * J.pos_out [0], dg = 8u * J.pos_out [1], db = 8u * J.pos_out [2], da = 8u * J.pos_out [3];
+    gbyte *out_row = gptr (J.dst) + (size_t) yrel0 * J.dst_stride;
+    uint32_t r = 0;
+    uint32_t e = smol_readlane (sched, 0);
+
+#pragma unroll
+    for (int s = 0; s + 1 < UP_NSRC_W; s++)
+    {
+        while (r < nrows && (e & 0xffffu) == (uint32_t) s)
+        {
+            const uint32_t F = e >> 16, G = 256u - F;
+            uint32_t o [UP_CPL];
+#pragma unroll
+            for (int c = 0; c < UP_CPL; c++)
+            {
+                const uint32_t rg = up16_tap (h_rg [s][c], h_rg [s + 1][c], F, G);
+                const uint32_t ba = up16_tap (h_ba [s][c], h_ba [s + 1][c], F, G);
+                const uint32_t a = ba >> 24;                    /* (alpha lane >> 8) & 0xff */
+                const uint32_t inv = inv_lut [a];
+                /* (s * inv) >> 16 & 0xff (:1036-1100): s < 2^16, inv <= 2^16, the product fits 32 bits */
+                const uint32_t cr = (__umul24 (rg & 0xffffu, inv) >> 16) & 0xffu;
+                const uint32_t cg = (__umul24 (rg >> 16, inv) >> 16) & 0xffu;
+                const uint32_t cb = (__umul24 (ba & 0xffffu, inv) >> 16) & 0xffu;
+                o [c] = (cr << dr) | (cg << dg) | (cb << db) | (a << da);
+            }
+
+            if (fast)
+            {
+                const u32x4 v = { o [0], o [1], o [2], o [3] };
+                __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (out_row + (size_t) xl * 4));
+            }
+            else
+            {
+#pragma unroll
+                for (int c = 0; c < UP_CPL; c++)
+                {
+                    if (xl + c < xn)
+                    {
+                        gbyte *p = out_row + (size_t) (xl + c) * 4;
+                        if (J.out_dword_ok)
+                        {
+                            *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (p) = o [c];
+                        }
+                        else
+                        {
+                            p [0] = (uint8_t) o [c];
+                            p [1] = (uint8_t) (o [c] >> 8);
+                            p [2] = (uint8_t) (o [c] >> 16);
+                            p [3] = (uint8_t) (o [c] >> 24);
+                        }
+                    }
+                }
+            }
+            out_row += J.dst_stride;
+            r++;
+            if (r < nrows)
+                e = smol_readlane (sched, r);
+        }
+    }
+}
+
 #ifdef SMOL_KERNEL_EMU
 /* host emulation: one entry that switches at run time */
 __global__ void k_up_one (const JobDev J)
 {
     const bool a4 = J.tile_aligned4;
+    if (J.up_wide)
+    {
+        if (a4) up16_body<UP_IN_A4> (J, smol_dyn_lds); else up16_body<UP_IN_ANY> (J, smol_dyn_lds);
+        return;
+    }
     switch (J.tile_variant & 3u)
     {
         case OUT_P4: if (a4) up_body<UP_IN_A4, OUT_P4> (J, smol_dyn_lds); else up_body<UP_IN_ANY, OUT_P4> (J, smol_dyn_lds); break;
@@ -272,14 +467,20 @@ __global__ void __launch_bounds__ (64)
 k_up_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = jobs [blockIdx.y];
-    up_body<INK, OUT> (J, smol_dyn_lds);
+    if (OUT == OUT_W16)
+        up16_body<INK> (J, smol_dyn_lds);
+    else
+        up_body<INK, OUT == OUT_W16 ? OUT_P4 : OUT> (J, smol_dyn_lds);
 }
 
 template <int INK, int OUT>
 __global__ void __launch_bounds__ (64)
 k_up_one (const JobDev J)
 {
-    up_body<INK, OUT> (J, smol_dyn_lds);
+    if (OUT == OUT_W16)
+        up16_body<INK> (J, smol_dyn_lds);
+    else
+        up_body<INK, OUT == OUT_W16 ? OUT_P4 : OUT> (J, smol_dyn_lds);
 }
 #endif
 

@@ -77,8 +77,9 @@ def test_emulated_pow2x_kernel_every_type_pair_and_class():
 
 
 def test_emulated_up_kernel_magnification():
-    """k_up: bilinear magnification on both axes, every 64bpp-class type pair, odd
-    strides, row slabs, tiny sources (2 pixels) and ratios from 1.01x to 9x."""
+    """k_up: bilinear magnification on both axes, every type pair without sRGB (64bpp
+    class and premul16), odd strides, row slabs, tiny sources (2 pixels) and ratios
+    from 1.01x to 9x."""
     rng = random.Random(808)
     hits = 0
     for it in range(140):
@@ -87,8 +88,7 @@ def test_emulated_up_kernel_magnification():
         w_out = rng.randint(w_in + 1, min(w_in * 9, 1300))
         h_out = rng.randint(h_in + 1, min(h_in * 9, 300))
         t_in, t_out = (it // 10) % 10, it % 10
-        if H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0).wide:
-            continue
+        # unassociated -> unassociated is the premul16 flavour of k_up
         sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 3, 4, 16])
         sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4, 16])
         src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
@@ -98,7 +98,7 @@ def test_emulated_up_kernel_magnification():
         got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
         hits += (k == 8)
         assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
-    assert hits >= 80
+    assert hits >= 130
 
 
 def test_emulated_kernels_match_golden_subset():
