@@ -81,6 +81,17 @@ launch_pow2x_h (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_
     }
 }
 
+/* k_down: one entry point per horizontal mode (halvings 0-2 | 3 = four columns per lane) */
+template <int HC>
+void
+launch_down_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_down_batch<HC>), grid, dim3 (64), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_down_one<HC>), grid, dim3 (64), lds, s, rep);
+}
+
 /* k_up: one entry point per (input alignment kind, output kind) */
 template <int INK, int OUT>
 void
@@ -193,6 +204,24 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
             case 1: launch_pow2x_h<1> (jobs_dev, rep, grid, s); break;
             default: launch_pow2x_h<2> (jobs_dev, rep, grid, s); break;
         }
+        return hipGetLastError ();
+    }
+
+    if (k == KC_DOWN)
+    {
+        /* groups share the horizontal mode; max_lds carries the
+         * largest block count, max_w_out (batches only) the largest LDS size */
+        dim3 grid (max_lds ? max_lds : down_blocks (rep), n_jobs);
+        const uint32_t lds = jobs_dev ? max_w_out : down_lds_bytes (rep);
+
+        if (rep.tile_cpl == 4)
+            launch_down_k<3> (jobs_dev, rep, grid, lds, s);
+        else if (rep.halv_h == 0)
+            launch_down_k<0> (jobs_dev, rep, grid, lds, s);
+        else if (rep.halv_h == 1)
+            launch_down_k<1> (jobs_dev, rep, grid, lds, s);
+        else
+            launch_down_k<2> (jobs_dev, rep, grid, lds, s);
         return hipGetLastError ();
     }
 
@@ -531,6 +560,8 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2X && (jobs [j].halv_h != g.rep.halv_h || jobs [j].px_kind != g.rep.px_kind))
                 continue;
+            if (g.k == KC_DOWN && (jobs [j].halv_h != g.rep.halv_h || jobs [j].tile_cpl != g.rep.tile_cpl))
+                continue;
             if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4 || jobs [j].up_wide != g.rep.up_wide
                                  || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))
                 continue;
@@ -543,11 +574,16 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             {
                 if (up_lds_bytes (jobs [j]) > g.max_w_out) g.max_w_out = up_lds_bytes (jobs [j]);
             }
+            else if (g.k == KC_DOWN)
+            {
+                if (down_lds_bytes (jobs [j]) > g.max_w_out) g.max_w_out = down_lds_bytes (jobs [j]);
+            }
             else if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
             if (jobs [j].n_rows > g.max_rows) g.max_rows = jobs [j].n_rows;
             if ((g.k == KC_TILE || g.k == KC_WTILE) && tile_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = tile_lds_bytes (jobs [j]);
             if (g.k == KC_POW2X && pow2x_blocks (jobs [j]) > g.max_lds) g.max_lds = pow2x_blocks (jobs [j]);
             if (g.k == KC_UP && up_blocks (jobs [j]) > g.max_lds) g.max_lds = up_blocks (jobs [j]);
+            if (g.k == KC_DOWN && down_blocks (jobs [j]) > g.max_lds) g.max_lds = down_blocks (jobs [j]);
             units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
         }
 

@@ -66,7 +66,7 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_UP, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_UP, KC_DOWN, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -400,6 +400,59 @@ up_blocks (const JobDev &d)
     return (n + 7u) & ~7u;
 }
 
+/* k_down: bilinear minification on both axes (0-2 halvings) for premul16 without
+ * sRGB (32-bit unassociated in and out) on 4-byte aligned rows. */
+inline bool
+down_setup (JobDev &d)
+{
+    const bool w16 = d.wide && d.p16 && !d.linear && d.bpp_in == 4 && d.bpp_out == 4;
+
+    if (!w16 || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR)
+        return false;
+    if (d.step_x < ((uint64_t) 1 << 32) || d.step_y < ((uint64_t) 1 << 32))
+        return false;
+    if (((((uintptr_t) d.src) | d.src_stride) & 3) || d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_DOWN"))
+        return false;
+
+    /* one sample per column and a wide enough image: 4 columns per lane */
+    const uint32_t cpl = (d.halv_h == 0 && d.w_out >= 256 && !getenv ("SMOL_DOWN_CPL1")) ? 4 : 1;
+
+    /* source pixels a tile can reach, rounded up to whole 4-pixel chunks */
+    uint64_t span = ((((uint64_t) (64u * cpl) << d.halv_h) * d.step_x) >> 32) + 3;
+    if (span > d.w_in)
+        span = d.w_in;
+    span = (span + 3 + 4) & ~(uint64_t) 3;
+    if (span > 64u * 4u * 3u)
+        return false;                           /* more than DOWN_NL loads per lane and row */
+    d.span_px = (uint32_t) span;
+
+    uint32_t th = 16u >> d.halv_v;              /* <= 128 vertical samples per tile */
+    if (const char *e = getenv ("SMOL_DOWN_ROWS"))
+        th = (uint32_t) atoi (e);
+    if (th > (128u >> d.halv_v))
+        th = 128u >> d.halv_v;
+    if (th < 1)
+        th = 1;
+    d.tile_rows = (uint16_t) th;
+    d.tile_cpl = (uint8_t) cpl;
+    d.up_wide = 1;
+    return true;
+}
+
+inline uint32_t
+down_blocks (const JobDev &d)
+{
+    const uint32_t tw = 64u * d.tile_cpl;
+    return ((d.w_out + tw - 1u) / tw) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
+}
+
+inline uint32_t
+down_lds_bytes (const JobDev &d)
+{
+    const uint32_t pitch = (d.span_px * 8u + 15u) & ~15u;
+    return 2u * pitch + 1024u + 16u;          /* two row buffers + the inverse table */
+}
+
 inline KClass
 classify (JobDev &d)
 {
@@ -409,6 +462,8 @@ classify (JobDev &d)
         return KC_POW2X;
     if (up_setup (d))
         return KC_UP;
+    if (down_setup (d))
+        return KC_DOWN;
     if (tile_ok (d))
         return KC_TILE;
     if (wtile_ok (d))
@@ -428,6 +483,7 @@ kclass_name (KClass k, const JobDev &d)
         case KC_POW2: return "k_pow2_batch";
         case KC_POW2X: return "k_pow2x_batch";
         case KC_UP: return "k_up_batch";
+        case KC_DOWN: return "k_down_batch";
         case KC_TILE: return "k_tile_batch";
         case KC_WTILE: return "k_wtile_batch";
         case KC_WAVEPX: return "k_wavepx_batch<false>";

@@ -1,0 +1,329 @@
+/* smol_kernel_down.hip.h -- k_down: bilinear MINIFICATION on both axes (0-2
+ * halvings each) for the premul16 class without sRGB -- unassociated in AND out,
+ * the 128bpp-class default for RGBA8 data (smolscale-generic.c:522-560 unpack,
+ * :1036-1100 pack) -- on 4-byte aligned rows. Included at the end of
+ * smol_kernels.hip.h. (The same structure was tried for the 64bpp class and lost
+ * to k_tile by 10-40 %: DESIGN.md section 4.)
+ *
+ * One wave owns 64 (or, without horizontal halvings, 256) output columns x tile_rows
+ * output rows; a lane owns one column (or 4 adjacent ones: 16-byte stores).
+ *
+ *   stage  source rows stream through in order. Row r+1 is loaded (16-byte loads
+ *          of 4 pixels, straight from the 4-byte aligned pixel addresses) while
+ *          row r is filtered; on arrival each pixel is expanded ONCE to four 16-bit
+ *          channels c*a, (a<<8)|0x80 and written to one of two LDS row buffers
+ *          (8 bytes per pixel).
+ *   H      a lane reads the pixel pair of each of its 2^HX samples with one 16-byte
+ *          LDS read and blends it (:1290-1425);
+ *   V      the vertical filter runs in registers per column against the previous
+ *          row's result (:1648-2007), following a schedule the lanes computed once
+ *          (read back with v_readlane); an output pixel is un-premultiplied through
+ *          the inverse table (LDS copy) and leaves as soon as its last row has passed.
+ *
+ * Values are 16 bit, two per register, taps are 24-bit multiplies:
+ *      q + (((p - q) * F) >> 8)  ==  (p * F + q * (256 - F)) >> 8
+ * (an integer identity, both sides below 2^24). */
+
+#pragma once
+
+namespace smolhip {
+
+constexpr int DOWN_NL = 3;          /* 16-byte loads per lane per source row, at most (span <= 768 pixels) */
+
+typedef uint32_t u32x4a4 __attribute__ ((ext_vector_type (4), aligned (4)));
+
+template <int HX, int CPL>
+__device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
+{
+    constexpr uint32_t NSX = 1u << HX;
+    constexpr uint32_t TW = TILE_COLS * CPL;            /* output columns per tile */
+    constexpr uint32_t PXB = 8u;                        /* LDS bytes per staged pixel */
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
+    const uint32_t tx = blockIdx.x % tiles_x;
+    const uint32_t ty = blockIdx.x / tiles_x;
+    const uint32_t yrel0 = ty * J.tile_rows;
+
+    if (yrel0 >= J.n_rows)
+        return;
+
+    const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
+    const uint32_t x0 = tx * TW;
+    const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;
+    const uint32_t xl = x0 + lane * CPL;                            /* this lane's first column */
+
+    /* ---- horizontal samples of this lane's columns ------------------------------ */
+    uint32_t tap_ofs [CPL][NSX], tap_f [CPL][NSX];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+    {
+        const uint32_t xc = (xl + c < xn) ? xl + c : xn - 1;
+        uint64_t pos = J.frac0_x + (uint64_t) (xc << HX) * J.step_x;
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+        {
+            bilin_tap (pos, J.w_in, tap_ofs [c][s], tap_f [c][s]);
+            pos += J.step_x;
+        }
+    }
+    const uint32_t sx0 = smol_readlane (tap_ofs [0][0], 0);         /* first source pixel of the tile */
+    uint32_t sx1, f_unused;
+    bilin_tap (J.frac0_x + (uint64_t) ((xn << HX) - 1) * J.step_x, J.w_in, sx1, f_unused);
+    sx1 += 1;                                                       /* last source pixel of the tile  */
+    const uint32_t nch = (sx1 - sx0 + 4) >> 2;                      /* 4-pixel chunks per staged row  */
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+            tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * PXB;          /* byte offset in the LDS row     */
+
+    /* ---- vertical schedule (as in k_tile): sample k of the tile in lane k & 63 of sched [k >> 6] */
+    const uint32_t hv = J.halv_v;
+    const uint32_t nsy = 1u << hv;
+    const uint32_t jy0 = (J.first_row + yrel0) << hv;
+    const uint32_t n_samples = (yrel1 - yrel0) << hv;               /* <= 128 (down_setup) */
+    uint32_t sched [2];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++)
+    {
+        uint32_t k = q * 64u + lane;
+        if (k >= n_samples)
+            k = n_samples - 1;
+        uint32_t o, f;
+        bilin_tap (J.frac0_y + (uint64_t) (jy0 + k) * J.step_y, J.h_in, o, f);
+        sched [q] = o | (f << 16);
+    }
+    uint32_t e = smol_readlane (sched [0], 0);
+    uint32_t oy = e & 0xffffu, Fy = e >> 16;
+    const uint32_t row_first = oy;
+    const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
+    const uint32_t row_last = (e_last & 0xffffu) + 1;
+
+    /* ---- staging ---------------------------------------------------------------------------- */
+    const uint32_t buf_pitch = (J.span_px * PXB + 15u) & ~15u;      /* one LDS row buffer (host bound on the span) */
+    uint32_t *inv_lut = reinterpret_cast<uint32_t *> (lds + 2 * (size_t) buf_pitch);
+    const uint32_t sr = 8u * J.pos_in [0], sg = 8u * J.pos_in [1], sb = 8u * J.pos_in [2], sa = 8u * J.pos_in [3];
+    const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;   /* row being loaded */
+
+    u32x4 raw [DOWN_NL];
+
+    auto load_row = [&] ()
+    {
+#pragma unroll
+        for (int l = 0; l < DOWN_NL; l++)
+        {
+            const uint32_t c = (uint32_t) l * 64u + lane;
+            raw [l] = u32x4 { 0, 0, 0, 0 };
+            if ((uint32_t) l * 64u < nch && c < nch)                /* first test is wave-uniform */
+            {
+                const uint32_t k = sx0 + 4u * c;
+                if (k + 3u <= J.w_in - 1u)
+                {
+                    raw [l] = *reinterpret_cast<const SMOL_AS_GLOBAL u32x4a4 *> (srow + (size_t) k * 4);
+                }
+                else
+                {
+                    /* the row's last pixels: never read past the end of the row */
+                    const SMOL_AS_GLOBAL uint32_t *px = reinterpret_cast<const SMOL_AS_GLOBAL uint32_t *> (srow);
+                    const uint32_t last = J.w_in - 1u;
+                    raw [l].x = px [k < last ? k : last];
+                    raw [l].y = px [k + 1u < last ? k + 1u : last];
+                    raw [l].z = px [k + 2u < last ? k + 2u : last];
+                    raw [l].w = px [last];
+                }
+            }
+        }
+        srow += J.src_stride;
+    };
+
+    auto convert_row = [&] (uint8_t *buf)
+    {
+#pragma unroll
+        for (int l = 0; l < DOWN_NL; l++)
+        {
+            const uint32_t c = (uint32_t) l * 64u + lane;
+            if ((uint32_t) l * 64u < nch && c < nch)
+            {
+                const uint32_t w [4] = { raw [l].x, raw [l].y, raw [l].z, raw [l].w };
+                uint32_t o [8];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const uint32_t a = (w [i] >> sa) & 0xffu;
+                    o [2 * i] = __umul24 ((w [i] >> sr) & 0xffu, a) | (__umul24 ((w [i] >> sg) & 0xffu, a) << 16);
+                    o [2 * i + 1] = __umul24 ((w [i] >> sb) & 0xffu, a) | (((a << 8) | 0x80u) << 16);
+                }
+                u32x4 *d = reinterpret_cast<u32x4 *> (buf + (size_t) c * 32);
+                d [0] = u32x4 { o [0], o [1], o [2], o [3] };
+                d [1] = u32x4 { o [4], o [5], o [6], o [7] };
+            }
+        }
+    };
+
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        inv_lut [u * 64 + lane] = smol_inv_p16_lut [u * 64 + lane];
+
+    /* ---- the row loop --------------------------------------------------------------------- */
+    const uint32_t dr = 8u * J.pos_out [0], dg = 8u * J.pos_out [1], db = 8u * J.pos_out [2], da = 8u * J.pos_out [3];
+    const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
+    gbyte *out_row = gptr (J.dst) + (size_t) yrel0 * J.dst_stride;
+    uint32_t ks = 0, s_y = 0;
+    /* previous row's horizontal result (two packed channel pairs) and the vertical sums */
+    uint32_t hp0 [CPL], hp1 [CPL], acc [CPL][4];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+    {
+        hp0 [c] = hp1 [c] = 0;
+        acc [c][0] = acc [c][1] = acc [c][2] = acc [c][3] = 0;
+    }
+
+    load_row ();
+    convert_row (lds);
+    smol_wave_sync ();
+
+    for (uint32_t r = row_first; r <= row_last; r++)
+    {
+        const uint32_t cur = (r - row_first) & 1u;
+        const uint8_t *buf = lds + cur * buf_pitch;
+
+        if (r < row_last)
+            load_row ();                                /* row r + 1 flies while row r is filtered */
+
+        /* ---- H ---------------------------------------------------------------------------- */
+        uint32_t h0 [CPL], h1 [CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+        {
+            uint32_t hs [4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (uint32_t s = 0; s < NSX; s++)
+            {
+                const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (buf + tap_ofs [c][s]);
+                const uint32_t F = tap_f [c][s], G = 256u - F;
+                hs [0] += (__umul24 (pq.x & 0xffffu, F) + __umul24 (pq.z & 0xffffu, G)) >> 8;
+                hs [1] += (__umul24 (pq.x >> 16, F) + __umul24 (pq.z >> 16, G)) >> 8;
+                hs [2] += (__umul24 (pq.y & 0xffffu, F) + __umul24 (pq.w & 0xffffu, G)) >> 8;
+                hs [3] += (__umul24 (pq.y >> 16, F) + __umul24 (pq.w >> 16, G)) >> 8;
+            }
+            h0 [c] = (hs [0] >> HX) | ((hs [1] >> HX) << 16);
+            h1 [c] = (hs [2] >> HX) | ((hs [3] >> HX) << 16);
+        }
+
+        /* ---- V: every sample whose bottom row is r ----------------------------------------- */
+        while (ks < n_samples && oy + 1u == r)
+        {
+            const uint32_t G = 256u - Fy;
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+            {
+                const uint32_t t0 = (__umul24 (hp0 [c] & 0xffffu, Fy) + __umul24 (h0 [c] & 0xffffu, G)) >> 8;
+                const uint32_t t1 = (__umul24 (hp0 [c] >> 16, Fy) + __umul24 (h0 [c] >> 16, G)) >> 8;
+                const uint32_t t2 = (__umul24 (hp1 [c] & 0xffffu, Fy) + __umul24 (h1 [c] & 0xffffu, G)) >> 8;
+                const uint32_t t3 = (__umul24 (hp1 [c] >> 16, Fy) + __umul24 (h1 [c] >> 16, G)) >> 8;
+                acc [c][0] = s_y ? acc [c][0] + t0 : t0;
+                acc [c][1] = s_y ? acc [c][1] + t1 : t1;
+                acc [c][2] = s_y ? acc [c][2] + t2 : t2;
+                acc [c][3] = s_y ? acc [c][3] + t3 : t3;
+            }
+            s_y++;
+            ks++;
+            if (s_y == nsy)
+            {
+                uint32_t w [CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                {
+                    const uint32_t a = ((acc [c][3] >> hv) >> 8) & 0xffu;
+                    const uint32_t inv = inv_lut [a];
+                    /* (s * inv) >> 16 & 0xff (:1036-1100): s < 2^16, inv <= 2^16, the product fits 32 bits */
+                    const uint32_t cr = (__umul24 ((acc [c][0] >> hv) & 0xffffu, inv) >> 16) & 0xffu;
+                    const uint32_t cg = (__umul24 ((acc [c][1] >> hv) & 0xffffu, inv) >> 16) & 0xffu;
+                    const uint32_t cb = (__umul24 ((acc [c][2] >> hv) & 0xffffu, inv) >> 16) & 0xffu;
+                    w [c] = (cr << dr) | (cg << dg) | (cb << db) | (a << da);
+                }
+                if (CPL == 4 && interior)
+                {
+                    const u32x4 v = { w [0], w [1 % CPL], w [2 % CPL], w [3 % CPL] };
+                    __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (out_row + (size_t) xl * 4));
+                }
+                else
+                {
+#pragma unroll
+                    for (int c = 0; c < CPL; c++)
+                    {
+                        if (xl + c < xn)
+                        {
+                            gbyte *p = out_row + (size_t) (xl + c) * 4;
+                            if (J.out_dword_ok)
+                                __builtin_nontemporal_store (w [c], reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (p));
+                            else
+                            {
+                                p [0] = (uint8_t) w [c]; p [1] = (uint8_t) (w [c] >> 8);
+                                p [2] = (uint8_t) (w [c] >> 16); p [3] = (uint8_t) (w [c] >> 24);
+                            }
+                        }
+                    }
+                }
+                s_y = 0;
+                out_row += J.dst_stride;
+            }
+            if (ks < n_samples)
+            {
+                e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
+                oy = e & 0xffffu;
+                Fy = e >> 16;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+        {
+            hp0 [c] = h0 [c];
+            hp1 [c] = h1 [c];
+        }
+
+        /* ---- park row r + 1 in the other buffer (its taps are read next iteration) ---------- */
+        if (r < row_last)
+        {
+            convert_row (lds + (cur ^ 1u) * buf_pitch);
+            smol_wave_sync ();
+        }
+    }
+}
+
+#ifdef SMOL_KERNEL_EMU
+/* host emulation: one entry that switches at run time */
+__global__ void k_down_one (const JobDev J)
+{
+    if (J.tile_cpl == 4)
+    {
+        down_body<0, 4> (J, smol_dyn_lds);
+        return;
+    }
+    switch (J.halv_h)
+    {
+        case 0: down_body<0, 1> (J, smol_dyn_lds); break;
+        case 1: down_body<1, 1> (J, smol_dyn_lds); break;
+        default: down_body<2, 1> (J, smol_dyn_lds); break;
+    }
+}
+#else
+/* HC: horizontal halvings 0-2 with one column per lane, or 3 = no halvings, 4 columns per lane */
+template <int HC>
+__global__ void __launch_bounds__ (64)
+k_down_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = jobs [blockIdx.y];
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1> (J, smol_dyn_lds);
+}
+
+template <int HC>
+__global__ void __launch_bounds__ (64)
+k_down_one (const JobDev J)
+{
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1> (J, smol_dyn_lds);
+}
+#endif
+
+} /* namespace smolhip */

@@ -20,6 +20,8 @@
  *                     and for the 128bpp class (smol_kernel_pow2x.hip.h).
  *   k_up<IN,OUT>      bilinear magnification on both axes, organised around the
  *                     stores (smol_kernel_up.hip.h).
+ *   k_down<W16,HX>    bilinear minification on both axes for 32-bit pixels on aligned
+ *                     rows, 64bpp class and premul16 (smol_kernel_down.hip.h).
  *   k_tile / k_wtile  LDS-tiled kernels for arbitrary ratios (smol_kernel_tile.hip.h,
  *                     smol_kernel_wtile.hip.h).
  */
@@ -810,3 +812,4 @@ k_pow2_one (const JobDev J)
 #include "smol_kernel_wtile.hip.h"
 #include "smol_kernel_pow2x.hip.h"
 #include "smol_kernel_up.hip.h"
+#include "smol_kernel_down.hip.h"

@@ -101,7 +101,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
     JobDev J;
     fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
     KClass k = classify (J);
-    if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_UP || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
+    if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_UP || k == KC_DOWN || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
     if (force_general == 2 && tile_ok (J))
         k = KC_TILE;                      /* force the tiled kernel where the fast path would win */
@@ -132,6 +132,12 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
             case 1: run_pow2x_h<1> (J, gx); break;
             default: run_pow2x_h<2> (J, gx); break;
         }
+        return 0;
+    }
+
+    if (k == KC_DOWN)
+    {
+        run_grid_coop (down_blocks (J), 64, down_lds_bytes (J), [&] { k_down_one (J); });
         return 0;
     }
 

@@ -101,6 +101,31 @@ def test_emulated_up_kernel_magnification():
     assert hits >= 130
 
 
+def test_emulated_down_kernel_premul16_minification():
+    """k_down: unassociated -> unassociated (premul16) bilinear minification, ratios
+    1..8 per axis (0-2 halvings), 1 and 4 columns per lane, row slabs, padded strides."""
+    rng = random.Random(4242)
+    hits = 0
+    for it in range(90):
+        w_out = rng.choice([1, 2, 3, 7, 40, 64, 65, 130, 256, 300, 515])
+        h_out = rng.choice([1, 2, 5, 17, 33])
+        w_in = max(2, min(int(w_out * rng.uniform(1.01, 7.99)) + rng.randint(0, 1), 8 * w_out - 1))
+        h_in = max(2, min(int(h_out * rng.uniform(1.01, 7.99)) + rng.randint(0, 1), 8 * h_out - 1))
+        if w_in <= w_out or h_in <= h_out:
+            continue
+        t_in, t_out = rng.choice([4, 5, 6, 7]), rng.choice([4, 5, 6, 7])
+        sin = w_in * 4 + rng.choice([0, 0, 4, 16, 12])
+        sout = w_out * 4 + rng.choice([0, 0, 1, 4, 16])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=False, stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        hits += (k == 9)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
+    assert hits >= 60
+
+
 def test_emulated_kernels_match_golden_subset():
     for (t_in, w_in, h_in, t_out, w_out, h_out, srgb, seed, valid), want in C.matrix_cases(stride=23):
         src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)

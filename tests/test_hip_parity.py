@@ -129,6 +129,26 @@ def test_up_kernel_magnification_shapes():
             assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
 
 
+def test_down_kernel_premul16_minification_shapes():
+    """k_down: unassociated -> unassociated minification at arbitrary ratios (0-2 halvings
+    per axis, 1 and 4 columns per lane), host pointers and misaligned device buffers."""
+    shapes = [
+        (4, 4096, 300, 4, 2731, 200), (5, 1000, 700, 6, 333, 100), (7, 2000, 64, 4, 260, 9),
+        (4, 515, 129, 5, 256, 65), (6, 4000, 33, 7, 1600, 11), (4, 799, 601, 4, 100, 99),
+        (5, 64, 4000, 5, 9, 501), (4, 3, 3, 4, 2, 2),
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out) in enumerate(shapes):
+        for (sin_pad, mis) in ((0, 0), (4, 4), (16, 1)):
+            sin = w_in * 4 + sin_pad
+            src = H.make_input(t_in, w_in, h_in, seed=k, valid=False, stride=sin, pad=0)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "host", sin_pad)
+            got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin,
+                                     src_misalign=mis, dst_misalign=mis)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
+
+
 def test_tile_kernel_wide_images_and_box_shapes():
     """Geometries that select every k_tile layout: 4 columns per lane (wide, few taps),
     one column per lane, box with 1 and with 8 lanes per column, box on one axis only."""
