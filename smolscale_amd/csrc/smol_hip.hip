@@ -92,6 +92,29 @@ launch_down_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
         hipLaunchKernelGGL ((smolhip::k_down_one<HC>), grid, dim3 (64), lds, s, rep);
 }
 
+/* table-driven k_down flavours: one entry point per (horizontal halvings, mode) */
+template <int HX, int MODE>
+void
+launch_downg_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_downg_batch<HX, MODE>), grid, dim3 (256), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_downg_one<HX, MODE>), grid, dim3 (256), lds, s, rep);
+}
+
+template <int MODE>
+void
+launch_downg_m (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (rep.halv_h)
+    {
+        case 0:  launch_downg_k<0, MODE> (jobs_dev, rep, grid, lds, s); break;
+        case 1:  launch_downg_k<1, MODE> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_downg_k<2, MODE> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
 /* k_up: one entry point per (input alignment kind, output kind) */
 template <int INK, int OUT>
 void
@@ -214,6 +237,15 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         dim3 grid (max_lds ? max_lds : down_blocks (rep), n_jobs);
         const uint32_t lds = jobs_dev ? max_w_out : down_lds_bytes (rep);
 
+        if (rep.down_mode)
+        {
+            grid.x = (grid.x + 3) / 4;          /* 4 waves = 4 tiles per workgroup */
+            if (rep.down_mode == 2)
+                launch_downg_m<smolhip::DOWN_GEN32> (jobs_dev, rep, grid, lds, s);
+            else
+                launch_downg_m<smolhip::DOWN_GEN16> (jobs_dev, rep, grid, lds, s);
+            return hipGetLastError ();
+        }
         if (rep.tile_cpl == 4)
             launch_down_k<3> (jobs_dev, rep, grid, lds, s);
         else if (rep.halv_h == 0)
@@ -560,7 +592,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_POW2X && (jobs [j].halv_h != g.rep.halv_h || jobs [j].px_kind != g.rep.px_kind))
                 continue;
-            if (g.k == KC_DOWN && (jobs [j].halv_h != g.rep.halv_h || jobs [j].tile_cpl != g.rep.tile_cpl))
+            if (g.k == KC_DOWN && (jobs [j].halv_h != g.rep.halv_h || jobs [j].tile_cpl != g.rep.tile_cpl || jobs [j].down_mode != g.rep.down_mode))
                 continue;
             if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4 || jobs [j].up_wide != g.rep.up_wide
                                  || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))

@@ -45,6 +45,7 @@ struct JobDev
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
     uint8_t up_wide;               /* k_up: premul16 flavour (unassociated in and out, no sRGB) */
+    uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
@@ -400,22 +401,36 @@ up_blocks (const JobDev &d)
     return (n + 7u) & ~7u;
 }
 
-/* k_down: bilinear minification on both axes (0-2 halvings) for premul16 without
- * sRGB (32-bit unassociated in and out) on 4-byte aligned rows. */
+/* k_down: bilinear minification on both axes (0-2 halvings) for the 128bpp class.
+ * Mode 0: premul16 without sRGB on 4-byte aligned 32-bit rows (table-free unpack);
+ * mode 1: any other job whose channels fit 16 bits (sRGB-linear with 8-bit alpha);
+ * mode 2: premul16 + sRGB-linear (19-bit channels). Modes 1-2 take any input type
+ * and alignment and run 4 waves per workgroup around one LDS copy of the tables. */
+constexpr uint32_t DOWN_LUT_BYTES = (4 * 1024 + 512 + 2048 + 15) & ~15u;
+
 inline bool
 down_setup (JobDev &d)
 {
-    const bool w16 = d.wide && d.p16 && !d.linear && d.bpp_in == 4 && d.bpp_out == 4;
-
-    if (!w16 || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR)
+    if (!d.wide || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR)
         return false;
     if (d.step_x < ((uint64_t) 1 << 32) || d.step_y < ((uint64_t) 1 << 32))
         return false;
-    if (((((uintptr_t) d.src) | d.src_stride) & 3) || d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_DOWN"))
+    if (d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_DOWN"))
         return false;
 
-    /* one sample per column and a wide enough image: 4 columns per lane */
-    const uint32_t cpl = (d.halv_h == 0 && d.w_out >= 256 && !getenv ("SMOL_DOWN_CPL1")) ? 4 : 1;
+    const bool aligned32 = d.bpp_in == 4 && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0;
+    uint32_t mode;
+    if (d.p16 && !d.linear && aligned32)
+        mode = 0;
+    else if (d.p16 && d.linear)
+        mode = 2;
+    else
+        mode = 1;
+    if (mode && getenv ("SMOL_NO_DOWN_GEN"))
+        return false;
+
+    /* one sample per column and a wide enough image: 4 columns per lane (mode 0 only) */
+    const uint32_t cpl = (mode == 0 && d.halv_h == 0 && d.w_out >= 256 && !getenv ("SMOL_DOWN_CPL1")) ? 4 : 1;
 
     /* source pixels a tile can reach, rounded up to whole 4-pixel chunks */
     uint64_t span = ((((uint64_t) (64u * cpl) << d.halv_h) * d.step_x) >> 32) + 3;
@@ -436,9 +451,11 @@ down_setup (JobDev &d)
     d.tile_rows = (uint16_t) th;
     d.tile_cpl = (uint8_t) cpl;
     d.up_wide = 1;
+    d.down_mode = (uint8_t) mode;
     return true;
 }
 
+/* tiles of the job (modes 1-2 launch one workgroup per 4 tiles) */
 inline uint32_t
 down_blocks (const JobDev &d)
 {
@@ -449,8 +466,10 @@ down_blocks (const JobDev &d)
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
-    const uint32_t pitch = (d.span_px * 8u + 15u) & ~15u;
-    return 2u * pitch + 1024u + 16u;          /* two row buffers + the inverse table */
+    const uint32_t pitch = (d.span_px * (d.down_mode == 2 ? 16u : 8u) + 15u) & ~15u;
+    if (d.down_mode)
+        return DOWN_LUT_BYTES + 4u * 2u * pitch + 16u;      /* the tables + two row buffers per wave */
+    return 2u * pitch + 1024u + 16u;                        /* two row buffers + the inverse table */
 }
 
 inline KClass

@@ -8,11 +8,10 @@
  * One wave owns 64 (or, without horizontal halvings, 256) output columns x tile_rows
  * output rows; a lane owns one column (or 4 adjacent ones: 16-byte stores).
  *
- *   stage  source rows stream through in order. Row r+1 is loaded (16-byte loads
- *          of 4 pixels, straight from the 4-byte aligned pixel addresses) while
- *          row r is filtered; on arrival each pixel is expanded ONCE to four 16-bit
- *          channels c*a, (a<<8)|0x80 and written to one of two LDS row buffers
- *          (8 bytes per pixel).
+ *   stage  source rows stream through in order. Row r+1 is loaded while row r is
+ *          filtered; on arrival each pixel is converted ONCE to its internal
+ *          channels and written to one of two LDS row buffers (8 or 16 bytes per
+ *          pixel).
  *   H      a lane reads the pixel pair of each of its 2^HX samples with one 16-byte
  *          LDS read and blends it (:1290-1425);
  *   V      the vertical filter runs in registers per column against the previous
@@ -32,17 +31,26 @@ constexpr int DOWN_NL = 3;          /* 16-byte loads per lane per source row, at
 
 typedef uint32_t u32x4a4 __attribute__ ((ext_vector_type (4), aligned (4)));
 
-template <int HX, int CPL>
-__device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
+/* MODE: how a pixel is converted and kept
+ *   DOWN_P16   premul16 without sRGB on aligned 32-bit rows: table-free unpack, 16-bit channel pairs
+ *   DOWN_GEN16 any other 128bpp-class job whose channels fit 16 bits (sRGB-linear with 8-bit alpha:
+ *              11-bit values), any input type / alignment: unpack_word<true> / store_px<true>
+ *   DOWN_GEN32 premul16 + sRGB-linear (19-bit values): four 32-bit channels per pixel */
+enum : int { DOWN_P16 = 0, DOWN_GEN16 = 1, DOWN_GEN32 = 2 };
+
+template <int HX, int CPL, int MODE>
+__device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const uint8_t *lut_lds,
+                                           const uint32_t lane, const uint32_t tile)
 {
     constexpr uint32_t NSX = 1u << HX;
     constexpr uint32_t TW = TILE_COLS * CPL;            /* output columns per tile */
-    constexpr uint32_t PXB = 8u;                        /* LDS bytes per staged pixel */
+    constexpr uint32_t PXB = (MODE == DOWN_GEN32) ? 16u : 8u;      /* LDS bytes per staged pixel */
+    constexpr bool GEN = (MODE != DOWN_P16);
+    static_assert (!GEN || CPL == 1, "the table-driven flavours take one column per lane");
 
-    const uint32_t lane = threadIdx.x;
     const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
-    const uint32_t tx = blockIdx.x % tiles_x;
-    const uint32_t ty = blockIdx.x / tiles_x;
+    const uint32_t tx = tile % tiles_x;
+    const uint32_t ty = tile / tiles_x;
     const uint32_t yrel0 = ty * J.tile_rows;
 
     if (yrel0 >= J.n_rows)
@@ -102,14 +110,39 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
 
     /* ---- staging ---------------------------------------------------------------------------- */
     const uint32_t buf_pitch = (J.span_px * PXB + 15u) & ~15u;      /* one LDS row buffer (host bound on the span) */
-    uint32_t *inv_lut = reinterpret_cast<uint32_t *> (lds + 2 * (size_t) buf_pitch);
+    uint32_t *inv_lut = reinterpret_cast<uint32_t *> (lds + 2 * (size_t) buf_pitch);       /* DOWN_P16 only */
+    const LutLds lut (lut_lds);                                                            /* table-driven flavours */
     const uint32_t sr = 8u * J.pos_in [0], sg = 8u * J.pos_in [1], sb = 8u * J.pos_in [2], sa = 8u * J.pos_in [3];
     const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;   /* row being loaded */
 
-    u32x4 raw [DOWN_NL];
+    /* DOWN_P16 moves 4-pixel chunks (16-byte loads, cheap conversion); the table-driven
+     * flavours spread single pixels over all 64 lanes, because their conversion is the
+     * expensive part and a short span would otherwise keep most lanes idle */
+    constexpr int NRAW = GEN ? (2 << HX) + 1 : DOWN_NL;          /* a 64-column tile spans < 64 * 2^(HX+1) + 3 pixels */
+    const uint32_t npx = sx1 - sx0 + 1;                             /* pixels per staged row */
+    u32x4 raw [GEN ? 1 : DOWN_NL];
+    uint32_t rawpx [GEN ? (2 << HX) + 1 : 1];
 
     auto load_row = [&] ()
     {
+        if (GEN)
+        {
+#pragma unroll
+            for (int l = 0; l < NRAW; l++)
+            {
+                const uint32_t i = (uint32_t) l * 64u + lane;
+                rawpx [l] = 0;
+                if ((uint32_t) l * 64u < npx && i < npx)            /* first test is wave-uniform */
+                {
+                    if (J.in_dword_ok)
+                        rawpx [l] = *reinterpret_cast<const SMOL_AS_GLOBAL uint32_t *> (srow + (size_t) (sx0 + i) * 4);
+                    else
+                        rawpx [l] = up_load_px<UP_IN_ANY> (J, srow, sx0 + i);
+                }
+            }
+            srow += J.src_stride;
+            return;
+        }
 #pragma unroll
         for (int l = 0; l < DOWN_NL; l++)
         {
@@ -139,6 +172,24 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
 
     auto convert_row = [&] (uint8_t *buf)
     {
+        if (GEN)
+        {
+#pragma unroll
+            for (int l = 0; l < NRAW; l++)
+            {
+                const uint32_t i = (uint32_t) l * 64u + lane;
+                if ((uint32_t) l * 64u < npx && i < npx)
+                {
+                    uint32_t ch [4];
+                    unpack_word<true> (J, rawpx [l], ch, lut);
+                    if (MODE == DOWN_GEN32)
+                        *reinterpret_cast<u32x4 *> (buf + (size_t) i * 16) = u32x4 { ch [0], ch [1], ch [2], ch [3] };
+                    else
+                        *reinterpret_cast<u32x2a8 *> (buf + (size_t) i * 8) = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int l = 0; l < DOWN_NL; l++)
         {
@@ -161,17 +212,21 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
         }
     };
 
+    if (!GEN)
+    {
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-        inv_lut [u * 64 + lane] = smol_inv_p16_lut [u * 64 + lane];
+        for (int u = 0; u < 4; u++)
+            inv_lut [u * 64 + lane] = smol_inv_p16_lut [u * 64 + lane];
+    }
 
     /* ---- the row loop --------------------------------------------------------------------- */
     const uint32_t dr = 8u * J.pos_out [0], dg = 8u * J.pos_out [1], db = 8u * J.pos_out [2], da = 8u * J.pos_out [3];
     const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
     gbyte *out_row = gptr (J.dst) + (size_t) yrel0 * J.dst_stride;
     uint32_t ks = 0, s_y = 0;
-    /* previous row's horizontal result (two packed channel pairs) and the vertical sums */
-    uint32_t hp0 [CPL], hp1 [CPL], acc [CPL][4];
+    /* previous row's horizontal result (two packed channel pairs; four 32-bit channels
+     * in hp32 for DOWN_GEN32) and the vertical sums */
+    uint32_t hp0 [CPL], hp1 [CPL], acc [CPL][4], hp32 [4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int c = 0; c < CPL; c++)
     {
@@ -180,23 +235,41 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
     }
 
     load_row ();
-    convert_row (lds);
-    smol_wave_sync ();
 
     for (uint32_t r = row_first; r <= row_last; r++)
     {
-        const uint32_t cur = (r - row_first) & 1u;
-        const uint8_t *buf = lds + cur * buf_pitch;
+        uint8_t *buf = lds + ((r - row_first) & 1u) * buf_pitch;
 
+        convert_row (buf);                              /* waits for row r's loads */
+        smol_wave_sync ();
         if (r < row_last)
             load_row ();                                /* row r + 1 flies while row r is filtered */
 
         /* ---- H ---------------------------------------------------------------------------- */
-        uint32_t h0 [CPL], h1 [CPL];
+        uint32_t h0 [CPL], h1 [CPL], h32 [4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int c = 0; c < CPL; c++)
         {
             uint32_t hs [4] = { 0, 0, 0, 0 };
+            if (MODE == DOWN_GEN32)
+            {
+#pragma unroll
+                for (uint32_t s = 0; s < NSX; s++)
+                {
+                    const u32x4 p = *reinterpret_cast<const u32x4 *> (buf + tap_ofs [c][s]);
+                    const u32x4 q = *reinterpret_cast<const u32x4 *> (buf + tap_ofs [c][s] + 16);
+                    const uint32_t F = tap_f [c][s], G = 256u - F;
+                    hs [0] += (__umul24 (p.x, F) + __umul24 (q.x, G)) >> 8;
+                    hs [1] += (__umul24 (p.y, F) + __umul24 (q.y, G)) >> 8;
+                    hs [2] += (__umul24 (p.z, F) + __umul24 (q.z, G)) >> 8;
+                    hs [3] += (__umul24 (p.w, F) + __umul24 (q.w, G)) >> 8;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    h32 [i] = hs [i] >> HX;
+                h0 [c] = h1 [c] = 0;
+                continue;
+            }
 #pragma unroll
             for (uint32_t s = 0; s < NSX; s++)
             {
@@ -218,6 +291,16 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
 #pragma unroll
             for (int c = 0; c < CPL; c++)
             {
+                if (MODE == DOWN_GEN32)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const uint32_t t = (__umul24 (hp32 [i], Fy) + __umul24 (h32 [i], G)) >> 8;
+                        acc [c][i] = s_y ? acc [c][i] + t : t;
+                    }
+                    continue;
+                }
                 const uint32_t t0 = (__umul24 (hp0 [c] & 0xffffu, Fy) + __umul24 (h0 [c] & 0xffffu, G)) >> 8;
                 const uint32_t t1 = (__umul24 (hp0 [c] >> 16, Fy) + __umul24 (h0 [c] >> 16, G)) >> 8;
                 const uint32_t t2 = (__umul24 (hp1 [c] & 0xffffu, Fy) + __umul24 (h1 [c] & 0xffffu, G)) >> 8;
@@ -229,7 +312,18 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
             }
             s_y++;
             ks++;
-            if (s_y == nsy)
+            if (s_y == nsy && GEN)
+            {
+                uint32_t v [4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    v [i] = acc [0][i] >> hv;
+                if (xl < xn)
+                    store_px<true> (J, reinterpret_cast<uint8_t *> (reinterpret_cast<uintptr_t> (out_row)), xl, v, lut);
+                s_y = 0;
+                out_row += J.dst_stride;
+            }
+            else if (s_y == nsy)
             {
                 uint32_t w [CPL];
 #pragma unroll
@@ -282,30 +376,57 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds)
             hp0 [c] = h0 [c];
             hp1 [c] = h1 [c];
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            hp32 [i] = h32 [i];
 
-        /* ---- park row r + 1 in the other buffer (its taps are read next iteration) ---------- */
-        if (r < row_last)
-        {
-            convert_row (lds + (cur ^ 1u) * buf_pitch);
-            smol_wave_sync ();
-        }
     }
+}
+
+/* table-driven flavours: 4 waves per workgroup share one LDS copy of the tables, each
+ * wave works on its own tile in its own LDS region */
+template <int HX, int MODE>
+__device__ __forceinline__ void down_gen_entry (const JobDev &J, uint8_t *lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    static uint8_t lut_lds [LUT_LDS_BYTES];
+    lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
+    down_body<HX, 1, MODE> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+#else
+    const uint32_t wave = threadIdx.x >> 6;
+    lut_fill_lds (lds, threadIdx.x, 256);
+    __syncthreads ();
+    const uint32_t pitch = (J.span_px * (MODE == DOWN_GEN32 ? 16u : 8u) + 15u) & ~15u;
+    down_body<HX, 1, MODE> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * 2u * pitch, lds,
+                            threadIdx.x & 63u, blockIdx.x * 4u + wave);
+#endif
 }
 
 #ifdef SMOL_KERNEL_EMU
 /* host emulation: one entry that switches at run time */
 __global__ void k_down_one (const JobDev J)
 {
+    if (J.down_mode == DOWN_GEN16 || J.down_mode == DOWN_GEN32)
+    {
+        const bool w32 = J.down_mode == DOWN_GEN32;
+        switch (J.halv_h)
+        {
+            case 0: if (w32) down_gen_entry<0, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<0, DOWN_GEN16> (J, smol_dyn_lds); break;
+            case 1: if (w32) down_gen_entry<1, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<1, DOWN_GEN16> (J, smol_dyn_lds); break;
+            default: if (w32) down_gen_entry<2, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<2, DOWN_GEN16> (J, smol_dyn_lds); break;
+        }
+        return;
+    }
     if (J.tile_cpl == 4)
     {
-        down_body<0, 4> (J, smol_dyn_lds);
+        down_body<0, 4, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
         return;
     }
     switch (J.halv_h)
     {
-        case 0: down_body<0, 1> (J, smol_dyn_lds); break;
-        case 1: down_body<1, 1> (J, smol_dyn_lds); break;
-        default: down_body<2, 1> (J, smol_dyn_lds); break;
+        case 0: down_body<0, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
+        case 1: down_body<1, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
+        default: down_body<2, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
     }
 }
 #else
@@ -315,14 +436,29 @@ __global__ void __launch_bounds__ (64)
 k_down_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = jobs [blockIdx.y];
-    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1> (J, smol_dyn_lds);
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
 }
 
 template <int HC>
 __global__ void __launch_bounds__ (64)
 k_down_one (const JobDev J)
 {
-    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1> (J, smol_dyn_lds);
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
+}
+
+template <int HX, int MODE>
+__global__ void __launch_bounds__ (256)
+k_downg_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = jobs [blockIdx.y];
+    down_gen_entry<HX, MODE> (J, smol_dyn_lds);
+}
+
+template <int HX, int MODE>
+__global__ void __launch_bounds__ (256)
+k_downg_one (const JobDev J)
+{
+    down_gen_entry<HX, MODE> (J, smol_dyn_lds);
 }
 #endif
 

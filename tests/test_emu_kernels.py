@@ -126,6 +126,36 @@ def test_emulated_down_kernel_premul16_minification():
     assert hits >= 60
 
 
+def test_emulated_down_kernel_table_driven_flavours():
+    """k_down modes 1 and 2: sRGB-linear (11-bit channels) and premul16 + sRGB (19-bit),
+    every input/output type incl. 24-bit, byte-aligned rows."""
+    rng = random.Random(999)
+    kinds = set()
+    for it in range(110):
+        w_out = rng.choice([1, 2, 7, 40, 64, 65, 130, 256])
+        h_out = rng.choice([1, 2, 5, 17, 33])
+        w_in = max(2, min(int(w_out * rng.uniform(1.01, 7.99)) + rng.randint(0, 1), 8 * w_out - 1))
+        h_in = max(2, min(int(h_out * rng.uniform(1.01, 7.99)) + rng.randint(0, 1), 8 * h_out - 1))
+        if w_in <= w_out or h_in <= h_out:
+            continue
+        t_in, t_out = rng.randrange(10), rng.randrange(10)
+        srgb = 0 if (t_in in (4, 5, 6, 7) and t_out in (4, 5, 6, 7) and it % 3 == 0) else 1
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 4, 1, 3])
+        sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4])
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        if not job.wide:
+            continue
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        if k == 9:
+            kinds.add((job.premul16, job.linear))
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n, k)
+    assert {(0, 1), (1, 1)} <= kinds
+
+
 def test_emulated_kernels_match_golden_subset():
     for (t_in, w_in, h_in, t_out, w_out, h_out, srgb, seed, valid), want in C.matrix_cases(stride=23):
         src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)

@@ -149,6 +149,25 @@ def test_down_kernel_premul16_minification_shapes():
             assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
 
 
+def test_down_kernel_srgb_linear_flavours():
+    """k_down modes 1 and 2 (with_srgb = 1, the API default): premultiplied, unassociated
+    and 24-bit types, odd strides, misaligned device buffers."""
+    shapes = [
+        (0, 4096, 300, 0, 2731, 200), (8, 4000, 90, 8, 1600, 36), (4, 1000, 700, 6, 333, 100),
+        (9, 2000, 64, 2, 260, 9), (1, 515, 129, 5, 256, 65), (4, 799, 601, 4, 100, 99), (8, 3, 3, 0, 2, 2),
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out) in enumerate(shapes):
+        for (sin_pad, mis) in ((0, 0), (3, 1)):
+            sin = w_in * H.bpp(t_in) + sin_pad
+            src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin)
+            got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "host", sin_pad)
+            got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin,
+                                     src_misalign=mis, dst_misalign=mis)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
+
+
 def test_tile_kernel_wide_images_and_box_shapes():
     """Geometries that select every k_tile layout: 4 columns per lane (wide, few taps),
     one column per lane, box with 1 and with 8 lanes per column, box on one axis only."""
