@@ -130,7 +130,7 @@ template <int INK>
 void
 launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
-    if (rep.up_wide)
+    if (rep.up_wide == 1)
     {
         launch_up_k<INK, smolhip::OUT_W16> (jobs_dev, rep, grid, lds, s);
         return;
@@ -264,6 +264,26 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         dim3 grid (max_lds ? max_lds : up_blocks (rep), n_jobs);
         const uint32_t lds = jobs_dev ? max_w_out : up_lds_bytes (rep);
 
+        if (rep.up_wide >= 2)
+        {
+            /* table-driven flavours: 4 waves = 4 tiles per workgroup */
+            grid.x = (grid.x + 3) / 4;
+            if (rep.up_wide == 3)
+            {
+                if (jobs_dev)
+                    hipLaunchKernelGGL (smolhip::k_upg_batch<true>, grid, dim3 (256), lds, s, jobs_dev);
+                else
+                    hipLaunchKernelGGL (smolhip::k_upg_one<true>, grid, dim3 (256), lds, s, rep);
+            }
+            else
+            {
+                if (jobs_dev)
+                    hipLaunchKernelGGL (smolhip::k_upg_batch<false>, grid, dim3 (256), lds, s, jobs_dev);
+                else
+                    hipLaunchKernelGGL (smolhip::k_upg_one<false>, grid, dim3 (256), lds, s, rep);
+            }
+            return hipGetLastError ();
+        }
         if (rep.tile_aligned4)
             launch_up_in<smolhip::UP_IN_A4> (jobs_dev, rep, grid, lds, s);
         else

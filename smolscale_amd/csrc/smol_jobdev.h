@@ -44,7 +44,7 @@ struct JobDev
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
-    uint8_t up_wide;               /* k_up: premul16 flavour (unassociated in and out, no sRGB) */
+    uint8_t up_wide;               /* k_up: 0 64bpp class, 1 premul16 fast path, 2 table-driven 16-bit channels, 3 table-driven 32-bit */
     uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
@@ -345,24 +345,28 @@ pow2x_blocks (const JobDev &d)
 /* k_up: bilinear magnification on both axes, 64bpp class. A tile of tile_rows
  * output rows may touch at most UP_NSRC source rows (smol_kernel_up.hip.h):
  * rows r = 0..TR-1 span floor ((TR-1) * step) + 3 source rows at most. */
+constexpr uint32_t DOWN_LUT_BYTES_FWD = (4 * 1024 + 512 + 2048 + 15) & ~15u;   /* LDS copy of the six tables */
 constexpr uint32_t UP_NSRC_HOST = 10;
 constexpr uint32_t UP_NSRC_W_HOST = 8;      /* premul16 flavour */
 
 inline bool
 up_setup (JobDev &d)
 {
-    /* of the 128bpp class only premul16 without sRGB (32-bit unassociated in and out) */
-    const bool w16 = d.wide && d.p16 && !d.linear && d.bpp_in == 4 && d.bpp_out == 4;
+    /* flavour: 0 64bpp class; 1 premul16 without sRGB on 32-bit pixels; 2 other 128bpp-class
+     * jobs with 16-bit channels (sRGB-linear, 8-bit alpha); 3 premul16 + sRGB (19-bit channels) */
+    uint32_t flavour = 0;
+    if (d.wide)
+        flavour = (d.p16 && !d.linear && d.bpp_in == 4 && d.bpp_out == 4) ? 1u : ((d.p16 && d.linear) ? 3u : 2u);
 
-    if ((d.wide && !w16) || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR || d.halv_h || d.halv_v)
+    if (d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR || d.halv_h || d.halv_v)
         return false;
     if (d.step_x >= ((uint64_t) 1 << 32) || d.step_y >= ((uint64_t) 1 << 32) || d.step_x == 0 || d.step_y == 0)
         return false;
-    if (d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_UP"))
+    if (d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_UP") || (flavour >= 2 && getenv ("SMOL_NO_UP_GEN")))
         return false;
 
-    d.up_wide = w16;
-    uint64_t tr = (((uint64_t) ((w16 ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
+    d.up_wide = (uint8_t) flavour;
+    uint64_t tr = (((uint64_t) ((flavour ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
     if (tr > 64)
         tr = 64;
     if (const char *e = getenv ("SMOL_UP_ROWS"))
@@ -370,8 +374,9 @@ up_setup (JobDev &d)
             tr = (uint64_t) atoi (e);
     d.tile_rows = (uint16_t) tr;
 
-    /* source pixels a 256-column tile can reach: ofs (x0 + 255) + 1 - ofs (x0) + 1 */
-    uint64_t span = ((255u * d.step_x) >> 32) + 3;
+    /* source pixels a tile can reach: ofs (x0 + cols - 1) + 1 - ofs (x0) + 1 */
+    const uint32_t cols = (flavour == 3) ? 128u : 256u;
+    uint64_t span = (((cols - 1u) * d.step_x) >> 32) + 3;
     if (span > d.w_in)
         span = d.w_in;
     d.span_px = (uint32_t) span;
@@ -389,15 +394,19 @@ up_setup (JobDev &d)
 inline uint32_t
 up_lds_bytes (const JobDev &d)
 {
+    if (d.up_wide >= 2)
+        return DOWN_LUT_BYTES_FWD + 4u * ((UP_NSRC_W_HOST * d.span_px * (d.up_wide == 3 ? 16u : 8u) + 15u) & ~15u) + 16u;
     if (d.up_wide)
         return UP_NSRC_W_HOST * d.span_px * 8u + 1024u + 16u;       /* + the inverse table */
     return UP_NSRC_HOST * d.span_px * 8u + 16u;
 }
 
+/* tiles of the job, rounded up to a multiple of 8 (flavours 2-3 launch one workgroup per 4 tiles) */
 inline uint32_t
 up_blocks (const JobDev &d)
 {
-    const uint32_t n = ((d.w_out + 255u) / 256u) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
+    const uint32_t tw = (d.up_wide == 3) ? 128u : 256u;
+    const uint32_t n = ((d.w_out + tw - 1u) / tw) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
     return (n + 7u) & ~7u;
 }
 

@@ -444,11 +444,203 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
     }
 }
 
+/* ------------------------------------------------------------------------- *
+ * k_up, table-driven flavours: every other 128bpp-class magnification --      *
+ * sRGB-linear (with_srgb = 1, the API default; 11-bit channels, W32 = false)  *
+ * and premul16 + sRGB (19-bit channels, W32 = true) -- any pixel types, any   *
+ * alignment. Pixels go through k_general's unpack_word<true> / store_px<true> *
+ * (smolscale-generic.c:470-752, 912-1164); 4 waves per workgroup share one    *
+ * LDS copy of the six tables, each wave works on its own tile.                *
+ * ------------------------------------------------------------------------- */
+template <bool W32>
+__device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const uint8_t *lut_lds,
+                                          const uint32_t lane, const uint32_t tile)
+{
+    constexpr int CPL = W32 ? 2 : 4;
+    constexpr uint32_t TW = TILE_COLS * CPL;
+    constexpr int NCH = W32 ? 4 : 2;                    /* registers per (source row, column) */
+
+    const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
+    const uint32_t tx = tile % tiles_x;
+    const uint32_t ty = tile / tiles_x;
+    const uint32_t yrel0 = ty * J.tile_rows;
+
+    if (yrel0 >= J.n_rows)
+        return;
+
+    const uint32_t nrows = (yrel0 + J.tile_rows < J.n_rows) ? J.tile_rows : J.n_rows - yrel0;
+    const uint32_t x0 = tx * TW;
+    const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;
+    const uint32_t xl = x0 + lane * CPL;
+    const LutLds lut (lut_lds);
+
+    uint32_t tap_ofs [CPL], tap_f [CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+    {
+        const uint32_t xc = (xl + c < xn) ? xl + c : xn - 1;
+        bilin_tap (J.frac0_x + (uint64_t) xc * J.step_x, J.w_in, tap_ofs [c], tap_f [c]);
+    }
+    const uint32_t sx0 = smol_readlane (tap_ofs [0], 0);
+
+    uint32_t my_oy, my_f;
+    {
+        const uint32_t r = (lane < nrows) ? lane : nrows - 1;
+        bilin_tap (J.frac0_y + (uint64_t) (J.first_row + yrel0 + r) * J.step_y, J.h_in, my_oy, my_f);
+    }
+    const uint32_t oy_first = smol_readlane (my_oy, 0);
+    const uint32_t oy_last = smol_readlane (my_oy, nrows - 1);
+    const uint32_t sched = (my_oy - oy_first) | (my_f << 16);
+    uint32_t n_src = oy_last - oy_first + 2;
+    if (n_src > (uint32_t) UP_NSRC_W)
+        n_src = UP_NSRC_W;                              /* cannot happen: up_setup sizes tile_rows */
+
+    /* ---- stage: every source pixel of the tile once, as internal channels ------------------ */
+    const uint32_t span = J.span_px;
+    {
+        const gbyte *srow0 = gptr (J.src) + (size_t) oy_first * J.src_stride;
+        const uint32_t total = n_src * span;
+
+        for (uint32_t i0 = 0; i0 < total; i0 += 64u * 4u)
+        {
+            uint32_t w [4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const uint32_t i = i0 + (uint32_t) u * 64u + lane;
+                const uint32_t srow = (uint32_t) (((uint64_t) i * J.span_chunks_inv) >> 32);   /* i / span */
+                const uint32_t k = i - srow * span;
+                uint32_t x = sx0 + k;
+                if (x > J.w_in - 1)
+                    x = J.w_in - 1;
+                w [u] = 0;
+                if (i < total)
+                {
+                    if (J.in_dword_ok)
+                        w [u] = up_load_px<UP_IN_A4> (J, srow0 + (size_t) srow * J.src_stride, x);
+                    else
+                        w [u] = up_load_px<UP_IN_ANY> (J, srow0 + (size_t) srow * J.src_stride, x);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const uint32_t i = i0 + (uint32_t) u * 64u + lane;
+                uint32_t ch [4];
+                unpack_word<true> (J, w [u], ch, lut);
+                if (i < total)
+                {
+                    if (W32)
+                        *reinterpret_cast<u32x4 *> (lds + (size_t) i * 16) = u32x4 { ch [0], ch [1], ch [2], ch [3] };
+                    else
+                        *reinterpret_cast<u32x2a8 *> (lds + (size_t) i * 8) = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
+                }
+            }
+        }
+    }
+    smol_wave_sync ();
+
+    /* ---- H ---------------------------------------------------------------------------- */
+    uint32_t h [UP_NSRC_W][CPL][NCH];
+#pragma unroll
+    for (int s = 0; s < UP_NSRC_W; s++)
+    {
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+                h [s][c][i] = 0;
+        if ((uint32_t) s < n_src)                       /* wave-uniform */
+        {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+            {
+                const uint32_t k = (uint32_t) s * span + (tap_ofs [c] - sx0);
+                const uint32_t F = tap_f [c], G = 256u - F;
+                if (W32)
+                {
+                    const u32x4 p = *reinterpret_cast<const u32x4 *> (lds + (size_t) k * 16);
+                    const u32x4 q = *reinterpret_cast<const u32x4 *> (lds + (size_t) k * 16 + 16);
+                    h [s][c][0] = (__umul24 (p.x, F) + __umul24 (q.x, G)) >> 8;
+                    h [s][c][1] = (__umul24 (p.y, F) + __umul24 (q.y, G)) >> 8;
+                    h [s][c][2 % NCH] = (__umul24 (p.z, F) + __umul24 (q.z, G)) >> 8;
+                    h [s][c][3 % NCH] = (__umul24 (p.w, F) + __umul24 (q.w, G)) >> 8;
+                }
+                else
+                {
+                    const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (lds + (size_t) k * 8);
+                    h [s][c][0] = up16_tap (pq.x, pq.z, F, G);
+                    h [s][c][1] = up16_tap (pq.y, pq.w, F, G);
+                }
+            }
+        }
+    }
+
+    /* ---- V + pack + store -------------------------------------------------------------------- */
+    uint8_t *out_row = J.dst + (size_t) yrel0 * J.dst_stride;
+    uint32_t r = 0;
+    uint32_t e = smol_readlane (sched, 0);
+
+#pragma unroll
+    for (int s = 0; s + 1 < UP_NSRC_W; s++)
+    {
+        while (r < nrows && (e & 0xffffu) == (uint32_t) s)
+        {
+            const uint32_t F = e >> 16, G = 256u - F;
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+            {
+                uint32_t v [4];
+                if (W32)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        v [i] = (__umul24 (h [s][c][i % NCH], F) + __umul24 (h [s + 1][c][i % NCH], G)) >> 8;
+                }
+                else
+                {
+                    const uint32_t rg = up16_tap (h [s][c][0], h [s + 1][c][0], F, G);
+                    const uint32_t ba = up16_tap (h [s][c][1], h [s + 1][c][1], F, G);
+                    v [0] = rg & 0xffffu; v [1] = rg >> 16; v [2] = ba & 0xffffu; v [3] = ba >> 16;
+                }
+                if (xl + c < xn)
+                    store_px<true> (J, out_row, xl + c, v, lut);
+            }
+            out_row += J.dst_stride;
+            r++;
+            if (r < nrows)
+                e = smol_readlane (sched, r);
+        }
+    }
+}
+
+template <bool W32>
+__device__ __forceinline__ void upg_entry (const JobDev &J, uint8_t *lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    static uint8_t lut_lds [LUT_LDS_BYTES];
+    lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
+    upg_body<W32> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+#else
+    const uint32_t wave = threadIdx.x >> 6;
+    lut_fill_lds (lds, threadIdx.x, 256);
+    __syncthreads ();
+    const uint32_t region = (UP_NSRC_W * J.span_px * (W32 ? 16u : 8u) + 15u) & ~15u;
+    upg_body<W32> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * region, lds,
+                   threadIdx.x & 63u, blockIdx.x * 4u + wave);
+#endif
+}
+
 #ifdef SMOL_KERNEL_EMU
 /* host emulation: one entry that switches at run time */
 __global__ void k_up_one (const JobDev J)
 {
     const bool a4 = J.tile_aligned4;
+    if (J.up_wide >= 2)
+    {
+        if (J.up_wide == 3) upg_entry<true> (J, smol_dyn_lds); else upg_entry<false> (J, smol_dyn_lds);
+        return;
+    }
     if (J.up_wide)
     {
         if (a4) up16_body<UP_IN_A4> (J, smol_dyn_lds); else up16_body<UP_IN_ANY> (J, smol_dyn_lds);
@@ -471,6 +663,21 @@ k_up_batch (const JobDev *__restrict__ jobs)
         up16_body<INK> (J, smol_dyn_lds);
     else
         up_body<INK, OUT == OUT_W16 ? OUT_P4 : OUT> (J, smol_dyn_lds);
+}
+
+template <bool W32>
+__global__ void __launch_bounds__ (256)
+k_upg_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = jobs [blockIdx.y];
+    upg_entry<W32> (J, smol_dyn_lds);
+}
+
+template <bool W32>
+__global__ void __launch_bounds__ (256)
+k_upg_one (const JobDev J)
+{
+    upg_entry<W32> (J, smol_dyn_lds);
 }
 
 template <int INK, int OUT>

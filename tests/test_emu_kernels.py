@@ -101,6 +101,31 @@ def test_emulated_up_kernel_magnification():
     assert hits >= 130
 
 
+def test_emulated_up_kernel_table_driven_flavours():
+    """k_up flavours 2 and 3: magnification with with_srgb = 1 (sRGB-linear; premul16 + sRGB),
+    every type pair incl. 24-bit, odd strides."""
+    rng = random.Random(31337)
+    kinds = set()
+    for it in range(100):
+        w_in = rng.choice([2, 3, 8, 17, 64, 100])
+        h_in = rng.choice([2, 3, 9, 30])
+        w_out = rng.randint(w_in + 1, min(w_in * 9, 700))
+        h_out = rng.randint(h_in + 1, min(h_in * 9, 120))
+        t_in, t_out = (it // 10) % 10, it % 10
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 3, 4])
+        sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 1)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin, sout, first, n)
+        if k == 8:
+            kinds.add((job.premul16, job.linear))
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
+    assert {(0, 1), (1, 1)} <= kinds
+
+
 def test_emulated_down_kernel_premul16_minification():
     """k_down: unassociated -> unassociated (premul16) bilinear minification, ratios
     1..8 per axis (0-2 halvings), 1 and 4 columns per lane, row slabs, padded strides."""

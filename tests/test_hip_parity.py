@@ -149,6 +149,24 @@ def test_down_kernel_premul16_minification_shapes():
             assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
 
 
+def test_up_kernel_srgb_linear_flavours():
+    """k_up flavours 2 and 3 (with_srgb = 1 magnification), host and misaligned device buffers."""
+    shapes = [
+        (0, 480, 270, 0, 1920, 1080), (8, 300, 200, 8, 1300, 900), (4, 257, 65, 4, 1300, 300),
+        (9, 64, 64, 5, 513, 511), (5, 100, 100, 2, 777, 333), (4, 2, 2, 6, 300, 37), (0, 1279, 719, 8, 1280, 720),
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out) in enumerate(shapes):
+        for (sin_pad, mis) in ((0, 0), (3, 1)):
+            sin = w_in * H.bpp(t_in) + sin_pad
+            src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin)
+            got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "host", sin_pad)
+            got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin,
+                                     src_misalign=mis, dst_misalign=mis)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
+
+
 def test_down_kernel_srgb_linear_flavours():
     """k_down modes 1 and 2 (with_srgb = 1, the API default): premultiplied, unassociated
     and 24-bit types, odd strides, misaligned device buffers."""

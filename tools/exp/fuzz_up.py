@@ -12,13 +12,14 @@ for it in range(N):
     t_in=random.randrange(10); t_out=random.randrange(10)
     sin=w_in*bpp(t_in)+random.choice([0,0,1,3,4,16]); sout=w_out*bpp(t_out)+random.choice([0,0,1,4,16])
     src=make_input(t_in,w_in,h_in,seed=it,valid=random.choice([True,False]),stride=sin,pad=0)
-    job=plan_job(t_in,w_in,h_in,t_out,w_out,h_out,0)
+    srgb=random.choice([0,1]) if len(sys.argv) > 4 else 0
+    job=plan_job(t_in,w_in,h_in,t_out,w_out,h_out,srgb)
     if job.wide and not (len(sys.argv) > 3): continue
     first=random.randint(0,h_out-1); nr=random.randint(1,h_out-first)
-    a=oracle_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,0,sin,sout,first,nr)
-    b,k=emu_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,0,sin,sout,first,nr)
-    seen[k]=seen.get(k,0)+1
+    a=oracle_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,srgb,sin,sout,first,nr)
+    b,k=emu_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,srgb,sin,sout,first,nr)
+    seen[(k,job.premul16,job.linear)]=seen.get((k,job.premul16,job.linear),0)+1
     n+=1
     if not np.array_equal(a,b):
-        bad+=1; print("MISMATCH types",t_in,t_out,(w_in,h_in),(w_out,h_out),sin,sout,first,nr,"class",k)
+        bad+=1; print("MISMATCH srgb",srgb,"types",t_in,t_out,(w_in,h_in),(w_out,h_out),sin,sout,first,nr,"class",k)
 print("cases",n,"bad",bad,"classes",seen)
