@@ -18,7 +18,8 @@
 #include <vector>
 
 #include "smol_hip.h"
-#include "smol_kernels.hip.h"
+#include "smol_jobdev.h"
+#include "smol_launch.h"
 
 using smolhip::JobDev;
 using namespace smolhip::dispatch;
@@ -32,325 +33,59 @@ using namespace smolhip::dispatch;
 
 namespace {
 
-/* A launch either reads descriptors from device memory (jobs_dev != NULL, one per
- * blockIdx.y) or takes the single descriptor `rep' by value as kernel argument. */
-template <int HX, int HY>
-void
-launch_pow2_one (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (64, 16), 0, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (64, 16), 0, s, rep);
-}
-
-template <int HX>
-void
-launch_pow2_hy (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
-{
-    switch (rep.halv_v)
-    {
-        case 0: launch_pow2_one<HX, 0> (jobs_dev, rep, grid, s); break;
-        case 1: launch_pow2_one<HX, 1> (jobs_dev, rep, grid, s); break;
-        default: launch_pow2_one<HX, 2> (jobs_dev, rep, grid, s); break;
-    }
-}
-
-/* k_pow2x: one entry point per (halvings, input kind) */
-template <int H, int IN>
-void
-launch_pow2x_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_pow2x_batch<H, IN>), grid, dim3 (64, 16), 0, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_pow2x_one<H, IN>), grid, dim3 (64, 16), 0, s, rep);
-}
-
-template <int H>
-void
-launch_pow2x_h (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
-{
-    switch (rep.px_kind)
-    {
-        case smolhip::PX_N32: launch_pow2x_k<H, smolhip::PX_N32> (jobs_dev, rep, grid, s); break;
-        case smolhip::PX_N24: launch_pow2x_k<H, smolhip::PX_N24> (jobs_dev, rep, grid, s); break;
-        case smolhip::PX_W32: launch_pow2x_k<H, smolhip::PX_W32> (jobs_dev, rep, grid, s); break;
-        case smolhip::PX_W16: launch_pow2x_k<H, smolhip::PX_W16> (jobs_dev, rep, grid, s); break;
-        default:              launch_pow2x_k<H, smolhip::PX_W24> (jobs_dev, rep, grid, s); break;
-    }
-}
-
-/* k_down: one entry point per horizontal mode (halvings 0-2 | 3 = four columns per lane) */
-template <int HC>
-void
-launch_down_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_down_batch<HC>), grid, dim3 (64), lds, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_down_one<HC>), grid, dim3 (64), lds, s, rep);
-}
-
-/* table-driven k_down flavours: one entry point per (horizontal halvings, mode) */
-template <int HX, int MODE>
-void
-launch_downg_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_downg_batch<HX, MODE>), grid, dim3 (256), lds, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_downg_one<HX, MODE>), grid, dim3 (256), lds, s, rep);
-}
-
-template <int MODE>
-void
-launch_downg_m (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    switch (rep.halv_h)
-    {
-        case 0:  launch_downg_k<0, MODE> (jobs_dev, rep, grid, lds, s); break;
-        case 1:  launch_downg_k<1, MODE> (jobs_dev, rep, grid, lds, s); break;
-        default: launch_downg_k<2, MODE> (jobs_dev, rep, grid, lds, s); break;
-    }
-}
-
-/* k_up: one entry point per (input alignment kind, output kind) */
-template <int INK, int OUT>
-void
-launch_up_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_up_batch<INK, OUT>), grid, dim3 (64), lds, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_up_one<INK, OUT>), grid, dim3 (64), lds, s, rep);
-}
-
-template <int INK>
-void
-launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (rep.up_wide == 1)
-    {
-        launch_up_k<INK, smolhip::OUT_W16> (jobs_dev, rep, grid, lds, s);
-        return;
-    }
-    switch (rep.tile_variant & 3u)
-    {
-        case smolhip::OUT_P4: launch_up_k<INK, smolhip::OUT_P4> (jobs_dev, rep, grid, lds, s); break;
-        case smolhip::OUT_U4: launch_up_k<INK, smolhip::OUT_U4> (jobs_dev, rep, grid, lds, s); break;
-        default:              launch_up_k<INK, smolhip::OUT_ANY> (jobs_dev, rep, grid, lds, s); break;
-    }
-}
-
-/* k_tile has one entry point per (tapsel, horizontal mode, columns per lane) */
-template <int TS, int HM, int CPL>
-void
-launch_tile_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL>), grid, dim3 (64), lds, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, dim3 (64), lds, s, rep);
-}
-
-template <int TS>
-void
-launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    const uint32_t hm = (rep.tile_variant >> 2) & 7u;
-
-    if (rep.tile_cpl == 4)
-    {
-        switch (hm)
-        {
-            case 0:  launch_tile_k<TS, 0, 4> (jobs_dev, rep, grid, lds, s); break;
-            case 1:  launch_tile_k<TS, 1, 4> (jobs_dev, rep, grid, lds, s); break;
-            case 2:  launch_tile_k<TS, 2, 4> (jobs_dev, rep, grid, lds, s); break;
-            default: launch_tile_k<TS, 3, 4> (jobs_dev, rep, grid, lds, s); break;
-        }
-        return;
-    }
-    switch (hm)
-    {
-        case 0:  launch_tile_k<TS, 0, 1> (jobs_dev, rep, grid, lds, s); break;
-        case 1:  launch_tile_k<TS, 1, 1> (jobs_dev, rep, grid, lds, s); break;
-        case 2:  launch_tile_k<TS, 2, 1> (jobs_dev, rep, grid, lds, s); break;
-        case 3:  launch_tile_k<TS, 3, 1> (jobs_dev, rep, grid, lds, s); break;
-        case 4:  launch_tile_k<TS, 4, 1> (jobs_dev, rep, grid, lds, s); break;
-        default: launch_tile_k<TS, 5, 1> (jobs_dev, rep, grid, lds, s); break;
-    }
-}
-
-void
-launch_tile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    switch (rep.tile_variant >> 5)
-    {
-        case 0:  launch_tile_ts<0> (jobs_dev, rep, grid, lds, s); break;
-        case 1:  launch_tile_ts<1> (jobs_dev, rep, grid, lds, s); break;
-        case 2:  launch_tile_ts<2> (jobs_dev, rep, grid, lds, s); break;
-        default: launch_tile_ts<3> (jobs_dev, rep, grid, lds, s); break;
-    }
-}
-
-/* Launch one kernel over `n_jobs' jobs that all share class k and (for k_pow2)
- * the same halvings as `rep'. max_* are maxima over the group. */
+/* Launch one kernel over `n_jobs' jobs that all share class k and the per-class
+ * grouping keys of smol_hip_batch_create. max_* are maxima over the group. */
 hipError_t
 launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &rep,
               uint32_t max_w_out, uint32_t max_rows, hipStream_t s, uint32_t max_lds = 0)
 {
+    namespace L = smolhip::launch;
+
     if (k == KC_POW2)
     {
         const uint32_t rx = 2u << rep.halv_h;
         const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
         const uint32_t tcols = max_w_out / opt;
-        dim3 grid (((tcols + 63) / 64) * ((max_rows + 15) / 16), n_jobs);
-
-        switch (rep.halv_h)
-        {
-            case 0: launch_pow2_hy<0> (jobs_dev, rep, grid, s); break;
-            case 1: launch_pow2_hy<1> (jobs_dev, rep, grid, s); break;
-            default: launch_pow2_hy<2> (jobs_dev, rep, grid, s); break;
-        }
-        return hipGetLastError ();
+        L::pow2 (jobs_dev, rep, dim3 (((tcols + 63) / 64) * ((max_rows + 15) / 16), n_jobs), s);
     }
-
-    if (k == KC_POW2X)
+    else if (k == KC_POW2X)
     {
-        /* groups share halvings and input kind; max_lds carries the group's largest block count */
-        dim3 grid (max_lds ? max_lds : pow2x_blocks (rep), n_jobs);
-
-        switch (rep.halv_h)
-        {
-            case 0: launch_pow2x_h<0> (jobs_dev, rep, grid, s); break;
-            case 1: launch_pow2x_h<1> (jobs_dev, rep, grid, s); break;
-            default: launch_pow2x_h<2> (jobs_dev, rep, grid, s); break;
-        }
-        return hipGetLastError ();
+        /* max_lds carries the group's largest block count */
+        L::pow2x (jobs_dev, rep, dim3 (max_lds ? max_lds : pow2x_blocks (rep), n_jobs), s);
     }
-
-    if (k == KC_DOWN)
+    else if (k == KC_DOWN)
     {
-        /* groups share the horizontal mode; max_lds carries the
-         * largest block count, max_w_out (batches only) the largest LDS size */
-        dim3 grid (max_lds ? max_lds : down_blocks (rep), n_jobs);
-        const uint32_t lds = jobs_dev ? max_w_out : down_lds_bytes (rep);
-
-        if (rep.down_mode)
-        {
-            grid.x = (grid.x + 3) / 4;          /* 4 waves = 4 tiles per workgroup */
-            if (rep.down_mode == 2)
-                launch_downg_m<smolhip::DOWN_GEN32> (jobs_dev, rep, grid, lds, s);
-            else
-                launch_downg_m<smolhip::DOWN_GEN16> (jobs_dev, rep, grid, lds, s);
-            return hipGetLastError ();
-        }
-        if (rep.tile_cpl == 4)
-            launch_down_k<3> (jobs_dev, rep, grid, lds, s);
-        else if (rep.halv_h == 0)
-            launch_down_k<0> (jobs_dev, rep, grid, lds, s);
-        else if (rep.halv_h == 1)
-            launch_down_k<1> (jobs_dev, rep, grid, lds, s);
-        else
-            launch_down_k<2> (jobs_dev, rep, grid, lds, s);
-        return hipGetLastError ();
+        /* max_lds carries the largest tile count, max_w_out (batches only) the largest LDS size */
+        L::down (jobs_dev, rep, dim3 (max_lds ? max_lds : down_blocks (rep), n_jobs),
+                 jobs_dev ? max_w_out : down_lds_bytes (rep), s);
     }
-
-    if (k == KC_UP)
+    else if (k == KC_UP)
     {
-        /* groups share the input and output kinds; max_lds carries the largest block
-         * count, max_w_out (batches only) the largest LDS size */
-        dim3 grid (max_lds ? max_lds : up_blocks (rep), n_jobs);
-        const uint32_t lds = jobs_dev ? max_w_out : up_lds_bytes (rep);
-
-        if (rep.up_wide >= 2)
-        {
-            /* table-driven flavours: 4 waves = 4 tiles per workgroup */
-            grid.x = (grid.x + 3) / 4;
-            if (rep.up_wide == 3)
-            {
-                if (jobs_dev)
-                    hipLaunchKernelGGL (smolhip::k_upg_batch<true>, grid, dim3 (256), lds, s, jobs_dev);
-                else
-                    hipLaunchKernelGGL (smolhip::k_upg_one<true>, grid, dim3 (256), lds, s, rep);
-            }
-            else
-            {
-                if (jobs_dev)
-                    hipLaunchKernelGGL (smolhip::k_upg_batch<false>, grid, dim3 (256), lds, s, jobs_dev);
-                else
-                    hipLaunchKernelGGL (smolhip::k_upg_one<false>, grid, dim3 (256), lds, s, rep);
-            }
-            return hipGetLastError ();
-        }
-        if (rep.tile_aligned4)
-            launch_up_in<smolhip::UP_IN_A4> (jobs_dev, rep, grid, lds, s);
-        else
-            launch_up_in<smolhip::UP_IN_ANY> (jobs_dev, rep, grid, lds, s);
-        return hipGetLastError ();
+        L::up (jobs_dev, rep, dim3 (max_lds ? max_lds : up_blocks (rep), n_jobs),
+               jobs_dev ? max_w_out : up_lds_bytes (rep), s);
     }
-
-    if (k == KC_TILE || k == KC_WTILE)
+    else if (k == KC_TILE || k == KC_WTILE)
     {
-        /* groups share tile_rows and LDS size (see smol_hip_batch_create) */
-        const uint32_t tw = smolhip::TILE_COLS * rep.tile_cpl / rep.tile_lpc;
+        /* groups share tile_rows and LDS size */
+        const uint32_t tw = 64u * rep.tile_cpl / rep.tile_lpc;
         const uint32_t tiles_x = (max_w_out + tw - 1) / tw;
         const uint32_t tiles_y = (max_rows + rep.tile_rows - 1) / rep.tile_rows;
-        dim3 grid (tiles_x * tiles_y, n_jobs);
+        const dim3 grid (tiles_x * tiles_y, n_jobs);
         const uint32_t lds = max_lds ? max_lds : tile_lds_bytes (rep);
 
         if (k == KC_WTILE)
-        {
-            if (jobs_dev)
-                hipLaunchKernelGGL (smolhip::k_wtile_batch, grid, dim3 (64), lds, s, jobs_dev);
-            else
-                hipLaunchKernelGGL (smolhip::k_wtile_one, grid, dim3 (64), lds, s, rep);
-        }
+            L::wtile (jobs_dev, rep, grid, lds, s);
         else
-        {
-            launch_tile (jobs_dev, rep, grid, lds, s);
-        }
-        return hipGetLastError ();
+            L::tile (jobs_dev, rep, grid, lds, s);
     }
-
-    if (k == KC_WAVEPX || k == KC_WAVEPX_WIDE)
+    else if (k == KC_WAVEPX || k == KC_WAVEPX_WIDE)
     {
-        /* groups hold jobs of one output width (see smol_hip_batch_create) */
-        dim3 grid (rep.w_out * max_rows, n_jobs);
-        if (k == KC_WAVEPX_WIDE)
-        {
-            if (jobs_dev)
-                hipLaunchKernelGGL (smolhip::k_wavepx_batch<true>, grid, dim3 (64), 0, s, jobs_dev);
-            else
-                hipLaunchKernelGGL (smolhip::k_wavepx_one<true>, grid, dim3 (64), 0, s, rep);
-        }
-        else
-        {
-            if (jobs_dev)
-                hipLaunchKernelGGL (smolhip::k_wavepx_batch<false>, grid, dim3 (64), 0, s, jobs_dev);
-            else
-                hipLaunchKernelGGL (smolhip::k_wavepx_one<false>, grid, dim3 (64), 0, s, rep);
-        }
-        return hipGetLastError ();
-    }
-
-    dim3 grid (((max_w_out + smolhip::GENERAL_BLOCK - 1) / smolhip::GENERAL_BLOCK) * max_rows, n_jobs);
-    dim3 block (smolhip::GENERAL_BLOCK);
-
-    if (k == KC_GENERAL_WIDE)
-    {
-        if (jobs_dev)
-            hipLaunchKernelGGL (smolhip::k_general_batch<true>, grid, block, 0, s, jobs_dev);
-        else
-            hipLaunchKernelGGL (smolhip::k_general_one<true>, grid, block, 0, s, rep);
+        /* groups hold jobs of one output width */
+        L::wavepx (jobs_dev, rep, dim3 (rep.w_out * max_rows, n_jobs), k == KC_WAVEPX_WIDE, s);
     }
     else
     {
-        if (jobs_dev)
-            hipLaunchKernelGGL (smolhip::k_general_batch<false>, grid, block, 0, s, jobs_dev);
-        else
-            hipLaunchKernelGGL (smolhip::k_general_one<false>, grid, block, 0, s, rep);
+        L::general (jobs_dev, rep, dim3 (((max_w_out + 255u) / 256u) * max_rows, n_jobs), k == KC_GENERAL_WIDE, s);
     }
     return hipGetLastError ();
 }

@@ -1,0 +1,136 @@
+/* smol_k_updown.hip -- kernel instantiations + launch wrappers of the k_up / k_down (magnification; 128bpp-class minification) family (gfx950).
+ * One translation unit per kernel family so that `make -j' compiles them side by
+ * side; smol_hip.hip (the runtime) only sees smol_launch.h. */
+
+#include <hip/hip_runtime.h>
+
+#include "smol_kernels.hip.h"
+#include "smol_kernel_tile.hip.h"
+#include "smol_kernel_up.hip.h"
+#include "smol_kernel_down.hip.h"
+#include "smol_launch.h"
+
+using smolhip::JobDev;
+
+namespace {
+
+/* k_down: one entry point per horizontal mode (halvings 0-2 | 3 = four columns per lane) */
+template <int HC>
+void
+launch_down_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_down_batch<HC>), grid, dim3 (64), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_down_one<HC>), grid, dim3 (64), lds, s, rep);
+}
+
+/* table-driven k_down flavours: one entry point per (horizontal halvings, mode) */
+template <int HX, int MODE>
+void
+launch_downg_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_downg_batch<HX, MODE>), grid, dim3 (256), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_downg_one<HX, MODE>), grid, dim3 (256), lds, s, rep);
+}
+
+template <int MODE>
+void
+launch_downg_m (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (rep.halv_h)
+    {
+        case 0:  launch_downg_k<0, MODE> (jobs_dev, rep, grid, lds, s); break;
+        case 1:  launch_downg_k<1, MODE> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_downg_k<2, MODE> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
+/* k_up: one entry point per (input alignment kind, output kind) */
+template <int INK, int OUT>
+void
+launch_up_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_up_batch<INK, OUT>), grid, dim3 (64), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_up_one<INK, OUT>), grid, dim3 (64), lds, s, rep);
+}
+
+template <int INK>
+void
+launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (rep.up_wide == 1)
+    {
+        launch_up_k<INK, smolhip::OUT_W16> (jobs_dev, rep, grid, lds, s);
+        return;
+    }
+    switch (rep.tile_variant & 3u)
+    {
+        case smolhip::OUT_P4: launch_up_k<INK, smolhip::OUT_P4> (jobs_dev, rep, grid, lds, s); break;
+        case smolhip::OUT_U4: launch_up_k<INK, smolhip::OUT_U4> (jobs_dev, rep, grid, lds, s); break;
+        default:              launch_up_k<INK, smolhip::OUT_ANY> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
+} /* namespace */
+
+namespace smolhip {
+namespace launch {
+
+/* grid.x counts tiles; the table-driven flavours run 4 tiles (4 waves) per workgroup */
+void
+down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (rep.down_mode)
+    {
+        grid.x = (grid.x + 3) / 4;
+        if (rep.down_mode == 2)
+            launch_downg_m<smolhip::DOWN_GEN32> (jobs_dev, rep, grid, lds, s);
+        else
+            launch_downg_m<smolhip::DOWN_GEN16> (jobs_dev, rep, grid, lds, s);
+        return;
+    }
+    if (rep.tile_cpl == 4)
+        launch_down_k<3> (jobs_dev, rep, grid, lds, s);
+    else if (rep.halv_h == 0)
+        launch_down_k<0> (jobs_dev, rep, grid, lds, s);
+    else if (rep.halv_h == 1)
+        launch_down_k<1> (jobs_dev, rep, grid, lds, s);
+    else
+        launch_down_k<2> (jobs_dev, rep, grid, lds, s);
+}
+
+void
+up (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (rep.up_wide >= 2)
+    {
+        grid.x = (grid.x + 3) / 4;
+        if (rep.up_wide == 3)
+        {
+            if (jobs_dev)
+                hipLaunchKernelGGL (smolhip::k_upg_batch<true>, grid, dim3 (256), lds, s, jobs_dev);
+            else
+                hipLaunchKernelGGL (smolhip::k_upg_one<true>, grid, dim3 (256), lds, s, rep);
+        }
+        else
+        {
+            if (jobs_dev)
+                hipLaunchKernelGGL (smolhip::k_upg_batch<false>, grid, dim3 (256), lds, s, jobs_dev);
+            else
+                hipLaunchKernelGGL (smolhip::k_upg_one<false>, grid, dim3 (256), lds, s, rep);
+        }
+        return;
+    }
+    if (rep.tile_aligned4)
+        launch_up_in<smolhip::UP_IN_A4> (jobs_dev, rep, grid, lds, s);
+    else
+        launch_up_in<smolhip::UP_IN_ANY> (jobs_dev, rep, grid, lds, s);
+}
+
+} /* namespace launch */
+} /* namespace smolhip */

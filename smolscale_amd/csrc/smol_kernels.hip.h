@@ -37,7 +37,7 @@
 #endif
 #include <stdint.h>
 
-#define SMOL_LUT_QUAL __constant__
+#define SMOL_LUT_QUAL static __constant__     /* one copy per translation unit */
 #include "smol_luts.h"
 
 #include "smol_jobdev.h"
@@ -807,9 +807,3 @@ k_pow2_one (const JobDev J)
 
 
 } /* namespace smolhip */
-
-#include "smol_kernel_tile.hip.h"
-#include "smol_kernel_wtile.hip.h"
-#include "smol_kernel_pow2x.hip.h"
-#include "smol_kernel_up.hip.h"
-#include "smol_kernel_down.hip.h"

@@ -1,0 +1,42 @@
+/* smol_launch.h -- launch wrappers of the kernel families, one translation unit each
+ * (smol_k_stream.hip, smol_k_updown.hip, smol_k_tile0-3.hip, smol_k_misc.hip). A launch
+ * either reads descriptors from device memory (jobs_dev != NULL, one per blockIdx.y)
+ * or takes the single descriptor `rep' by value as kernel argument. */
+
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smol_jobdev.h"
+
+namespace smolhip {
+namespace launch {
+
+void pow2 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s);
+void pow2x (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s);
+void up (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+void down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+void tile_ts0 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+void tile_ts1 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+void tile_ts2 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+void tile_ts3 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+
+/* k_tile: tapsel of tile_variant picks the translation unit */
+inline void
+tile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (rep.tile_variant >> 5)
+    {
+        case 0:  tile_ts0 (jobs_dev, rep, grid, lds, s); break;
+        case 1:  tile_ts1 (jobs_dev, rep, grid, lds, s); break;
+        case 2:  tile_ts2 (jobs_dev, rep, grid, lds, s); break;
+        default: tile_ts3 (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+void wtile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+void wavepx (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, bool wide, hipStream_t s);
+void general (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, bool wide, hipStream_t s);
+
+} /* namespace launch */
+} /* namespace smolhip */

@@ -3,7 +3,7 @@
  * kernel-class selection code the real runtime uses (smol_jobdev.h).
  * Built by tests/emu/Makefile with clang++ -DSMOL_KERNEL_EMU. */
 #define SMOL_KERNEL_EMU 1
-#include "smol_kernels.hip.h"
+#include "smol_kernels_all.hip.h"
 
 #include <thread>
 #include <vector>
