@@ -64,6 +64,13 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         L::up (jobs_dev, rep, dim3 (max_lds ? max_lds : up_blocks (rep), n_jobs),
                jobs_dev ? max_w_out : up_lds_bytes (rep), s);
     }
+    else if (k == KC_BOX2)
+    {
+        /* rep.tmp / jobs [i].tmp point at the intermediate images; max_w_out / max_rows
+         * carry the group's largest pass-1 / pass-2 wave counts, max_lds the largest LDS size */
+        L::box2 (jobs_dev, rep, n_jobs, jobs_dev ? max_w_out : box2_h_tiles (rep),
+                 jobs_dev ? max_rows : box2_v_tiles (rep), jobs_dev ? max_lds : box2_h_lds_bytes (rep), s);
+    }
     else if (k == KC_TILE || k == KC_WTILE)
     {
         /* groups share tile_rows and LDS size */
@@ -90,6 +97,38 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
     return hipGetLastError ();
 }
 
+/* One job, descriptor by value. The two-pass box filter needs an intermediate image:
+ * `scratch' (caller-owned, at least box2_tmp_bytes + 64) if given; otherwise a
+ * temporary allocation released after the stream has drained. (hipMallocAsync /
+ * hipFreeAsync would avoid the drain, but on this ROCm build kernels reading such an
+ * allocation intermittently saw stale data: 1048 of 4000 randomized cases wrong,
+ * none with plain hipMalloc -- tools/exp/fuzz_box2_gpu.py.) */
+hipError_t
+launch_single (JobDev &jd, hipStream_t s, void *scratch = nullptr)
+{
+    const KClass k = classify (jd);
+
+    if (k != KC_BOX2)
+        return launch_class (k, nullptr, 1, jd, jd.w_out, jd.n_rows, s);
+
+    void *tmp = scratch;
+    hipError_t e = hipSuccess;
+    if (!tmp)
+        e = hipMalloc (&tmp, box2_tmp_bytes (jd) + 64);
+    if (e != hipSuccess)
+        return e;
+    jd.tmp = static_cast<uint8_t *> (tmp);
+    e = launch_class (k, nullptr, 1, jd, jd.w_out, jd.n_rows, s);
+    if (!scratch)
+    {
+        const hipError_t e2 = hipStreamSynchronize (s);
+        (void) hipFree (tmp);
+        if (e == hipSuccess)
+            e = e2;
+    }
+    return e;
+}
+
 /* ---- per-device lanes: stream + grow-only staging buffers ---------------- */
 
 struct Lane
@@ -99,6 +138,7 @@ struct Lane
     hipStream_t stream = nullptr;
     void *src_buf = nullptr;  size_t src_cap = 0;
     void *dst_buf = nullptr;  size_t dst_cap = 0;
+    void *tmp_buf = nullptr;  size_t tmp_cap = 0;      /* intermediate image of the two-pass box filter */
 };
 
 constexpr int N_LANES = 4;
@@ -111,6 +151,20 @@ struct DeviceState
 };
 
 DeviceState g_devices [MAX_DEVICES];
+
+int
+lane_prepare_tmp (Lane &ln, size_t need)
+{
+    if (need > ln.tmp_cap)
+    {
+        if (ln.tmp_buf)
+            HIP_TRY (hipFree (ln.tmp_buf));
+        ln.tmp_buf = nullptr; ln.tmp_cap = 0;
+        HIP_TRY (hipMalloc (&ln.tmp_buf, need));
+        ln.tmp_cap = need;
+    }
+    return 0;
+}
 
 int
 lane_prepare (Lane &ln, size_t src_need, size_t dst_need)
@@ -152,6 +206,7 @@ struct SmolHipBatch
     int device = 0;
     uint32_t n_images = 0;
     JobDev *jobs_dev = nullptr;            /* all jobs, grouped by launch */
+    void *scratch = nullptr;               /* intermediate images of the two-pass box jobs */
     struct Group { KClass k; uint32_t first, count; JobDev rep; uint32_t max_w_out, max_rows, max_lds; };
     std::vector<Group> groups;
     uint64_t dominant_units = 0;
@@ -216,8 +271,7 @@ smol_hip_scale_rows_device (SmolHipPlan *plan,
 
     JobDev jd;
     fill_jobdev (jd, plan->job, pixels_in_dev, rowstride_in, dest_dev, rowstride_out, first_row, n_rows);
-    HIP_TRY (launch_class (classify (jd), nullptr, 1, jd, jd.w_out, n_rows,
-                           static_cast<hipStream_t> (hip_stream)));
+    HIP_TRY (launch_single (jd, static_cast<hipStream_t> (hip_stream)));
     return 0;
 }
 
@@ -271,7 +325,19 @@ smol_hip_scale_rows_host (SmolHipPlan *plan,
     JobDev jd;
     fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch, ln.dst_buf, (uint32_t) dst_pitch,
                  first_row, n_rows);
-    HIP_TRY (launch_class (classify (jd), nullptr, 1, jd, jd.w_out, n_rows, ln.stream));
+    {
+        /* the two-pass box filter keeps its intermediate image in the lane */
+        JobDev probe = jd;
+        if (classify (probe) == KC_BOX2)
+        {
+            rc = lane_prepare_tmp (ln, box2_tmp_bytes (probe) + 64);
+            if (rc)
+                return rc;
+            HIP_TRY (launch_single (jd, ln.stream, ln.tmp_buf));
+        }
+        else
+            HIP_TRY (launch_single (jd, ln.stream));
+    }
     HIP_TRY (hipMemcpy2DAsync (dest_host, rowstride_out, ln.dst_buf, dst_pitch,
                                out_row_bytes, n_rows, hipMemcpyDeviceToHost, ln.stream));
     HIP_TRY (hipStreamSynchronize (ln.stream));
@@ -352,11 +418,22 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4 || jobs [j].up_wide != g.rep.up_wide
                                  || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))
                 continue;
+            if (g.k == KC_BOX2 && jobs [j].wide != g.rep.wide)
+                continue;
             if (g.count == 65535)
                 break;
             taken [j] = true;
             sorted.push_back (jobs [j]);
             g.count++;
+            if (g.k == KC_BOX2)
+            {
+                /* max_w_out / max_rows / max_lds = pass-1 waves / pass-2 waves / pass-1 LDS bytes */
+                if (box2_h_tiles (jobs [j]) > g.max_w_out) g.max_w_out = box2_h_tiles (jobs [j]);
+                if (box2_v_tiles (jobs [j]) > g.max_rows) g.max_rows = box2_v_tiles (jobs [j]);
+                if (box2_h_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = box2_h_lds_bytes (jobs [j]);
+                units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
+                continue;
+            }
             if (g.k == KC_UP)
             {
                 if (up_lds_bytes (jobs [j]) > g.max_w_out) g.max_w_out = up_lds_bytes (jobs [j]);
@@ -383,13 +460,36 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             b->groups.push_back (g);
     }
 
-    hipError_t e = hipMalloc (reinterpret_cast<void **> (&b->jobs_dev), sorted.size () * sizeof (JobDev));
+    /* intermediate images of the two-pass box jobs: one allocation, carved up per job */
+    hipError_t e = hipSuccess;
+    {
+        size_t total = 0;
+        for (const JobDev &jd : sorted)
+            if (box2_is (jd))
+                total += align_up (box2_tmp_bytes (jd) + 64, 256);
+        if (total)
+        {
+            e = hipMalloc (&b->scratch, total);
+            size_t off = 0;
+            if (e == hipSuccess)
+                for (JobDev &jd : sorted)
+                    if (box2_is (jd))
+                    {
+                        jd.tmp = static_cast<uint8_t *> (b->scratch) + off;
+                        off += align_up (box2_tmp_bytes (jd) + 64, 256);
+                    }
+        }
+    }
+    if (e == hipSuccess)
+        e = hipMalloc (reinterpret_cast<void **> (&b->jobs_dev), sorted.size () * sizeof (JobDev));
     if (e == hipSuccess)
         e = hipMemcpy (b->jobs_dev, sorted.data (), sorted.size () * sizeof (JobDev), hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
         if (b->jobs_dev)
             (void) hipFree (b->jobs_dev);
+        if (b->scratch)
+            (void) hipFree (b->scratch);
         delete b;
         return -(int) e;
     }
@@ -424,7 +524,11 @@ smol_hip_batch_use_graph (SmolHipBatch *batch, int enable)
         {
             if (jd.n_rows == 0)
                 continue;
-            e = launch_class (classify (jd), nullptr, 1, jd, jd.w_out, jd.n_rows, cs);
+            /* (two-pass jobs keep the intermediate image the batch allocated for them) */
+            uint8_t *tmp_keep = jd.tmp;
+            const KClass kc = classify (jd);
+            jd.tmp = tmp_keep;
+            e = launch_class (kc, nullptr, 1, jd, jd.w_out, jd.n_rows, cs);
             if (e != hipSuccess)
                 break;
         }
@@ -480,6 +584,8 @@ smol_hip_batch_destroy (SmolHipBatch *batch)
     {
         if (batch->jobs_dev)
             (void) hipFree (batch->jobs_dev);
+        if (batch->scratch)
+            (void) hipFree (batch->scratch);
         if (batch->graph_exec)
             (void) hipGraphExecDestroy (batch->graph_exec);
         if (batch->graph)

@@ -23,9 +23,11 @@ struct JobDev
 {
     const uint8_t *src;            /* address of input row 0 (may lie before a row slab) */
     uint8_t *dst;                  /* address of output row `first_row'                  */
+    uint8_t *tmp;                  /* k_boxh/k_boxv: intermediate image (rows tmp_row0..tmp_row1 x w_out x 8 bytes) */
     uint32_t src_stride, dst_stride;
     uint32_t w_in, h_in, w_out, h_out;
     uint32_t first_row, n_rows;
+    uint32_t tmp_row0, tmp_row1;   /* k_boxh/k_boxv: first and last source row of the intermediate image */
     uint64_t frac0_x, step_x, frac0_y, step_y;
     uint32_t span_mul_x, span_mul_y;
     uint32_t out_perm;             /* v_perm selector, 32bpp -> 32bpp byte shuffle       */
@@ -45,6 +47,7 @@ struct JobDev
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
     uint8_t up_wide;               /* k_up: 0 64bpp class, 1 premul16 fast path, 2 table-driven 16-bit channels, 3 table-driven 32-bit */
+    uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
     uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
@@ -67,7 +70,7 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_UP, KC_DOWN, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_UP, KC_DOWN, KC_BOX2, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -123,7 +126,10 @@ tile_setup (JobDev &d)
     if (d.filter_h == F_BOX)
     {
         /* narrow boxes: one lane per column; wide ones: 8 lanes per column, 8 columns per tile */
-        box_lpc = (d.step_x > ((uint64_t) 24 << 16)) ? 8 : 1;
+        uint64_t lpc8_min = 24;                 /* ratio above which a column gets 8 lanes */
+        if (const char *e = getenv ("SMOL_TILE_BOX_LPC8_MIN"))
+            lpc8_min = (uint64_t) atoi (e);
+        box_lpc = (d.step_x > (lpc8_min << 16)) ? 8 : 1;
         cols = 64u / box_lpc;
         span_px = ((cols * d.step_x) >> 16) + 2;
         d.box_nmax = (uint32_t) (d.step_x >> 16) + 1;
@@ -481,6 +487,86 @@ down_lds_bytes (const JobDev &d)
     return 2u * pitch + 1024u + 16u;                        /* two row buffers + the inverse table */
 }
 
+/* host twin of the device box_span (smol_kernels.hip.h; closed form of smolscale.c's box precalc) */
+inline void
+box_span_host (uint64_t step, uint32_t dim_in, uint32_t k, uint32_t &o0, uint32_t &o1)
+{
+    const uint64_t b = (uint64_t) k * step;
+    const uint64_t e = b + step;
+    const uint32_t last = (uint32_t) (e >> 16);
+
+    o0 = (uint32_t) (b >> 16);
+    o1 = last > dim_in - 1 ? dim_in - 1 : last;
+}
+
+/* k_boxh + k_boxv: box on both axes in two passes through an intermediate image.
+ * Every box/box job of the 128bpp class, and 64bpp-class ones from a vertical ratio
+ * of 12 up (below that the single-pass k_tile has enough tiles and wins). */
+constexpr uint32_t BOXH_ROWS_HOST = 8;
+
+inline bool
+box2_setup (JobDev &d)
+{
+    if (d.filter_h != F_BOX || d.filter_v != F_BOX || getenv ("SMOL_NO_BOX2") || d.n_rows == 0)
+        return false;
+    uint64_t min_ratio = 12;
+    if (const char *e = getenv ("SMOL_BOX2_MIN"))
+        min_ratio = (uint64_t) atoi (e);
+    if (!d.wide && d.step_y < (min_ratio << 16))
+        return false;
+
+    uint32_t y0, y1, t;
+    box_span_host (d.step_y, d.h_in, d.first_row, y0, t);
+    box_span_host (d.step_y, d.h_in, d.first_row + d.n_rows - 1, t, y1);
+    d.tmp_row0 = y0;
+    d.tmp_row1 = y1;
+
+    /* source bytes a 64-column tile can span in one row, as 16-byte chunks (+ misalignment and reader slack) */
+    uint64_t span_px = ((64u * d.step_x) >> 16) + 2;
+    if (span_px > d.w_in)
+        span_px = d.w_in;
+    const uint32_t bytes = (uint32_t) span_px * d.bpp_in + 15 + 8;
+    d.span_px = (uint32_t) span_px;
+    d.span_chunks = (bytes + 15) / 16;
+    d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / d.span_chunks) + 1;
+    d.box_nmax = (uint32_t) (d.step_x >> 16) + 1;
+    if (2u * d.span_chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
+        return false;                           /* four waves' row buffers must fit the LDS */
+    d.box2 = 1;
+    return true;
+}
+
+inline bool
+box2_is (const JobDev &d)
+{
+    return d.box2 != 0;
+}
+
+inline size_t
+box2_tmp_bytes (const JobDev &d)
+{
+    return (size_t) (d.tmp_row1 - d.tmp_row0 + 1) * d.w_out * 8;
+}
+
+/* tiles (= waves) of each pass; a workgroup runs 4 of them */
+inline uint32_t
+box2_h_tiles (const JobDev &d)
+{
+    return ((d.w_out + 63u) / 64u) * ((d.tmp_row1 - d.tmp_row0 + BOXH_ROWS_HOST) / BOXH_ROWS_HOST);
+}
+
+inline uint32_t
+box2_v_tiles (const JobDev &d)
+{
+    return ((d.w_out + 63u) / 64u) * d.n_rows;
+}
+
+inline uint32_t
+box2_h_lds_bytes (const JobDev &d)
+{
+    return (d.wide ? DOWN_LUT_BYTES_FWD : 0u) + 4u * 2u * d.span_chunks * 16u + 32u;
+}
+
 inline KClass
 classify (JobDev &d)
 {
@@ -492,6 +578,8 @@ classify (JobDev &d)
         return KC_UP;
     if (down_setup (d))
         return KC_DOWN;
+    if (box2_setup (d))
+        return KC_BOX2;
     if (tile_ok (d))
         return KC_TILE;
     if (wtile_ok (d))
@@ -512,6 +600,7 @@ kclass_name (KClass k, const JobDev &d)
         case KC_POW2X: return "k_pow2x_batch";
         case KC_UP: return "k_up_batch";
         case KC_DOWN: return "k_down_batch";
+        case KC_BOX2: return "k_boxh_batch + k_boxv_batch";
         case KC_TILE: return "k_tile_batch";
         case KC_WTILE: return "k_wtile_batch";
         case KC_WAVEPX: return "k_wavepx_batch<false>";

@@ -1,0 +1,281 @@
+/* smol_kernel_box2.hip.h -- k_boxh + k_boxv: the box filter on both axes as TWO
+ * passes through an intermediate image, for strong minification (photo ->
+ * thumbnail) and for every box job of the 128bpp class. Included after
+ * smol_kernel_tile.hip.h (packed-lane helpers, LDS staging, pixel stores).
+ *
+ * A single-pass tile kernel has one lane per output column and one wave per 64
+ * columns x a few rows: at a ratio of 20 a 200 x 150 thumbnail is a few hundred
+ * waves that each walk 1300 source pixels per row, far too few to fill 256 CUs.
+ * Splitting the axes puts the parallelism where the work is:
+ *
+ *   k_boxh  one wave per 64 output columns x BOXH_ROWS SOURCE rows (h_in / 8 x
+ *           w_out / 64 waves). Rows arrive in LDS by LDS-DMA (double-buffered, as in
+ *           k_tile); a lane sums its column's span (smolscale-generic.c:1427-1556:
+ *           left edge weighted, interior in full, right edge weighted, then the
+ *           span_mul normalisation) and writes the horizontal result -- four 16-bit
+ *           channels, 8 bytes -- to the intermediate image (coalesced).
+ *   k_boxv  lane = output column, one wave per 64 columns x 1 output row: sums the
+ *           intermediate rows of the box (:2026-2260) with 8-byte coalesced loads,
+ *           normalises, packs and stores the pixel.
+ *
+ * The intermediate image is h_rows x w_out x 8 bytes (a few per cent of the source),
+ * allocated by the runtime. 64bpp class: values are 8 bit, two per register in
+ * 16-bit lanes (the Px2 arithmetic of k_tile). 128bpp class: pixels go through
+ * unpack_word<true> / store_px<true> with the tables in LDS, sums are 32 bit. */
+
+#pragma once
+
+namespace smolhip {
+
+constexpr uint32_t BOXH_ROWS = 8;       /* source rows per k_boxh wave */
+
+/* One staged source pixel at byte offset `off' of the LDS row (any alignment). */
+__device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t *rowb, uint32_t off)
+{
+    const uint32_t w = lds_load_unaligned (rowb, off);
+    return (J.bpp_in == 3) ? (w | 0xff000000u) : w;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const uint8_t *lut_lds,
+                                           const uint32_t lane, const uint32_t tile)
+{
+    const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+    const uint32_t tx = tile % tiles_x;
+    const uint32_t tr = tile / tiles_x;
+    const uint32_t r0 = J.tmp_row0 + tr * BOXH_ROWS;                /* first source row of this wave */
+
+    if (r0 > J.tmp_row1)
+        return;
+
+    const uint32_t r1 = (r0 + BOXH_ROWS - 1 < J.tmp_row1) ? r0 + BOXH_ROWS - 1 : J.tmp_row1;
+    const uint32_t x0 = tx * TILE_COLS;
+    const uint32_t xn = (x0 + TILE_COLS < J.w_out) ? x0 + TILE_COLS : J.w_out;
+    const uint32_t x = x0 + lane;
+    const uint32_t xc = (x < xn) ? x : xn - 1;
+    const uint32_t bpp = J.bpp_in;
+
+    /* this lane's span: pixels o0 (weight wl), o0+1 .. o1-1 (in full), o1 (weight fr) */
+    uint32_t o0, o1, fr, wl, sx0, sx1, t0, t1, t2;
+    box_span (J.step_x, J.w_in, xc, o0, o1, fr, wl);
+    box_span (J.step_x, J.w_in, x0, sx0, t0, t1, t2);
+    box_span (J.step_x, J.w_in, xn - 1, t0, sx1, t1, t2);
+    const uint32_t n_int = o1 - o0 - 1;
+    const uint32_t g0 = sx0 * bpp, g1 = (sx1 + 1) * bpp;
+    const uint32_t row_pitch = J.span_chunks * 16u;
+    const uint32_t first_ofs = (o0 - sx0) * bpp;
+    const LutLds lut (lut_lds);
+    const uintptr_t src_base = (uintptr_t) J.src;
+
+    tile_stage<true, false> (J, lds, lane, r0, 1, g0, g1);
+
+    for (uint32_t r = r0; r <= r1; r++)
+    {
+        const uint32_t cur = (r - r0) & 1u;
+        smol_wait_vmcnt0 ();
+        smol_wave_sync ();
+        if (r < r1)
+            tile_stage<true, false> (J, lds + (cur ^ 1u) * row_pitch, lane, r + 1, 1, g0, g1);
+
+        const uint8_t *rowb = lds + cur * row_pitch;
+        const uint32_t mis = (uint32_t) (src_base + (size_t) r * J.src_stride + g0) & 15u;
+        uint32_t off = first_ofs + mis;
+        u32x2a8 res;
+
+        if (WIDE)
+        {
+            uint32_t acc [4], c [4];
+            unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc [i] = ((c [i] * wl) >> 8) & 0x00ffffffu;
+            off += bpp;
+            for (uint32_t k = 0; k < J.box_nmax; k++)
+            {
+                if (k < n_int)
+                {
+                    unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        acc [i] += c [i];
+                    off += bpp;
+                }
+            }
+            unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc [i] = box_scale<true> (acc [i] + (((c [i] * fr) >> 8) & 0x00ffffffu), J.span_mul_x);
+            res = u32x2a8 { acc [0] | (acc [1] << 16), acc [2] | (acc [3] << 16) };
+        }
+        else
+        {
+            /* unassociated input is premultiplied per pixel (smolscale-generic.c:238-244, 415-464) */
+            const bool pm = J.unassoc_in;
+            const uint32_t ain = J.pos_in [3];
+            uint32_t w = box2_px_word (J, rowb, off);
+            Px2 a = px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), wl);
+            off += bpp;
+            for (uint32_t k = 0; k < J.box_nmax; k++)
+            {
+                if (k < n_int)
+                {
+                    w = box2_px_word (J, rowb, off);
+                    a = px2_add (a, pm ? premul_px2 (w, ain) : px2_from_word (w));
+                    off += bpp;
+                }
+            }
+            w = box2_px_word (J, rowb, off);
+            a = px2_add (a, px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), fr));
+            a = px2_box_scale (a, J.span_mul_x);
+            res = u32x2a8 { a.lo, a.hi };
+        }
+
+        if (x < xn)
+            *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (gptr (J.tmp) + ((size_t) (r - J.tmp_row0) * J.w_out + x) * 8) = res;
+    }
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_lds,
+                                           const uint32_t lane, const uint32_t tile)
+{
+    const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+    const uint32_t tx = tile % tiles_x;
+    const uint32_t row = tile / tiles_x;                            /* output row of the strip */
+
+    if (row >= J.n_rows)
+        return;
+
+    const uint32_t x = tx * TILE_COLS + lane;
+    if (x >= J.w_out)
+        return;
+
+    const LutLds lut (lut_lds);
+    uint32_t y0, y1, w2, w1;
+    box_span (J.step_y, J.h_in, J.first_row + row, y0, y1, w2, w1);
+    /* 128bpp-class rows weight the last row by w2 - 1 and skip it when w2 == 0
+     * (smolscale-generic.c:2236-2253); 64bpp-class rows use w2 as is (:2042-2069) */
+    const uint32_t last_w = WIDE ? (w2 ? w2 - 1 : 0) : w2;
+    const uint32_t y_end = (WIDE && w2 == 0) ? y1 - 1 : y1;
+    const gbyte *ip = gptr (J.tmp) + ((size_t) (y0 - J.tmp_row0) * J.w_out + x) * 8;
+    const size_t ipitch = (size_t) J.w_out * 8;
+    uint8_t *out_row = J.dst + (size_t) row * J.dst_stride;
+
+    if (WIDE)
+    {
+        uint32_t acc [4] = { 0, 0, 0, 0 };
+        for (uint32_t r = y0; r <= y_end; r++, ip += ipitch)
+        {
+            const u32x2a8 v = *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip);
+            const uint32_t c [4] = { v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16 };
+            const uint32_t w = (r == y0) ? w1 : ((r == y1) ? last_w : 0x10000u);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc [i] += (w == 0x10000u) ? c [i] : (((c [i] * w) >> 8) & 0x00ffffffu);
+        }
+        uint32_t o [4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            o [i] = box_scale<true> (acc [i], J.span_mul_y);
+        store_px<true> (J, out_row, x, o, lut);
+    }
+    else
+    {
+        Px2 acc = { 0, 0 };
+        for (uint32_t r = y0; r <= y_end; r++, ip += ipitch)
+        {
+            const u32x2a8 v = *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip);
+            const Px2 p = { v.x, v.y };
+            if (r == y0)
+                acc = px2_add (acc, px2_mulw (p, w1));
+            else if (r == y1)
+                acc = px2_add (acc, px2_mulw (p, last_w));
+            else
+                acc = px2_add (acc, p);
+        }
+        tile_store<OUT_ANY> (J, out_row, x, px2_box_scale (acc, J.span_mul_y));
+    }
+}
+
+/* 4 waves per workgroup, each on its own tile; the 128bpp class shares one LDS copy of the tables */
+template <bool WIDE>
+__device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    static uint8_t lut_lds [LUT_LDS_BYTES];
+    if (WIDE)
+        lut_fill_lds (lut_lds, 0, 1);
+    boxh_body<WIDE> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+#else
+    const uint32_t wave = threadIdx.x >> 6;
+    if (WIDE)
+    {
+        lut_fill_lds (lds, threadIdx.x, 256);
+        __syncthreads ();
+    }
+    const uint32_t lut_bytes = WIDE ? ((LUT_LDS_BYTES + 15u) & ~15u) : 0u;
+    boxh_body<WIDE> (J, lds + lut_bytes + wave * 2u * J.span_chunks * 16u, lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+#endif
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void boxv_entry (const JobDev &J, uint8_t *lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    static uint8_t lut_lds [LUT_LDS_BYTES];
+    if (WIDE)
+        lut_fill_lds (lut_lds, 0, 1);
+    boxv_body<WIDE> (J, lut_lds, threadIdx.x, blockIdx.x);
+#else
+    if (WIDE)
+    {
+        lut_fill_lds (lds, threadIdx.x, 256);
+        __syncthreads ();
+    }
+    boxv_body<WIDE> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6));
+#endif
+}
+
+#ifdef SMOL_KERNEL_EMU
+__global__ void k_boxh_one (const JobDev J)
+{
+    if (J.wide) boxh_entry<true> (J, smol_dyn_lds); else boxh_entry<false> (J, smol_dyn_lds);
+}
+
+__global__ void k_boxv_one (const JobDev J)
+{
+    if (J.wide) boxv_entry<true> (J, smol_dyn_lds); else boxv_entry<false> (J, smol_dyn_lds);
+}
+#else
+template <bool WIDE>
+__global__ void __launch_bounds__ (256)
+k_boxh_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = jobs [blockIdx.y];
+    boxh_entry<WIDE> (J, smol_dyn_lds);
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__ (256)
+k_boxh_one (const JobDev J)
+{
+    boxh_entry<WIDE> (J, smol_dyn_lds);
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__ (256)
+k_boxv_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = jobs [blockIdx.y];
+    boxv_entry<WIDE> (J, smol_dyn_lds);
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__ (256)
+k_boxv_one (const JobDev J)
+{
+    boxv_entry<WIDE> (J, smol_dyn_lds);
+}
+#endif
+
+} /* namespace smolhip */

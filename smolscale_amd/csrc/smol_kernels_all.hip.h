@@ -6,3 +6,4 @@
 #include "smol_kernel_pow2x.hip.h"
 #include "smol_kernel_up.hip.h"
 #include "smol_kernel_down.hip.h"
+#include "smol_kernel_box2.hip.h"

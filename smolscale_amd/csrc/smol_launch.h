@@ -1,5 +1,5 @@
 /* smol_launch.h -- launch wrappers of the kernel families, one translation unit each
- * (smol_k_stream.hip, smol_k_updown.hip, smol_k_tile0-3.hip, smol_k_misc.hip). A launch
+ * (smol_k_stream.hip, smol_k_updown.hip, smol_k_tile0-3.hip, smol_k_box2.hip, smol_k_misc.hip). A launch
  * either reads descriptors from device memory (jobs_dev != NULL, one per blockIdx.y)
  * or takes the single descriptor `rep' by value as kernel argument. */
 
@@ -34,6 +34,9 @@ tile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStr
         default: tile_ts3 (jobs_dev, rep, grid, lds, s); break;
     }
 }
+/* two passes through rep.tmp / jobs [i].tmp; h_tiles, v_tiles = waves of each pass (group maxima) */
+void box2 (const JobDev *jobs_dev, const JobDev &rep, uint32_t n_jobs, uint32_t h_tiles, uint32_t v_tiles,
+           uint32_t h_lds, hipStream_t s);
 void wtile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
 void wavepx (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, bool wide, hipStream_t s);
 void general (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, bool wide, hipStream_t s);

@@ -101,7 +101,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
     JobDev J;
     fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
     KClass k = classify (J);
-    if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_UP || k == KC_DOWN || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
+    if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_UP || k == KC_DOWN || k == KC_BOX2 || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
     if (force_general == 2 && tile_ok (J))
         k = KC_TILE;                      /* force the tiled kernel where the fast path would win */
@@ -132,6 +132,15 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
             case 1: run_pow2x_h<1> (J, gx); break;
             default: run_pow2x_h<2> (J, gx); break;
         }
+        return 0;
+    }
+
+    if (k == KC_BOX2)
+    {
+        std::vector<uint8_t> tmp (box2_tmp_bytes (J) + 64);
+        J.tmp = tmp.data ();
+        run_grid_coop (box2_h_tiles (J), 64, box2_h_lds_bytes (J), [&] { k_boxh_one (J); });
+        run_grid_coop (box2_v_tiles (J), 64, 0, [&] { k_boxv_one (J); });
         return 0;
     }
 

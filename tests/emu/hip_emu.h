@@ -8,7 +8,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __constant__ static const
+#define __constant__ const
 #define __launch_bounds__(...)
 #define __shared__ static
 

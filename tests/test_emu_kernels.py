@@ -181,6 +181,33 @@ def test_emulated_down_kernel_table_driven_flavours():
     assert {(0, 1), (1, 1)} <= kinds
 
 
+def test_emulated_two_pass_box_kernels():
+    """k_boxh + k_boxv: box on both axes through the intermediate image; 64bpp class at
+    ratios >= 12 and every 128bpp-class box job, all types, odd strides, row strips."""
+    rng = random.Random(2468)
+    seen = set()
+    for it in range(70):
+        w_out = rng.choice([1, 2, 3, 7, 40, 64, 65, 100])
+        h_out = rng.choice([1, 2, 3, 5, 9])
+        w_in = min(int(w_out * rng.uniform(8.5, 40)) + 1, 4000)
+        h_in = min(int(h_out * rng.uniform(8.5, 40)) + 1, 400)
+        t_in, t_out, srgb = rng.randrange(10), rng.randrange(10), rng.choice([0, 0, 1])
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        if job.filter_h != 3 or job.filter_v != 3:
+            continue
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 3, 4, 16])
+        sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        if k == 10:
+            seen.add(job.wide)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n, k)
+    assert seen == {0, 1}
+
+
 def test_emulated_kernels_match_golden_subset():
     for (t_in, w_in, h_in, t_out, w_out, h_out, srgb, seed, valid), want in C.matrix_cases(stride=23):
         src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)

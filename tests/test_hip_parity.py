@@ -186,6 +186,48 @@ def test_down_kernel_srgb_linear_flavours():
             assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
 
 
+def test_two_pass_box_thumbnails_single_and_batched():
+    """k_boxh + k_boxv (strong minification; every 128bpp-class box): host API, device API
+    (temporary intermediate image), one batch with its own scratch, and the same batch as a hipGraph."""
+    shapes = [
+        (8, 4000, 300, 8, 200, 15, 0), (8, 4000, 300, 8, 200, 15, 1), (4, 2000, 900, 4, 64, 30, 0),
+        (0, 3000, 2000, 1, 100, 5, 1), (5, 999, 777, 9, 1, 1, 1), (9, 1300, 500, 2, 65, 9, 0),
+    ]
+    lib = sm.lib()
+    images, bufs, wants = [], [], []
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in enumerate(shapes):
+        sin = w_in * H.bpp(t_in) + (3 if k & 1 else 0)
+        src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin)
+        assert np.array_equal(H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin), want), ("host", k)
+        got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, src_misalign=k & 3, dst_misalign=k & 1)
+        assert np.array_equal(got, want), ("device", k)
+        dsrc = sm.DeviceBuffer(src.size + 16)
+        dsrc.upload(src)
+        ddst = sm.DeviceBuffer(want.size + 16)
+        ddst.fill(0)
+        im = sm.SmolHipImage()
+        im.job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        im.src, im.dst = dsrc.ptr, ddst.ptr
+        im.rowstride_in, im.rowstride_out = sin, w_out * H.bpp(t_out)
+        im.first_row, im.n_rows = 0, h_out
+        images.append(im)
+        bufs.append((dsrc, ddst))
+        wants.append(want)
+    batch = sm.HipBatch(images)
+    for use_graph in (False, True):
+        batch.use_graph(use_graph)
+        batch.launch()
+        sm.check(lib.smol_hip_device_synchronize(0))
+        for k, (want, (dsrc, ddst)) in enumerate(zip(wants, bufs)):
+            assert np.array_equal(ddst.download(want.size), want), ("batch", use_graph, k)
+            ddst.fill(0)
+    batch.destroy()
+    for dsrc, ddst in bufs:
+        dsrc.free()
+        ddst.free()
+
+
 def test_tile_kernel_wide_images_and_box_shapes():
     """Geometries that select every k_tile layout: 4 columns per lane (wide, few taps),
     one column per lane, box with 1 and with 8 lanes per column, box on one axis only."""

@@ -50,5 +50,5 @@ for it in range(N):
     rb = w_out * H.bpp(t_out)
     if not np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want, n, rb, sout)):
         bad += 1
-        print("MISMATCH", fam, (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n), "dev" if it & 1 else "host", flush=True)
+        print("MISMATCH it=%d" % it, fam, (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n), "dev" if it & 1 else "host", flush=True)
 print("cases", N, "bad", bad, fam_count, "%.0f s" % (time.time() - t0))
