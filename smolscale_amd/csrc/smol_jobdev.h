@@ -14,6 +14,10 @@ namespace smolhip {
 
 enum : uint8_t { F_COPY = 0, F_ONE = 1, F_BILINEAR = 2, F_BOX = 3 };
 
+/* LDS copy of the parity tables: four inverse tables (4 x 1 KB), from_srgb (512 B), to_srgb (2 KB)
+ * and the fused opaque-pixel linearisation (512 B); layout in smol_kernels.hip.h (LutLds) */
+constexpr uint32_t SMOL_LUT_LDS_BYTES = 4 * 1024 + 512 + 2048 + 512;
+
 /* k_pow2x input kinds: 32/24-bit input x 64bpp/128bpp-class math */
 enum : int { PX_N32 = 0, PX_N24 = 1, PX_W32 = 2, PX_W24 = 3, PX_W16 = 4 /* 32-bit in, premul16 without sRGB */ };
 
@@ -218,7 +222,7 @@ tile_lds_bytes (const JobDev &d)
     uint32_t bytes = 2 * d.group_rows * d.span_chunks * 16 + 32;
     if (d.wide)
         bytes += d.group_rows * d.span_px * ((d.p16 && d.linear) ? 16 : 8) + 16   /* converted rows (k_wtile) */
-                 + (4 * 1024 + 512 + 2048);                                       /* + LDS copy of the tables */
+                 + SMOL_LUT_LDS_BYTES;                                            /* + LDS copy of the tables */
     return bytes;
 }
 
@@ -351,7 +355,7 @@ pow2x_blocks (const JobDev &d)
 /* k_up: bilinear magnification on both axes, 64bpp class. A tile of tile_rows
  * output rows may touch at most UP_NSRC source rows (smol_kernel_up.hip.h):
  * rows r = 0..TR-1 span floor ((TR-1) * step) + 3 source rows at most. */
-constexpr uint32_t DOWN_LUT_BYTES_FWD = (4 * 1024 + 512 + 2048 + 15) & ~15u;   /* LDS copy of the six tables */
+constexpr uint32_t DOWN_LUT_BYTES_FWD = (SMOL_LUT_LDS_BYTES + 15) & ~15u;   /* LDS copy of the tables */
 constexpr uint32_t UP_NSRC_HOST = 10;
 constexpr uint32_t UP_NSRC_W_HOST = 8;      /* premul16 flavour */
 
@@ -421,7 +425,7 @@ up_blocks (const JobDev &d)
  * mode 1: any other job whose channels fit 16 bits (sRGB-linear with 8-bit alpha);
  * mode 2: premul16 + sRGB-linear (19-bit channels). Modes 1-2 take any input type
  * and alignment and run 4 waves per workgroup around one LDS copy of the tables. */
-constexpr uint32_t DOWN_LUT_BYTES = (4 * 1024 + 512 + 2048 + 15) & ~15u;
+constexpr uint32_t DOWN_LUT_BYTES = (SMOL_LUT_LDS_BYTES + 15) & ~15u;
 
 inline bool
 down_setup (JobDev &d)

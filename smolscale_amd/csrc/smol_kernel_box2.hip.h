@@ -90,17 +90,27 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             for (int i = 0; i < 4; i++)
                 acc [i] = ((c [i] * wl) >> 8) & 0x00ffffffu;
             off += bpp;
-            for (uint32_t k = 0; k < J.box_nmax; k++)
+            /* interior pixels four at a time: the LDS reads of a group are independent */
+            for (uint32_t k = 0; k < J.box_nmax; k += 4)
             {
-                if (k < n_int)
-                {
-                    unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
+                uint32_t w4 [4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        acc [i] += c [i];
-                    off += bpp;
+                for (uint32_t u = 0; u < 4; u++)
+                    w4 [u] = (k + u < n_int) ? box2_px_word (J, rowb, off + u * bpp) : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++)
+                {
+                    if (k + u < n_int)
+                    {
+                        unpack_word<true> (J, w4 [u], c, lut);
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            acc [i] += c [i];
+                    }
                 }
+                off += 4u * bpp;
             }
+            off = first_ofs + mis + (n_int + 1u) * bpp;
             unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -115,15 +125,60 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             uint32_t w = box2_px_word (J, rowb, off);
             Px2 a = px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), wl);
             off += bpp;
-            for (uint32_t k = 0; k < J.box_nmax; k++)
+            if (bpp == 3)
             {
-                if (k < n_int)
+                /* 24-bit pixels, whole groups of 4 = 12 bytes = 3 dwords (b0 b1 b2 b0 | b1 b2 b0 b1 |
+                 * b2 b0 b1 b2): every dword position is summed in packed 16-bit lanes (at most 64
+                 * groups x 255 per lane) and the twelve partial sums are sorted out once at the end */
+                const uint32_t ngrp = n_int >> 2;
+                uint32_t s0l = 0, s0h = 0, s1l = 0, s1h = 0, s2l = 0, s2h = 0;
+                const uint32_t sh = off & 3u;
+                const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
+                for (uint32_t g = 0; g < J.box_nmax; g += 4, pp += 3)
                 {
-                    w = box2_px_word (J, rowb, off);
-                    a = px2_add (a, pm ? premul_px2 (w, ain) : px2_from_word (w));
-                    off += bpp;
+                    if ((g >> 2) < ngrp)
+                    {
+                        const uint32_t q0 = pp [0], q1 = pp [1], q2 = pp [2], q3 = pp [3];
+                        const uint32_t d0 = __builtin_amdgcn_alignbyte (q1, q0, sh);
+                        const uint32_t d1 = __builtin_amdgcn_alignbyte (q2, q1, sh);
+                        const uint32_t d2 = __builtin_amdgcn_alignbyte (q3, q2, sh);
+                        s0l = as_u32 (as_u16x2 (s0l) + as_u16x2 (d0 & PAIR_MASK));
+                        s0h = as_u32 (as_u16x2 (s0h) + as_u16x2 ((d0 >> 8) & PAIR_MASK));
+                        s1l = as_u32 (as_u16x2 (s1l) + as_u16x2 (d1 & PAIR_MASK));
+                        s1h = as_u32 (as_u16x2 (s1h) + as_u16x2 ((d1 >> 8) & PAIR_MASK));
+                        s2l = as_u32 (as_u16x2 (s2l) + as_u16x2 (d2 & PAIR_MASK));
+                        s2h = as_u32 (as_u16x2 (s2h) + as_u16x2 ((d2 >> 8) & PAIR_MASK));
+                    }
                 }
+                /* byte 0 of a pixel: d0.b0 d0.b3 d1.b2 d2.b1; byte 1: d0.b1 d1.b0 d1.b3 d2.b2; byte 2: d0.b2 d1.b1 d2.b0 d2.b3 */
+                const uint32_t b0 = (s0l & 0xffffu) + (s0h >> 16) + (s1l >> 16) + (s2h & 0xffffu);
+                const uint32_t b1 = (s0h & 0xffffu) + (s1l & 0xffffu) + (s1h >> 16) + (s2l >> 16);
+                const uint32_t b2 = (s0l >> 16) + (s1h & 0xffffu) + (s2l & 0xffffu) + (s2h >> 16);
+                Px2 grp;
+                grp.lo = b0 | (b2 << 16);
+                grp.hi = b1 | ((ngrp * 4u * 255u) << 16);                 /* alpha = 0xff per pixel */
+                a = px2_add (a, grp);
+                off += ngrp * 12u;
+                /* the 0-3 pixels left over */
+                for (uint32_t k = ngrp * 4u; k < n_int; k++, off += 3u)
+                    a = px2_add (a, px2_from_word (box2_px_word (J, rowb, off)));
             }
+            else
+            {
+            /* interior pixels four at a time (a zero word adds nothing in this class) */
+            for (uint32_t k = 0; k < J.box_nmax; k += 4)
+            {
+                uint32_t w4 [4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++)
+                    w4 [u] = (k + u < n_int) ? box2_px_word (J, rowb, off + u * bpp) : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++)
+                    a = px2_add (a, pm ? premul_px2 (w4 [u], ain) : px2_from_word (w4 [u]));
+                off += 4u * bpp;
+            }
+            }
+            off = first_ofs + mis + (n_int + 1u) * bpp;
             w = box2_px_word (J, rowb, off);
             a = px2_add (a, px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), fr));
             a = px2_box_scale (a, J.span_mul_x);
@@ -164,14 +219,22 @@ __device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_l
     if (WIDE)
     {
         uint32_t acc [4] = { 0, 0, 0, 0 };
-        for (uint32_t r = y0; r <= y_end; r++, ip += ipitch)
+        /* rows eight at a time: the loads of a group are in flight together */
+        for (uint32_t r = y0; r <= y_end; r += 8, ip += 8 * ipitch)
         {
-            const u32x2a8 v = *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip);
-            const uint32_t c [4] = { v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16 };
-            const uint32_t w = (r == y0) ? w1 : ((r == y1) ? last_w : 0x10000u);
+            u32x2a8 v8 [8];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                acc [i] += (w == 0x10000u) ? c [i] : (((c [i] * w) >> 8) & 0x00ffffffu);
+            for (uint32_t u = 0; u < 8; u++)
+                v8 [u] = (r + u <= y_end) ? *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip + u * ipitch) : u32x2a8 { 0, 0 };
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++)
+            {
+                const uint32_t c [4] = { v8 [u].x & 0xffffu, v8 [u].x >> 16, v8 [u].y & 0xffffu, v8 [u].y >> 16 };
+                const uint32_t w = (r + u == y0) ? w1 : ((r + u == y1) ? last_w : 0x10000u);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += (w == 0x10000u) ? c [i] : (((c [i] * w) >> 8) & 0x00ffffffu);
+            }
         }
         uint32_t o [4];
 #pragma unroll
@@ -182,16 +245,23 @@ __device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_l
     else
     {
         Px2 acc = { 0, 0 };
-        for (uint32_t r = y0; r <= y_end; r++, ip += ipitch)
+        for (uint32_t r = y0; r <= y_end; r += 8, ip += 8 * ipitch)
         {
-            const u32x2a8 v = *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip);
-            const Px2 p = { v.x, v.y };
-            if (r == y0)
-                acc = px2_add (acc, px2_mulw (p, w1));
-            else if (r == y1)
-                acc = px2_add (acc, px2_mulw (p, last_w));
-            else
-                acc = px2_add (acc, p);
+            u32x2a8 v8 [8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++)
+                v8 [u] = (r + u <= y_end) ? *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip + u * ipitch) : u32x2a8 { 0, 0 };
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++)
+            {
+                const Px2 p = { v8 [u].x, v8 [u].y };
+                if (r + u == y0)
+                    acc = px2_add (acc, px2_mulw (p, w1));
+                else if (r + u == y1)
+                    acc = px2_add (acc, px2_mulw (p, last_w));
+                else
+                    acc = px2_add (acc, p);
+            }
         }
         tile_store<OUT_ANY> (J, out_row, x, px2_box_scale (acc, J.span_mul_y));
     }

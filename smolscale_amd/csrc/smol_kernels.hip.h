@@ -93,14 +93,20 @@ struct LutConst
     __device__ __forceinline__ uint32_t inv_p16l (uint32_t a) const { return smol_inv_p16l_lut [a]; }
     __device__ __forceinline__ uint32_t from_srgb (uint32_t v) const { return smol_from_srgb_lut [v]; }
     __device__ __forceinline__ uint32_t to_srgb (uint32_t v) const { return smol_to_srgb_lut [v]; }
+    /* opaque pixel (alpha = 255), sRGB byte -> premultiplied linear: the chain of unpack_word */
+    __device__ __forceinline__ uint32_t opaque_lin (uint32_t v) const
+    {
+        const uint32_t u = (uint32_t) ((((uint64_t) v * smol_inv_p8_lut [255]) >> 13) & 0xffu);
+        return premul8l (smol_from_srgb_lut [u], 255u);
+    }
 };
 
-constexpr uint32_t LUT_LDS_BYTES = 4 * 1024 + 512 + 2048;
+constexpr uint32_t LUT_LDS_BYTES = SMOL_LUT_LDS_BYTES;
 
 struct LutLds
 {
     const uint32_t *p8, *p8l, *p16, *p16l;
-    const uint16_t *fs;
+    const uint16_t *fs, *oq;
     const uint8_t *ts;
 
     __device__ __forceinline__ explicit LutLds (const uint8_t *base)
@@ -109,6 +115,7 @@ struct LutLds
           p16 (reinterpret_cast<const uint32_t *> (base + 2048)),
           p16l (reinterpret_cast<const uint32_t *> (base + 3072)),
           fs (reinterpret_cast<const uint16_t *> (base + 4096)),
+          oq (reinterpret_cast<const uint16_t *> (base + 6656)),
           ts (base + 4608) {}
 
     __device__ __forceinline__ uint32_t inv_p8 (uint32_t a) const { return p8 [a]; }
@@ -117,6 +124,7 @@ struct LutLds
     __device__ __forceinline__ uint32_t inv_p16l (uint32_t a) const { return p16l [a]; }
     __device__ __forceinline__ uint32_t from_srgb (uint32_t v) const { return fs [v]; }
     __device__ __forceinline__ uint32_t to_srgb (uint32_t v) const { return ts [v]; }
+    __device__ __forceinline__ uint32_t opaque_lin (uint32_t v) const { return oq [v]; }
 };
 
 /* cooperative copy of the tables into LDS (caller synchronises afterwards) */
@@ -137,6 +145,10 @@ __device__ __forceinline__ void lut_fill_lds (uint8_t *base, uint32_t tid, uint3
     uint32_t *t = reinterpret_cast<uint32_t *> (base + 4608);
     for (uint32_t i = tid; i < 512; i += nthreads)
         t [i] = tsrc [i];
+    /* fused table for opaque pixels: exactly what unpack_word computes for alpha = 255 */
+    uint16_t *o = reinterpret_cast<uint16_t *> (base + 6656);
+    for (uint32_t i = tid; i < 256; i += nthreads)
+        o [i] = (uint16_t) LutConst ().opaque_lin (i);
 }
 
 /* premultiplied -> unassociated 8 bit via the inverse table: :227-236, 246-259 */
@@ -200,7 +212,14 @@ __device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32
         return;
     }
 
-    if (WIDE && J.linear)
+    if (WIDE && J.linear && J.bpp_in == 3)
+    {
+        /* 24-bit input is opaque: the whole chain below is one table look-up per channel */
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            c [i] = lut.opaque_lin (c [i]);
+    }
+    else if (WIDE && J.linear)
     {
 #pragma unroll
         for (int i = 0; i < 3; i++)
