@@ -118,9 +118,12 @@ def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srg
     ms = batch.time(max(warmup, n_settle), iters)
     per_step_ms = ms / iters
     algo = total_in + total_out
+    # SURVEY 8d asks for min and median too: 20 single-step timings (hipEvents around one step each)
+    singles = sorted(batch.time(0, 1) * 1e3 for _ in range(20))
     line = {
         "config": name, "desc": desc, "kernel": kname, "launches_per_step": n_launches,
         "step_us": round(per_step_ms * 1e3, 2),
+        "step_us_min": round(singles[0], 2), "step_us_median": round(singles[len(singles) // 2], 2),
         "algorithmic_bytes_per_step": algo,
         "GBps": round(algo / (per_step_ms * 1e-3) / 1e9, 1),
         "frac_of_8TBps": round(algo / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
