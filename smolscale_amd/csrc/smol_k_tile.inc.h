@@ -23,6 +23,16 @@ launch_tile_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
         hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, dim3 (64), lds, s, rep);
 }
 
+template <int TS, int HM>
+void
+launch_tile_kv (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, 1, true>), grid, dim3 (64), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, 1, true>), grid, dim3 (64), lds, s, rep);
+}
+
 template <int TS>
 void
 launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
@@ -37,6 +47,17 @@ launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t l
             case 1:  launch_tile_k<TS, 1, 4> (jobs_dev, rep, grid, lds, s); break;
             case 2:  launch_tile_k<TS, 2, 4> (jobs_dev, rep, grid, lds, s); break;
             default: launch_tile_k<TS, 3, 4> (jobs_dev, rep, grid, lds, s); break;
+        }
+        return;
+    }
+    if (rep.tile_vcopy)
+    {
+        /* horizontal bilinear minification with a vertical copy (e.g. width-only resizes, BASELINE config 4) */
+        switch (hm)
+        {
+            case 1:  launch_tile_kv<TS, 1> (jobs_dev, rep, grid, lds, s); break;
+            case 2:  launch_tile_kv<TS, 2> (jobs_dev, rep, grid, lds, s); break;
+            default: launch_tile_kv<TS, 3> (jobs_dev, rep, grid, lds, s); break;
         }
         return;
     }

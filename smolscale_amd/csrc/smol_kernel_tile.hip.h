@@ -487,7 +487,7 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
  * the register path, single LDS buffer). CPL: adjacent output columns per lane
  * (a tile is 64*CPL columns wide) -- amortises the wave's scalar bookkeeping
  * when there is little vector work per column (magnification). */
-template <int TAP, int HM, int OUT, bool STAGE_PREMUL, int CPL>
+template <int TAP, int HM, int OUT, bool STAGE_PREMUL, int CPL, bool VCOPY = false>
 __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 {
     constexpr bool HBOX = (HM >= 4);
@@ -584,8 +584,10 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
      * sched[k >> 6]) and fetched with v_readlane in the row loop: the wave's
      * scalar unit, shared by the whole CU, stays out of the 64-bit position
      * arithmetic. */
-    const bool vbox = (J.filter_v == F_BOX);
-    const bool vpair = (J.filter_v == F_BILINEAR);
+    /* VCOPY: the vertical axis is a copy (source row = output row), known at compile time:
+     * no schedule, one output row per staged row */
+    const bool vbox = !VCOPY && (J.filter_v == F_BOX);
+    const bool vpair = !VCOPY && (J.filter_v == F_BILINEAR);
     const uint32_t hv = vpair ? J.halv_v : 0u;
     const uint32_t nsy = 1u << hv;
     const uint32_t vlag = vpair ? 1u : 0u;
@@ -593,9 +595,9 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     const uint32_t y_end = J.first_row + yrel1;
     const uint32_t jy0 = y << hv;
     const uint32_t n_samples = (y_end - y) << hv;       /* <= 128 (tile_setup)             */
-    uint32_t sched [2];
+    uint32_t sched [2] = { 0, 0 };
 #pragma unroll
-    for (uint32_t q = 0; q < 2; q++)
+    for (uint32_t q = 0; q < (VCOPY ? 0u : 2u); q++)
     {
         uint32_t k = q * 64u + lane;
         if (k >= n_samples)
@@ -615,7 +617,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     }
     uint32_t ks = 0;                                    /* running sample index in the tile */
     uint32_t s_y = 0;                                   /* sample within the output row     */
-    uint32_t e = smol_readlane (sched [0], 0);
+    uint32_t e = VCOPY ? (y | (256u << 16)) : smol_readlane (sched [0], 0);
     uint32_t oy = e & 0xffffu, Fy = e >> 16;
     uint32_t vy0 = 0, vw1 = 0;                          /* vbox: first row of the current box, its weight */
     if (vbox)
@@ -624,7 +626,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         box_span (J.step_y, J.h_in, jy0, vy0, o1, f, vw1);
     }
     const uint32_t row_first = vbox ? vy0 : oy;
-    const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
+    const uint32_t e_last = VCOPY ? (y_end - 1u) : smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
     const uint32_t row_last = (e_last & 0xffffu) + vlag;
     const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
     /* 24-bit output, full-width tile, 4-byte aligned rows: dword-granular stores */
@@ -791,6 +793,14 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     }
                 }
             }
+            else if (VCOPY)
+            {
+                /* vertical copy: this row is an output row */
+                if (!dbg_nostore)
+                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, h);
+                stores_since_dma += dbg_nostore ? 0u : 1u;
+                out_row += J.dst_stride;
+            }
             else
             /* vertical: emit every sample whose last row is r */
             while (ks < n_samples && oy + vlag == r)
@@ -824,9 +834,12 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     Fy = e >> 16;
                 }
             }
+            if (!VCOPY)
+            {
 #pragma unroll
-            for (int c = 0; c < CPL; c++)
-                hprev [c] = h [c];
+                for (int c = 0; c < CPL; c++)
+                    hprev [c] = h [c];
+            }
         }
 
         gfirst += nrows;
@@ -837,14 +850,14 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     }
 }
 
-template <int TAP, int HM, bool STAGE_PREMUL, int CPL>
+template <int TAP, int HM, bool STAGE_PREMUL, int CPL, bool VCOPY = false>
 __device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf)
 {
     switch (J.tile_variant & 3u)
     {
-        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL, CPL> (J, sbuf); break;
-        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL, CPL> (J, sbuf); break;
-        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL, CPL> (J, sbuf); break;
+        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL, CPL, VCOPY> (J, sbuf); break;
+        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL, CPL, VCOPY> (J, sbuf); break;
+        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL, CPL, VCOPY> (J, sbuf); break;
     }
 }
 
@@ -861,6 +874,17 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
             case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4> (J, sbuf); break;
             case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 4> (J, sbuf); break;
             default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 4> (J, sbuf); break;
+        }
+        return;
+    }
+
+    if (J.tile_vcopy)
+    {
+        switch (hm)
+        {
+            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1, true> (J, sbuf); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1, true> (J, sbuf); break;
+            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1, true> (J, sbuf); break;
         }
         return;
     }
@@ -897,11 +921,11 @@ extern __shared__ __attribute__ ((aligned (16))) uint8_t smol_dyn_lds [];
  * gets its own register allocation, so a lean variant (a 1-tap copy) is not held
  * to the occupancy of the heaviest one (4 columns x 4 samples). TS = tapsel of
  * tile_variant: 0 A4, 1 A4 + premultiply while staging, 2 U4, 3 U3. */
-template <int TS, int HM, int CPL>
+template <int TS, int HM, int CPL, bool VCOPY = false>
 __device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf)
 {
     constexpr int TAP = (TS <= 1) ? TAP_A4 : (TS == 2 ? TAP_U4 : TAP_U3);
-    tile_dispatch_out<TAP, HM, TS == 1, CPL> (J, sbuf);
+    tile_dispatch_out<TAP, HM, TS == 1, CPL, VCOPY> (J, sbuf);
 }
 
 #ifdef SMOL_KERNEL_EMU
@@ -911,21 +935,21 @@ __global__ void k_tile_one (const JobDev J)
     tile_dispatch (J, smol_dyn_lds);
 }
 #else
-template <int TS, int HM, int CPL>
+template <int TS, int HM, int CPL, bool VCOPY = false>
 __global__ void __launch_bounds__ (64)
 k_tile_batch (const JobDev *__restrict__ jobs)
 {
     /* private copy: the descriptor must not be re-read from memory after every
      * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
     const JobDev J = jobs [blockIdx.y];
-    tile_entry<TS, HM, CPL> (J, smol_dyn_lds);
+    tile_entry<TS, HM, CPL, VCOPY> (J, smol_dyn_lds);
 }
 
-template <int TS, int HM, int CPL>
+template <int TS, int HM, int CPL, bool VCOPY = false>
 __global__ void __launch_bounds__ (64)
 k_tile_one (const JobDev J)
 {
-    tile_entry<TS, HM, CPL> (J, smol_dyn_lds);
+    tile_entry<TS, HM, CPL, VCOPY> (J, smol_dyn_lds);
 }
 #endif
 
