@@ -221,13 +221,24 @@ __device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32
     }
     else if (WIDE && J.linear)
     {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
+        if (a == 255u)
         {
-            uint32_t v = c [i];
-            if (!J.unassoc_in)
-                v = unpremul8 (v, a, lut);
-            c [i] = premul8l (lut.from_srgb (v), a);
+            /* opaque pixel (most pixels of most images): un-premultiplying by 255 is the
+             * identity, so premultiplied and unassociated input alike reduce to the fused table */
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                c [i] = lut.opaque_lin (c [i]);
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+            {
+                uint32_t v = c [i];
+                if (!J.unassoc_in)
+                    v = unpremul8 (v, a, lut);
+                c [i] = premul8l (lut.from_srgb (v), a);
+            }
         }
     }
     else if (J.unassoc_in)

@@ -60,7 +60,7 @@ def bpp(t):
     return sm.bytes_per_pixel(t)
 
 
-def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3):
+def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False):
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
     srgb = cfg[9] if len(cfg) > 9 else 0
@@ -92,6 +92,9 @@ def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srg
             pool = host
         else:
             host = pool          # reuse host bytes (device copies are still distinct allocations)
+        if opaque and bpp(t_in) == 4 and (i < 16 or n_in > (1 << 24)):
+            # photographs with an alpha channel are opaque: alpha byte 3 (RGBA/BGRA) or 0 (ARGB/ABGR)
+            host[(3 if (t_in & 3) < 2 else 0)::4] = 255
         dsrc.upload(host[:n_in])
         if i == 0:
             host_src_kept = host[:n_in].copy()
@@ -156,11 +159,12 @@ def main():
     ap.add_argument("--tin", type=int, default=None, help="override the input pixel type (0-9) of every config")
     ap.add_argument("--tout", type=int, default=None, help="override the output pixel type (0-9)")
     ap.add_argument("--srgb", type=int, default=None, help="override with_srgb")
+    ap.add_argument("--opaque", action="store_true", help="set the alpha channel of 32-bit inputs to 255 (like real photographs)")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of warm-up load before timing (clock settling)")
     args = ap.parse_args()
     for name in args.configs.split(","):
         print(json.dumps(run_config(name, args.iters, args.warmup, args.check, args.graph,
-                                    args.tin, args.tout, args.srgb, args.settle)), flush=True)
+                                    args.tin, args.tout, args.srgb, args.settle, args.opaque)), flush=True)
 
 
 if __name__ == "__main__":
