@@ -207,6 +207,8 @@ struct SmolHipBatch
     uint32_t n_images = 0;
     JobDev *jobs_dev = nullptr;            /* all jobs, grouped by launch */
     void *scratch = nullptr;               /* intermediate images of the two-pass box jobs */
+    hipStream_t tstream = nullptr;         /* smol_hip_batch_time: stream and events, created once */
+    hipEvent_t te0 = nullptr, te1 = nullptr;
     struct Group { KClass k; uint32_t first, count; JobDev rep; uint32_t max_w_out, max_rows, max_lds; };
     std::vector<Group> groups;
     uint64_t dominant_units = 0;
@@ -586,6 +588,12 @@ smol_hip_batch_destroy (SmolHipBatch *batch)
             (void) hipFree (batch->jobs_dev);
         if (batch->scratch)
             (void) hipFree (batch->scratch);
+        if (batch->tstream)
+        {
+            (void) hipEventDestroy (batch->te0);
+            (void) hipEventDestroy (batch->te1);
+            (void) hipStreamDestroy (batch->tstream);
+        }
         if (batch->graph_exec)
             (void) hipGraphExecDestroy (batch->graph_exec);
         if (batch->graph)
@@ -602,11 +610,16 @@ smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float
 
     HIP_TRY (hipSetDevice (batch->device));
 
-    hipStream_t s;
-    hipEvent_t e0, e1;
-    HIP_TRY (hipStreamCreateWithFlags (&s, hipStreamNonBlocking));
-    HIP_TRY (hipEventCreate (&e0));
-    HIP_TRY (hipEventCreate (&e1));
+    /* the timing stream and its events live with the batch: creating a stream costs a few
+     * hundred microseconds, which a caller timing K launches would see as a fixed overhead */
+    if (!batch->tstream)
+    {
+        HIP_TRY (hipStreamCreateWithFlags (&batch->tstream, hipStreamNonBlocking));
+        HIP_TRY (hipEventCreate (&batch->te0));
+        HIP_TRY (hipEventCreate (&batch->te1));
+    }
+    const hipStream_t s = batch->tstream;
+    const hipEvent_t e0 = batch->te0, e1 = batch->te1;
 
     int rc = 0;
     for (uint32_t i = 0; i < warmup && !rc; i++)
@@ -622,9 +635,6 @@ smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float
         HIP_TRY (hipEventElapsedTime (ms_total, e0, e1));
     }
 
-    (void) hipEventDestroy (e0);
-    (void) hipEventDestroy (e1);
-    (void) hipStreamDestroy (s);
     return rc;
 }
 
