@@ -60,7 +60,7 @@ def bpp(t):
     return sm.bytes_per_pixel(t)
 
 
-def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False):
+def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False):
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
     srgb = cfg[9] if len(cfg) > 9 else 0
@@ -77,6 +77,25 @@ def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srg
     total_in = total_out = 0
     host_src_kept = None
 
+    # Small images come out of one arena per side (256-byte aligned slots), as a pipeline that
+    # batches thumbnails would hold them; big ones get their own allocations.
+    class _Slot:
+        def __init__(self, arena, off, n):
+            self.arena, self.off, self.ptr, self.n = arena, off, arena.ptr + off, n
+        def upload(self, host):
+            self.arena.upload(host, offset=self.off)
+        def download(self, n_bytes=None):
+            return self.arena.download(self.n if n_bytes is None else n_bytes, offset=self.off)
+        def free(self):
+            pass
+    arena_in = arena_out = None
+    use_arena = (w_in * h_in * 4 <= (1 << 22)) and not no_arena
+    slot_in = ((h_in * (stride_in or w_in * 4) + 64 + 255) // 256) * 256        # sized for 4-byte pixels
+    slot_out = ((h_out * w_out * 4 + 64 + 255) // 256) * 256
+    if use_arena:
+        arena_in, arena_out = sm.DeviceBuffer(n_images * slot_in), sm.DeviceBuffer(n_images * slot_out)
+    off_in = off_out = 0
+
     # one shared pool of random bytes uploaded once per distinct input size
     for i in range(n_images):
         t_in = int(rng.integers(0, 10)) if t_in0 < 0 else t_in0
@@ -85,8 +104,14 @@ def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srg
         s_out = w_out * bpp(t_out)
         n_in = h_in * s_in
         n_out = h_out * s_out
-        dsrc = sm.DeviceBuffer(n_in + 64)
-        ddst = sm.DeviceBuffer(n_out + 64)
+        if use_arena:
+            dsrc = _Slot(arena_in, off_in, n_in)
+            ddst = _Slot(arena_out, off_out, n_out)
+            off_in += slot_in
+            off_out += slot_out
+        else:
+            dsrc = sm.DeviceBuffer(n_in + 64)
+            ddst = sm.DeviceBuffer(n_out + 64)
         if i < 16 or n_in > (1 << 24):
             host = rng.integers(0, 256, n_in, dtype=np.uint8)
             pool = host
@@ -146,6 +171,9 @@ def run_config(name, iters, warmup, check, graph=False, tin=None, tout=None, srg
     for a, b in bufs:
         a.free()
         b.free()
+    if arena_in is not None:
+        arena_in.free()
+        arena_out.free()
     return line
 
 
@@ -159,12 +187,13 @@ def main():
     ap.add_argument("--tin", type=int, default=None, help="override the input pixel type (0-9) of every config")
     ap.add_argument("--tout", type=int, default=None, help="override the output pixel type (0-9)")
     ap.add_argument("--srgb", type=int, default=None, help="override with_srgb")
+    ap.add_argument("--no-arena", action="store_true", help="one allocation per image even for small images")
     ap.add_argument("--opaque", action="store_true", help="set the alpha channel of 32-bit inputs to 255 (like real photographs)")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of warm-up load before timing (clock settling)")
     args = ap.parse_args()
     for name in args.configs.split(","):
         print(json.dumps(run_config(name, args.iters, args.warmup, args.check, args.graph,
-                                    args.tin, args.tout, args.srgb, args.settle, args.opaque)), flush=True)
+                                    args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena)), flush=True)
 
 
 if __name__ == "__main__":
