@@ -317,6 +317,13 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
         {
             c [i] = J.unassoc_out ? unpremul8 (s, a, lut) : (s & 0xffu);
         }
+        else if (a == 255u && !J.quirk24)
+        {
+            /* opaque pixel: the inverse for 255 is 1028 = 1024 + 4, so (s * 1028) >> 10 is
+             * s + (s >> 8) exactly, and premultiplying the sRGB byte by 255 is the identity:
+             * premultiplied, unassociated and 24-bit outputs alike are one table look-up */
+            c [i] = lut.to_srgb ((s + (s >> 8)) & 0x7ffu);
+        }
         else
         {
             uint32_t u = (uint32_t) (((uint64_t) s * lut.inv_p8l (a)) >> 10) & 0x7ffu;

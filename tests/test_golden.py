@@ -76,3 +76,16 @@ def test_oracle_planner_matches_golden_planner():
         assert (q.filter_v, q.storage_type, q.gamma_type, q.height_bilin_out) == (fv, st_v, g_v, bil_h), (i, o)
         if fv == 9:
             assert q.span_mul_y == mul_y
+
+
+def test_opaque_fast_path_constants():
+    """The opaque-pixel fast paths of the sRGB-linear class (smol_kernels.hip.h) rely on
+    inv_p8l[255] == 1028 (so (s * 1028) >> 10 == s + (s >> 8)) and on un-premultiplying by 255
+    being the identity on bytes."""
+    import numpy as np
+    import os
+    luts = np.load(os.path.join(os.path.dirname(__file__), "golden", "luts.npz"))
+    assert int(luts["inv_p8l"][255]) == 1028
+    inv255 = int(luts["inv_p8"][255])
+    assert all(((v * inv255) >> 13) & 0xff == v for v in range(256))
+    assert all(((((x + 1) * 256) - 1) >> 8) & 0xff == x for x in range(256))      # premul8(x, 255) == x
