@@ -524,20 +524,22 @@ box2_setup (JobDev &d)
     uint32_t y0, y1, t;
     box_span_host (d.step_y, d.h_in, d.first_row, y0, t);
     box_span_host (d.step_y, d.h_in, d.first_row + d.n_rows - 1, t, y1);
-    d.tmp_row0 = y0;
-    d.tmp_row1 = y1;
 
     /* source bytes a 64-column tile can span in one row, as 16-byte chunks (+ misalignment and reader slack) */
     uint64_t span_px = ((64u * d.step_x) >> 16) + 2;
     if (span_px > d.w_in)
         span_px = d.w_in;
     const uint32_t bytes = (uint32_t) span_px * d.bpp_in + 15 + 8;
+    const uint32_t chunks = (bytes + 15) / 16;
+    if (2u * chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
+        return false;                           /* four waves' row buffers must fit the LDS (nothing of d touched yet) */
+
+    d.tmp_row0 = y0;
+    d.tmp_row1 = y1;
     d.span_px = (uint32_t) span_px;
-    d.span_chunks = (bytes + 15) / 16;
-    d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / d.span_chunks) + 1;
+    d.span_chunks = chunks;
+    d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / chunks) + 1;
     d.box_nmax = (uint32_t) (d.step_x >> 16) + 1;
-    if (2u * d.span_chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
-        return false;                           /* four waves' row buffers must fit the LDS */
     d.box2 = 1;
     return true;
 }

@@ -228,6 +228,21 @@ def test_two_pass_box_thumbnails_single_and_batched():
         ddst.free()
 
 
+def test_workgroups_with_more_than_64k_of_lds():
+    """Geometries whose workgroups need 70-130 KB of dynamic LDS (gfx950 has 160 KB per CU)."""
+    cases = [
+        (4, 2000, 100, 4, 2050, 110, 1),    # k_upg<32>, mild magnification
+        (0, 4000, 600, 0, 64, 10, 0),       # k_boxh, 64bpp class, ratio 62
+        (0, 4000, 600, 0, 64, 10, 1),       # k_boxh, 128bpp class, ratio 62
+        (8, 4000, 100, 8, 3990, 99, 1),     # k_downg, mild minification
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in enumerate(cases):
+        src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, pad=0)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+
+
 def test_tile_kernel_wide_images_and_box_shapes():
     """Geometries that select every k_tile layout: 4 columns per lane (wide, few taps),
     one column per lane, box with 1 and with 8 lanes per column, box on one axis only."""
