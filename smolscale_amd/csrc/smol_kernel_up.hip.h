@@ -446,7 +446,7 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
 
 /* ------------------------------------------------------------------------- *
  * k_up, table-driven flavours: every other 128bpp-class magnification --      *
- * sRGB-linear (with_srgb = 1, the API default; 11-bit channels, W32 = false)  *
+ * sRGB-linear (with_srgb = 1, gamma-correct scaling; 11-bit channels, W32 = false)  *
  * and premul16 + sRGB (19-bit channels, W32 = true) -- any pixel types, any   *
  * alignment. Pixels go through k_general's unpack_word<true> / store_px<true> *
  * (smolscale-generic.c:470-752, 912-1164); 4 waves per workgroup share one    *

@@ -168,7 +168,7 @@ def test_up_kernel_srgb_linear_flavours():
 
 
 def test_down_kernel_srgb_linear_flavours():
-    """k_down modes 1 and 2 (with_srgb = 1, the API default): premultiplied, unassociated
+    """k_down modes 1 and 2 (with_srgb = 1): premultiplied, unassociated
     and 24-bit types, odd strides, misaligned device buffers."""
     shapes = [
         (0, 4096, 300, 0, 2731, 200), (8, 4000, 90, 8, 1600, 36), (4, 1000, 700, 6, 333, 100),

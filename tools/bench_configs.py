@@ -47,10 +47,10 @@ CONFIGS = {
     "P16HALF": (4, 4096, 4096, None, 4, 2731, 2731, 2, "4096^2->2731^2 unassociated->unassociated (premul16, ratio 1.5), 2 frames"),
     "SRGBPNGUP": (4, 1920, 1080, None, 4, 7680, 4320, 2, "1920x1080->7680x4320 rgbA->rgbA with_srgb=1 (premul16 + linear magnify), 2 frames", 1),
     "THUMB": (8, 4000, 3000, None, 8, 200, 150, 16, "4000x3000 RGB8 -> 200x150 RGB8 (BOX ratio 20, 64bpp class), 16 frames"),
-    "SRGBTHUMB": (8, 4000, 3000, None, 8, 200, 150, 16, "4000x3000 RGB8 -> 200x150 RGB8 with_srgb=1 (BOX ratio 20, 128bpp class: photo thumbnails with default flags), 16 frames", 1),
+    "SRGBTHUMB": (8, 4000, 3000, None, 8, 200, 150, 16, "4000x3000 RGB8 -> 200x150 RGB8 with_srgb=1 (BOX ratio 20, 128bpp class: gamma-correct photo thumbnails), 16 frames", 1),
     "SRGBBOX": (0, 4096, 4096, None, 0, 448, 448, 8, "4096^2->448^2 RGBA8 premul with_srgb=1 (BOX/BOX 128bpp), 8 frames", 1),
     "SRGBHALF": (0, 4096, 4096, None, 0, 2731, 2731, 2, "4096^2->2731^2 RGBA8 premul with_srgb=1 (linear, ratio 1.5), 2 frames", 1),
-    "SRGBPHOTO": (8, 4000, 3000, None, 8, 1600, 1200, 4, "4000x3000 RGB8 -> 1600x1200 RGB8 with_srgb=1 (the API default for photos), 4 frames", 1),
+    "SRGBPHOTO": (8, 4000, 3000, None, 8, 1600, 1200, 4, "4000x3000 RGB8 -> 1600x1200 RGB8 with_srgb=1 (gamma-correct photo downscale), 4 frames", 1),
     "SRGBPNG": (4, 4000, 3000, None, 4, 1600, 1200, 4, "4000x3000 rgbA -> 1600x1200 rgbA with_srgb=1 (premul16 + linear), 4 frames", 1),
     "BOX128": (0, 8192, 8192, None, 0, 30, 30, 2, "8192^2->30^2 RGBA8 premul (BOX ratio 273 > 255: 128bpp class), 2 frames"),
 }
