@@ -53,6 +53,7 @@ struct JobDev
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
     uint8_t up_wide;               /* k_up: 0 64bpp class, 1 premul16 fast path, 2 table-driven 16-bit channels, 3 table-driven 32-bit */
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
+    uint8_t box2_vlpc;             /* k_boxv: lanes per output pixel (1 or 8)           */
     uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
     uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
     uint16_t tile_rows;            /* output rows per tile                               */
@@ -525,8 +526,15 @@ box2_setup (JobDev &d)
     box_span_host (d.step_y, d.h_in, d.first_row, y0, t);
     box_span_host (d.step_y, d.h_in, d.first_row + d.n_rows - 1, t, y1);
 
-    /* source bytes a 64-column tile can span in one row, as 16-byte chunks (+ misalignment and reader slack) */
-    uint64_t span_px = ((64u * d.step_x) >> 16) + 2;
+    /* pass 1: 64 columns per wave, or 8 columns with 8 lanes each when a column's span is very
+     * wide (then 64 columns' worth of a row would not fit the LDS either) */
+    uint64_t lpc8_min = 48;
+    if (const char *e = getenv ("SMOL_BOX2_LPC8_MIN"))
+        lpc8_min = (uint64_t) atoi (e);
+    const uint32_t lpc = (d.step_x > (lpc8_min << 16)) ? 8u : 1u;
+
+    /* source bytes a tile can span in one row, as 16-byte chunks (+ misalignment and reader slack) */
+    uint64_t span_px = (((64u / lpc) * d.step_x) >> 16) + 2;
     if (span_px > d.w_in)
         span_px = d.w_in;
     const uint32_t bytes = (uint32_t) span_px * d.bpp_in + 15 + 8;
@@ -534,12 +542,14 @@ box2_setup (JobDev &d)
     if (2u * chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
         return false;                           /* four waves' row buffers must fit the LDS (nothing of d touched yet) */
 
+    d.tile_lpc = (uint8_t) lpc;
+    d.box2_vlpc = (d.step_y > (lpc8_min << 16)) ? 8 : 1;
     d.tmp_row0 = y0;
     d.tmp_row1 = y1;
     d.span_px = (uint32_t) span_px;
     d.span_chunks = chunks;
     d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / chunks) + 1;
-    d.box_nmax = (uint32_t) (d.step_x >> 16) + 1;
+    d.box_nmax = ((uint32_t) (d.step_x >> 16) + 1 + lpc - 1) / lpc + 1;   /* most interior pixels a lane walks */
     d.box2 = 1;
     return true;
 }
@@ -560,13 +570,15 @@ box2_tmp_bytes (const JobDev &d)
 inline uint32_t
 box2_h_tiles (const JobDev &d)
 {
-    return ((d.w_out + 63u) / 64u) * ((d.tmp_row1 - d.tmp_row0 + BOXH_ROWS_HOST) / BOXH_ROWS_HOST);
+    const uint32_t cols = 64u / d.tile_lpc;
+    return ((d.w_out + cols - 1u) / cols) * ((d.tmp_row1 - d.tmp_row0 + BOXH_ROWS_HOST) / BOXH_ROWS_HOST);
 }
 
 inline uint32_t
 box2_v_tiles (const JobDev &d)
 {
-    return ((d.w_out + 63u) / 64u) * d.n_rows;
+    const uint32_t cols = 64u / d.box2_vlpc;
+    return ((d.w_out + cols - 1u) / cols) * d.n_rows;
 }
 
 inline uint32_t

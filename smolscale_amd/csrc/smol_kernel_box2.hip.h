@@ -14,7 +14,7 @@
  *           left edge weighted, interior in full, right edge weighted, then the
  *           span_mul normalisation) and writes the horizontal result -- four 16-bit
  *           channels, 8 bytes -- to the intermediate image (coalesced).
- *   k_boxv  lane = output column, one wave per 64 columns x 1 output row: sums the
+ *   k_boxv  lane = output column (or 8 lanes per column for tall boxes), one wave per output row: sums the
  *           intermediate rows of the box (:2026-2260) with 8-byte coalesced loads,
  *           normalises, packs and stores the pixel.
  *
@@ -36,11 +36,16 @@ __device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t
     return (J.bpp_in == 3) ? (w | 0xff000000u) : w;
 }
 
-template <bool WIDE>
+/* LPC = lanes per output column: 1 (64 columns per wave) or, for very wide spans, 8 (8 columns
+ * per wave; the 8 lanes of a column take consecutive eighths of its interior pixels and meet
+ * through wave shuffles -- sums of exact integers, so the order does not matter) */
+template <bool WIDE, int LPC>
 __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
 {
-    const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+    constexpr uint32_t COLS = TILE_COLS / LPC;
+    const uint32_t sub = lane % LPC;                                /* position in the column's lane group */
+    const uint32_t tiles_x = (J.w_out + COLS - 1) / COLS;
     const uint32_t tx = tile % tiles_x;
     const uint32_t tr = tile / tiles_x;
     const uint32_t r0 = J.tmp_row0 + tr * BOXH_ROWS;                /* first source row of this wave */
@@ -49,21 +54,28 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
         return;
 
     const uint32_t r1 = (r0 + BOXH_ROWS - 1 < J.tmp_row1) ? r0 + BOXH_ROWS - 1 : J.tmp_row1;
-    const uint32_t x0 = tx * TILE_COLS;
-    const uint32_t xn = (x0 + TILE_COLS < J.w_out) ? x0 + TILE_COLS : J.w_out;
-    const uint32_t x = x0 + lane;
+    const uint32_t x0 = tx * COLS;
+    const uint32_t xn = (x0 + COLS < J.w_out) ? x0 + COLS : J.w_out;
+    const uint32_t x = x0 + lane / LPC;
     const uint32_t xc = (x < xn) ? x : xn - 1;
     const uint32_t bpp = J.bpp_in;
 
-    /* this lane's span: pixels o0 (weight wl), o0+1 .. o1-1 (in full), o1 (weight fr) */
+    /* the column's span: pixels o0 (weight wl), o0+1 .. o1-1 (in full), o1 (weight fr) */
     uint32_t o0, o1, fr, wl, sx0, sx1, t0, t1, t2;
     box_span (J.step_x, J.w_in, xc, o0, o1, fr, wl);
     box_span (J.step_x, J.w_in, x0, sx0, t0, t1, t2);
     box_span (J.step_x, J.w_in, xn - 1, t0, sx1, t1, t2);
-    const uint32_t n_int = o1 - o0 - 1;
+    const uint32_t n_col = o1 - o0 - 1;                             /* interior pixels of the column */
+    /* this lane's share of the interior: pixels [i_begin, i_begin + n_int) of it */
+    const uint32_t per = (LPC == 1) ? n_col : (n_col + LPC - 1) / LPC;
+    const uint32_t i_begin = (LPC == 1) ? 0u : ((sub * per < n_col) ? sub * per : n_col);
+    const uint32_t n_int = (LPC == 1) ? n_col : ((i_begin + per < n_col) ? per : n_col - i_begin);
+    const bool edges = (sub == 0);                                  /* the first lane of a group adds both weighted edge pixels */
     const uint32_t g0 = sx0 * bpp, g1 = (sx1 + 1) * bpp;
     const uint32_t row_pitch = J.span_chunks * 16u;
     const uint32_t first_ofs = (o0 - sx0) * bpp;
+    const uint32_t int_ofs = first_ofs + (1u + i_begin) * bpp;      /* first interior pixel of this lane */
+    const uint32_t last_ofs = first_ofs + (n_col + 1u) * bpp;       /* the column's last pixel */
     const LutLds lut (lut_lds);
     const uintptr_t src_base = (uintptr_t) J.src;
 
@@ -84,12 +96,19 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
 
         if (WIDE)
         {
-            uint32_t acc [4], c [4];
-            unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
+            uint32_t acc [4] = { 0, 0, 0, 0 }, c [4];
+            if (edges)
+            {
+                unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                acc [i] = ((c [i] * wl) >> 8) & 0x00ffffffu;
-            off += bpp;
+                for (int i = 0; i < 4; i++)
+                    acc [i] = ((c [i] * wl) >> 8) & 0x00ffffffu;
+                unpack_word<true> (J, box2_px_word (J, rowb, last_ofs + mis), c, lut);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += ((c [i] * fr) >> 8) & 0x00ffffffu;
+            }
+            off = int_ofs + mis;
             /* interior pixels four at a time: the LDS reads of a group are independent */
             for (uint32_t k = 0; k < J.box_nmax; k += 4)
             {
@@ -110,11 +129,17 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                 }
                 off += 4u * bpp;
             }
-            off = first_ofs + mis + (n_int + 1u) * bpp;
-            unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
+            if (LPC > 1)
+            {
+#pragma unroll
+                for (uint32_t m = 1; m < (uint32_t) LPC; m <<= 1)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        acc [i] += smol_shfl_xor (acc [i], m);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                acc [i] = box_scale<true> (acc [i] + (((c [i] * fr) >> 8) & 0x00ffffffu), J.span_mul_x);
+                acc [i] = box_scale<true> (acc [i], J.span_mul_x);
             res = u32x2a8 { acc [0] | (acc [1] << 16), acc [2] | (acc [3] << 16) };
         }
         else
@@ -122,9 +147,16 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             /* unassociated input is premultiplied per pixel (smolscale-generic.c:238-244, 415-464) */
             const bool pm = J.unassoc_in;
             const uint32_t ain = J.pos_in [3];
-            uint32_t w = box2_px_word (J, rowb, off);
-            Px2 a = px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), wl);
-            off += bpp;
+            uint32_t w;
+            Px2 a = { 0, 0 };
+            if (edges)
+            {
+                w = box2_px_word (J, rowb, off);
+                a = px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), wl);
+                w = box2_px_word (J, rowb, last_ofs + mis);
+                a = px2_add (a, px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), fr));
+            }
+            off = int_ofs + mis;
             if (bpp == 3)
             {
                 /* 24-bit pixels, whole groups of 4 = 12 bytes = 3 dwords (b0 b1 b2 b0 | b1 b2 b0 b1 |
@@ -165,45 +197,59 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             }
             else
             {
-            /* interior pixels four at a time (a zero word adds nothing in this class) */
-            for (uint32_t k = 0; k < J.box_nmax; k += 4)
+                /* interior pixels four at a time (a zero word adds nothing in this class) */
+                for (uint32_t k = 0; k < J.box_nmax; k += 4)
+                {
+                    uint32_t w4 [4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        w4 [u] = (k + u < n_int) ? box2_px_word (J, rowb, off + u * bpp) : 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        a = px2_add (a, pm ? premul_px2 (w4 [u], ain) : px2_from_word (w4 [u]));
+                    off += 4u * bpp;
+                }
+            }
+            if (LPC > 1)
             {
-                uint32_t w4 [4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++)
-                    w4 [u] = (k + u < n_int) ? box2_px_word (J, rowb, off + u * bpp) : 0u;
-#pragma unroll
-                for (uint32_t u = 0; u < 4; u++)
-                    a = px2_add (a, pm ? premul_px2 (w4 [u], ain) : px2_from_word (w4 [u]));
-                off += 4u * bpp;
+                for (uint32_t m = 1; m < (uint32_t) LPC; m <<= 1)
+                {
+                    Px2 o2;
+                    o2.lo = smol_shfl_xor (a.lo, m);
+                    o2.hi = smol_shfl_xor (a.hi, m);
+                    a = px2_add (a, o2);
+                }
             }
-            }
-            off = first_ofs + mis + (n_int + 1u) * bpp;
-            w = box2_px_word (J, rowb, off);
-            a = px2_add (a, px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), fr));
             a = px2_box_scale (a, J.span_mul_x);
             res = u32x2a8 { a.lo, a.hi };
         }
 
-        if (x < xn)
+        if (x < xn && sub == 0)
             *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (gptr (J.tmp) + ((size_t) (r - J.tmp_row0) * J.w_out + x) * 8) = res;
     }
 }
 
-template <bool WIDE>
+/* LPC = lanes per output pixel: 1, or 8 for tall boxes (the lanes take every 8th row of the
+ * span and meet through wave shuffles) */
+template <bool WIDE, int LPC>
 __device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
 {
-    const uint32_t tiles_x = (J.w_out + TILE_COLS - 1) / TILE_COLS;
+    constexpr uint32_t COLS = TILE_COLS / LPC;
+    const uint32_t sub = lane % LPC;
+    const uint32_t tiles_x = (J.w_out + COLS - 1) / COLS;
     const uint32_t tx = tile % tiles_x;
     const uint32_t row = tile / tiles_x;                            /* output row of the strip */
 
     if (row >= J.n_rows)
         return;
 
-    const uint32_t x = tx * TILE_COLS + lane;
-    if (x >= J.w_out)
+    const uint32_t x = tx * COLS + lane / LPC;
+    const bool active = x < J.w_out;
+    if (LPC == 1 && !active)
         return;
+    const uint32_t xc = active ? x : J.w_out - 1;                   /* idle lane groups shadow the last column (shuffles below) */
 
     const LutLds lut (lut_lds);
     uint32_t y0, y1, w2, w1;
@@ -212,58 +258,81 @@ __device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_l
      * (smolscale-generic.c:2236-2253); 64bpp-class rows use w2 as is (:2042-2069) */
     const uint32_t last_w = WIDE ? (w2 ? w2 - 1 : 0) : w2;
     const uint32_t y_end = (WIDE && w2 == 0) ? y1 - 1 : y1;
-    const gbyte *ip = gptr (J.tmp) + ((size_t) (y0 - J.tmp_row0) * J.w_out + x) * 8;
     const size_t ipitch = (size_t) J.w_out * 8;
+    const gbyte *ip = gptr (J.tmp) + ((size_t) (y0 + sub - J.tmp_row0) * J.w_out + xc) * 8;
     uint8_t *out_row = J.dst + (size_t) row * J.dst_stride;
 
     if (WIDE)
     {
         uint32_t acc [4] = { 0, 0, 0, 0 };
         /* rows eight at a time: the loads of a group are in flight together */
-        for (uint32_t r = y0; r <= y_end; r += 8, ip += 8 * ipitch)
+        for (uint32_t r = y0 + sub; r <= y_end; r += 8 * LPC, ip += 8 * LPC * ipitch)
         {
             u32x2a8 v8 [8];
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++)
-                v8 [u] = (r + u <= y_end) ? *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip + u * ipitch) : u32x2a8 { 0, 0 };
+                v8 [u] = (r + u * LPC <= y_end) ? *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip + u * LPC * ipitch) : u32x2a8 { 0, 0 };
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++)
             {
                 const uint32_t c [4] = { v8 [u].x & 0xffffu, v8 [u].x >> 16, v8 [u].y & 0xffffu, v8 [u].y >> 16 };
-                const uint32_t w = (r + u == y0) ? w1 : ((r + u == y1) ? last_w : 0x10000u);
+                const uint32_t rr = r + u * LPC;
+                const uint32_t w = (rr == y0) ? w1 : ((rr == y1) ? last_w : 0x10000u);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     acc [i] += (w == 0x10000u) ? c [i] : (((c [i] * w) >> 8) & 0x00ffffffu);
             }
         }
+        if (LPC > 1)
+        {
+#pragma unroll
+            for (uint32_t m = 1; m < (uint32_t) LPC; m <<= 1)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [i] += smol_shfl_xor (acc [i], m);
+        }
         uint32_t o [4];
 #pragma unroll
         for (int i = 0; i < 4; i++)
             o [i] = box_scale<true> (acc [i], J.span_mul_y);
-        store_px<true> (J, out_row, x, o, lut);
+        if (active && sub == 0)
+            store_px<true> (J, out_row, x, o, lut);
     }
     else
     {
         Px2 acc = { 0, 0 };
-        for (uint32_t r = y0; r <= y_end; r += 8, ip += 8 * ipitch)
+        for (uint32_t r = y0 + sub; r <= y_end; r += 8 * LPC, ip += 8 * LPC * ipitch)
         {
             u32x2a8 v8 [8];
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++)
-                v8 [u] = (r + u <= y_end) ? *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip + u * ipitch) : u32x2a8 { 0, 0 };
+                v8 [u] = (r + u * LPC <= y_end) ? *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (ip + u * LPC * ipitch) : u32x2a8 { 0, 0 };
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++)
             {
                 const Px2 p = { v8 [u].x, v8 [u].y };
-                if (r + u == y0)
+                const uint32_t rr = r + u * LPC;
+                if (rr == y0)
                     acc = px2_add (acc, px2_mulw (p, w1));
-                else if (r + u == y1)
+                else if (rr == y1)
                     acc = px2_add (acc, px2_mulw (p, last_w));
                 else
                     acc = px2_add (acc, p);
             }
         }
-        tile_store<OUT_ANY> (J, out_row, x, px2_box_scale (acc, J.span_mul_y));
+        if (LPC > 1)
+        {
+#pragma unroll
+            for (uint32_t m = 1; m < (uint32_t) LPC; m <<= 1)
+            {
+                Px2 o2;
+                o2.lo = smol_shfl_xor (acc.lo, m);
+                o2.hi = smol_shfl_xor (acc.hi, m);
+                acc = px2_add (acc, o2);
+            }
+        }
+        if (active && sub == 0)
+            tile_store<OUT_ANY> (J, out_row, x, px2_box_scale (acc, J.span_mul_y));
     }
 }
 
@@ -275,7 +344,10 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     static uint8_t lut_lds [LUT_LDS_BYTES];
     if (WIDE)
         lut_fill_lds (lut_lds, 0, 1);
-    boxh_body<WIDE> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    if (J.tile_lpc == 8)
+        boxh_body<WIDE, 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    else
+        boxh_body<WIDE, 1> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     const uint32_t wave = threadIdx.x >> 6;
     if (WIDE)
@@ -284,7 +356,10 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
         __syncthreads ();
     }
     const uint32_t lut_bytes = WIDE ? ((LUT_LDS_BYTES + 15u) & ~15u) : 0u;
-    boxh_body<WIDE> (J, lds + lut_bytes + wave * 2u * J.span_chunks * 16u, lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    if (J.tile_lpc == 8)
+        boxh_body<WIDE, 8> (J, lds + lut_bytes + wave * 2u * J.span_chunks * 16u, lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    else
+        boxh_body<WIDE, 1> (J, lds + lut_bytes + wave * 2u * J.span_chunks * 16u, lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
 }
 
@@ -295,14 +370,20 @@ __device__ __forceinline__ void boxv_entry (const JobDev &J, uint8_t *lds)
     static uint8_t lut_lds [LUT_LDS_BYTES];
     if (WIDE)
         lut_fill_lds (lut_lds, 0, 1);
-    boxv_body<WIDE> (J, lut_lds, threadIdx.x, blockIdx.x);
+    if (J.box2_vlpc == 8)
+        boxv_body<WIDE, 8> (J, lut_lds, threadIdx.x, blockIdx.x);
+    else
+        boxv_body<WIDE, 1> (J, lut_lds, threadIdx.x, blockIdx.x);
 #else
     if (WIDE)
     {
         lut_fill_lds (lds, threadIdx.x, 256);
         __syncthreads ();
     }
-    boxv_body<WIDE> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (J.box2_vlpc == 8)
+        boxv_body<WIDE, 8> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6));
+    else
+        boxv_body<WIDE, 1> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6));
 #endif
 }
 
