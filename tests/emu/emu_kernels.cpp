@@ -100,11 +100,19 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
 {
     JobDev J;
     fill_jobdev (J, *job, src, stride_in, dst, stride_out, first_row, n_rows);
+    /* classify() adapts the descriptor to the class it picks; forcing another class below
+     * must start from the pristine descriptor again */
+    const JobDev pristine = J;
     KClass k = classify (J);
     if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_UP || k == KC_DOWN || k == KC_BOX2 || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
     if (force_general == 2 && tile_ok (J))
+    {
         k = KC_TILE;                      /* force the tiled kernel where the fast path would win */
+        J = pristine;
+    }
+    else if (force_general && (k == KC_GENERAL || k == KC_GENERAL_WIDE))
+        J = pristine;
     if (kclass_out)
         *kclass_out = (int) k;
 
