@@ -181,12 +181,12 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
     }
     else if (TAP == TAP_U4)
     {
+        /* v_alignbyte shifts by the low two bits of its third operand: `off' goes in as is */
         const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
-        const uint32_t sh = off & 3u;
         const uint32_t d0 = pp [0], d1 = pp [1];
-        wp = __builtin_amdgcn_alignbyte (d1, d0, sh);
+        wp = __builtin_amdgcn_alignbyte (d1, d0, off);
         if (PAIR)
-            wq = __builtin_amdgcn_alignbyte (pp [2], d1, sh);
+            wq = __builtin_amdgcn_alignbyte (pp [2], d1, off);
         else
             wq = wp;
         if (J.unassoc_in)
@@ -199,19 +199,21 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
     else
     {
         const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
-        const uint32_t sh = off & 3u;
         const uint32_t d0 = pp [0], d1 = pp [1];
-        const uint32_t b0 = __builtin_amdgcn_alignbyte (d1, d0, sh);      /* bytes 0..3 from p */
-        wp = b0 | 0xff000000u;
+        const uint32_t b0 = __builtin_amdgcn_alignbyte (d1, d0, off);     /* bytes 0..3 from p */
         if (PAIR)
         {
-            const uint32_t b1 = __builtin_amdgcn_alignbyte (pp [2], d1, sh);  /* bytes 4..7 */
-            wq = __builtin_amdgcn_alignbyte (b1, b0, 3) | 0xff000000u;        /* bytes 3..5 */
+            /* bytes 0..7 from p hold both pixels (p = bytes 0-2, q = bytes 3-5): four v_perm pick
+             * the packed halves directly -- selector 0x0c = 0x00, 0x0d = 0xff (the alpha lane) */
+            const uint32_t b1 = __builtin_amdgcn_alignbyte (pp [2], d1, off);
+            p.lo = __builtin_amdgcn_perm (b1, b0, 0x0c020c00u);
+            p.hi = __builtin_amdgcn_perm (b1, b0, 0x0c0d0c01u);
+            q.lo = __builtin_amdgcn_perm (b1, b0, 0x0c050c03u);
+            q.hi = __builtin_amdgcn_perm (b1, b0, 0x0c0d0c04u);
+            return;
         }
-        else
-        {
-            wq = wp;
-        }
+        wp = b0 | 0xff000000u;
+        wq = wp;
     }
 
     p = px2_from_word (wp);
