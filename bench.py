@@ -99,12 +99,62 @@ def cpu_baseline(seconds_budget=12.0):
     return info, src, want
 
 
+# The other BASELINE.json configs, single GPU, device resident: not the metric (that is config 2
+# above) -- reported beside it so that the driver's own run records them. name: (type_in, w_in,
+# h_in, stride_in, type_out, w_out, h_out, images per launch)
+OTHER_CONFIGS = {
+    "C1 640x480->320x240 RGBA8 premul x384": (0, 640, 480, None, 0, 320, 240, 384),
+    "C3 1920x1080 RGBA unassociated->7680x4320 RGBA premul x4": (4, 1920, 1080, None, 0, 7680, 4320, 4),
+    "C4 65535x4096 RGB8 (stride 196605)->8192x4096 RGBA8 x1": (8, 65535, 4096, 65535 * 3, 0, 8192, 4096, 1),
+    "C5 256x256->64x64 RGBA8 premul x10000": (0, 256, 256, None, 0, 64, 64, 10000),
+}
+
+
+def other_configs(dev, local_rank):
+    """Time the other BASELINE configs with synthetic device-resident data (hipEvents, after
+    0.2 s of warm-up load each). Any failure is reported in place of the numbers."""
+    out = {}
+    for name, (t_in, w_in, h_in, stride_in, t_out, w_out, h_out, n_img) in OTHER_CONFIGS.items():
+        try:
+            bpp_in, bpp_out = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
+            s_in, s_out = stride_in or w_in * bpp_in, w_out * bpp_out
+            src = torch.randint(0, 256, (n_img, h_in * s_in + 64), dtype=torch.uint8, device=dev)
+            dst = torch.zeros((n_img, h_out * s_out + 64), dtype=torch.uint8, device=dev)
+            job = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+            images = []
+            for i in range(n_img):
+                im = sm.SmolHipImage()
+                im.job = job
+                im.src, im.dst = src[i].data_ptr(), dst[i].data_ptr()
+                im.rowstride_in, im.rowstride_out = s_in, s_out
+                im.first_row, im.n_rows = 0, h_out
+                images.append(im)
+            torch.cuda.synchronize()
+            b = sm.HipBatch(images, device=local_rank)
+            n_launches, kname = b.info()
+            probe = b.time(2, 5) / 5
+            ms = b.time(int(200.0 / max(probe, 1e-3)), 20) / 20
+            algo = n_img * (w_in * h_in * bpp_in + w_out * h_out * bpp_out)
+            gbs = algo / (ms * 1e-3) / 1e9
+            out[name] = {"kernel": kname, "launches": n_launches, "step_us": round(ms * 1e3, 1),
+                         "GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                         "Mpix_out_per_s": round(n_img * w_out * h_out / (ms * 1e-3) / 1e6, 1)}
+            b.destroy()
+            del src, dst
+        except Exception as e:                      # noqa: BLE001 -- a side table must not break the bench line
+            out[name] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the side table of the other BASELINE configs (N=1 only, a few seconds)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL)")
     ap.add_argument("--share-devices", action="store_true",
                     help="testing aid: rank r uses GPU r %% device_count (several ranks on one GPU; needs --backend gloo)")
@@ -241,6 +291,8 @@ def main():
                 "launch_us": round(launch_ms * 1e3, 3),
             },
         }
+        if world == 1 and not args.no_other_configs:
+            line["other_baseline_configs"] = other_configs(dev, local_rank)
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if verified is not None:
