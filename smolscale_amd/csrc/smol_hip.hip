@@ -102,7 +102,7 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
  * temporary allocation released after the stream has drained. (hipMallocAsync /
  * hipFreeAsync would avoid the drain, but on this ROCm build kernels reading such an
  * allocation intermittently saw stale data: 1048 of 4000 randomized cases wrong,
- * none with plain hipMalloc -- tools/exp/fuzz_box2_gpu.py.) */
+ * none with plain hipMalloc -- tests/exp/fuzz_box2_gpu.py.) */
 hipError_t
 launch_single (JobDev &jd, hipStream_t s, void *scratch = nullptr)
 {

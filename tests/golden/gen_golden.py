@@ -15,7 +15,7 @@ Writes
                             suites (incl. the known-bad pre/unmul bytes, pinned)
   tests/golden/planner.npz  planner tuples from ref_probe_plan() for ~300 dims
 
-Usage: python tools/gen_golden.py
+Usage: python tests/golden/gen_golden.py
 """
 import ctypes
 import os
@@ -23,7 +23,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as H  # noqa: E402
 

@@ -1,5 +1,5 @@
 """Oracle vs the committed golden vectors (captured from the real reference by
-tools/gen_golden.py). These run anywhere -- no reference, no GPU needed."""
+tests/golden/gen_golden.py). These run anywhere -- no reference, no GPU needed."""
 import ctypes
 
 import numpy as np
