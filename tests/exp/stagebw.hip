@@ -56,6 +56,11 @@ __global__ void __launch_bounds__ (64) k_dma (const uint8_t *src, uint32_t *sink
             if (STORE == 2) __builtin_nontemporal_store (v, o); else *o = v;
         }
         if (STORE == 3) outv [r] = v;
+        if (STORE == 6)
+        {
+            // as STORE 1, output rows padded by 256 bytes (row stride 33024 instead of 32768): power-of-two stride test
+            dst [(size_t) (ty * TILE_ROWS + r) * (TILES_X * 64 + 64) + tx * 64 + lane] = v;
+        }
         if (STORE == 4 && (tx & 3u) == 0)
         {
             // same bytes as STORE 1, but in 1-KB runs: every fourth tile writes 16 bytes per lane
@@ -167,13 +172,14 @@ int main ()
     run ("LDS-DMA ring 4", [&] { hipLaunchKernelGGL (k_dma<4>, dim3 (grid), dim3 (64), 5 * 1568, 0, src, sink); });
     run ("LDS-DMA ring 6", [&] { hipLaunchKernelGGL (k_dma<6>, dim3 (grid), dim3 (64), 7 * 1568, 0, src, sink); });
     run ("LDS-DMA ring 8", [&] { hipLaunchKernelGGL (k_dma<8>, dim3 (grid), dim3 (64), 9 * 1568, 0, src, sink); });
-    uint32_t *dst; CK (hipMalloc (&dst, (size_t) ROWS * TILES_X * 256));
+    uint32_t *dst; CK (hipMalloc (&dst, (size_t) ROWS * (TILES_X * 256 + 256) + 4096));
     run ("LDS-DMA ring 2 + plain 256-B store per row", [&] { hipLaunchKernelGGL ((k_dma<2, 1>), dim3 (grid), dim3 (64), 3 * 1568, 0, src, sink, dst); });
     run ("LDS-DMA ring 4 + plain 256-B store per row", [&] { hipLaunchKernelGGL ((k_dma<4, 1>), dim3 (grid), dim3 (64), 5 * 1568, 0, src, sink, dst); });
     run ("LDS-DMA ring 2 + nt 256-B store per row", [&] { hipLaunchKernelGGL ((k_dma<2, 2>), dim3 (grid), dim3 (64), 3 * 1568, 0, src, sink, dst); });
     run ("LDS-DMA ring 4 + nt 256-B store per row", [&] { hipLaunchKernelGGL ((k_dma<4, 2>), dim3 (grid), dim3 (64), 5 * 1568, 0, src, sink, dst); });
     run ("LDS-DMA ring 4 + same bytes in 1-KB runs (1/4 of the waves)", [&] { hipLaunchKernelGGL ((k_dma<4, 4>), dim3 (grid), dim3 (64), 5 * 1568, 0, src, sink, dst); });
     run ("LDS-DMA ring 4 + same bytes in 4-KB runs (1/16 of the waves)", [&] { hipLaunchKernelGGL ((k_dma<4, 5>), dim3 (grid), dim3 (64), 5 * 1568, 0, src, sink, dst); });
+    run ("LDS-DMA ring 4 + plain 256-B store, output stride 32768+256", [&] { hipLaunchKernelGGL ((k_dma<4, 6>), dim3 (grid), dim3 (64), 5 * 1568, 0, src, sink, dst); });
     run ("256-column tiles x 16 rows, ring 2, 1-KB stores", [&] { hipLaunchKernelGGL ((k_dma_wide<2, 16>), dim3 (grid / 4), dim3 (64), 2 * 6176 + 64, 0, src, sink, dst); });
     run ("256-column tiles x 4 rows, ring 2, 1-KB stores", [&] { hipLaunchKernelGGL ((k_dma_wide<2, 4>), dim3 (grid), dim3 (64), 2 * 6176 + 64, 0, src, sink, dst); });
     run ("LDS-DMA ring 2 + 16 stores at the tile's end", [&] { hipLaunchKernelGGL ((k_dma<2, 3>), dim3 (grid), dim3 (64), 3 * 1568, 0, src, sink, dst); });
