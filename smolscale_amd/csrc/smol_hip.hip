@@ -77,7 +77,8 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         const uint32_t tw = 64u * rep.tile_cpl / rep.tile_lpc;
         const uint32_t tiles_x = (max_w_out + tw - 1) / tw;
         const uint32_t tiles_y = (max_rows + rep.tile_rows - 1) / rep.tile_rows;
-        const dim3 grid (tiles_x * tiles_y, n_jobs);
+        /* k_tile deals its tiles out in XCD bands: the count is rounded up to a multiple of 8 */
+        const dim3 grid (k == KC_TILE ? ((tiles_x * tiles_y + 7u) & ~7u) : tiles_x * tiles_y, n_jobs);
         const uint32_t lds = max_lds ? max_lds : tile_lds_bytes (rep);
 
         if (k == KC_WTILE)

@@ -46,6 +46,7 @@ struct JobDev
     uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
     uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
     uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8)              */
+    uint8_t tile_band;             /* k_tile: deal tiles out in XCD bands (very wide images) */
     uint8_t tile_vcopy;            /* k_tile: vertical copy specialisation (bilinear 0-2H horizontally, 1 column per lane) */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
@@ -214,6 +215,7 @@ tile_setup (JobDev &d)
         out = 2;
 
     d.tile_variant = (uint8_t) ((tapsel << 5) | (hm << 2) | out);
+    d.tile_band = ((d.w_out + cols - 1) / cols >= 64 && !getenv ("SMOL_NO_TILE_BAND"));
     d.tile_vcopy = (d.filter_v == F_COPY && d.tile_cpl == 1 && hm >= 1 && hm <= 3 && !getenv ("SMOL_NO_TILE_VCOPY"));
     d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
     d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);

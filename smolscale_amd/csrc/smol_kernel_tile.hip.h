@@ -244,16 +244,21 @@ __device__ __forceinline__ uint32_t tile_pack (const JobDev &J, Px2 v)
     return __builtin_amdgcn_perm (w, w, J.out_perm);
 }
 
-template <int OUT>
+template <int OUT, bool NT = false>
 __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint32_t x, Px2 v)
 {
     const uint32_t w = tile_pack<OUT> (J, v);
 
     if (OUT != OUT_ANY)
     {
-        /* output pixels are never read back: non-temporal (C4 189 -> 184 us; the copy-only skeleton
-         * of tests/exp/stagebw.hip shows the same 183 -> 175 us) */
-        __builtin_nontemporal_store (w, reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4));
+        /* NT: the wave's 64 dwords are contiguous (one column per lane) and never read back:
+         * non-temporal (C4 189 -> 184 us; the copy-only skeleton of tests/exp/stagebw.hip shows
+         * the same 183 -> 175 us). Strided dword stores (edge tiles of the 4-columns-per-lane
+         * variants) must NOT be: partial lines written around the L2 cost ratio 1.5 127 -> 211 us. */
+        if (NT)
+            __builtin_nontemporal_store (w, reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4));
+        else
+            *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4) = w;
     }
     else if (J.bpp_out == 4)
     {
@@ -382,7 +387,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
 #pragma unroll
     for (int c = 0; c < CPL; c++)
         if (xl + c < xn)
-            tile_store<OUT> (J, rowp, xl + c, o [c]);
+            tile_store<OUT, CPL == 1> (J, rowp, xl + c, o [c]);
 }
 
 
@@ -506,8 +511,18 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 
     const uint32_t lane = threadIdx.x;
     const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
-    const uint32_t tx = blockIdx.x % tiles_x;
-    const uint32_t ty = blockIdx.x / tiles_x;
+    /* Workgroups go round-robin over the 8 XCDs, each with its own L2: give every XCD a
+     * contiguous band of this job's tiles, so that horizontally adjacent tiles (which share the
+     * cache lines at their segment boundaries) meet in one L2 (the copy-only skeleton of
+     * tests/exp/patternbw.hip gains 1-4 % from it; HBM traffic 1.07x -> ~1.0x) */
+    const uint32_t n_tiles8 = (tiles_x * ((J.n_rows + J.tile_rows - 1) / J.tile_rows) + 7u) & ~7u;
+    if (blockIdx.x >= n_tiles8)
+        return;
+    /* only for very wide images (tile_band: 64 tiles or more per row, host: tile_setup): narrower
+     * ones lose (ratio 1.5 with 11 tiles per row: 133 -> 238 us) */
+    const uint32_t bid = J.tile_band ? (blockIdx.x & 7u) * (n_tiles8 >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t tx = bid % tiles_x;
+    const uint32_t ty = bid / tiles_x;
     const uint32_t yrel0 = ty * J.tile_rows;
 
     if (yrel0 >= J.n_rows)

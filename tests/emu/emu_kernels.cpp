@@ -186,7 +186,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
         const uint32_t tw = TILE_COLS * J.tile_cpl / J.tile_lpc;
         const uint32_t tiles_x = (J.w_out + tw - 1) / tw;
         const uint32_t tiles_y = (n_rows + J.tile_rows - 1) / J.tile_rows;
-        run_grid_coop (tiles_x * tiles_y, 64, tile_lds_bytes (J), [&] { k_tile_one (J); });
+        run_grid_coop ((tiles_x * tiles_y + 7u) & ~7u, 64, tile_lds_bytes (J), [&] { k_tile_one (J); });
         return 0;
     }
 

@@ -8,7 +8,7 @@
 #include <stdint.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf ("%s: %s\n", #x, hipGetErrorString (e)); return 1; } } while (0)
 extern __shared__ __attribute__ ((aligned (16))) uint8_t lds [];
-struct P { const uint8_t *src; uint32_t *dst; uint32_t w_in, h_in, bpp, stride, w_out, h_out, tr, tiles_x, tiles_y, tc; size_t frame_in, frame_out; };
+struct P { const uint8_t *src; uint32_t *dst; uint32_t w_in, h_in, bpp, stride, w_out, h_out, tr, tiles_x, tiles_y, tc, band; size_t frame_in, frame_out; };
 
 __device__ __forceinline__ void dma16 (const void *g, uint8_t *l)
 {
@@ -18,7 +18,10 @@ __device__ __forceinline__ void dma16 (const void *g, uint8_t *l)
 
 __global__ void __launch_bounds__ (64) k_pattern (const P p, uint32_t *sink)
 {
-    const uint32_t lane = threadIdx.x, tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x, f = blockIdx.y;
+    // band = 1: each XCD (blocks go round-robin over the 8 of them) takes a contiguous band of tiles
+    const uint32_t bid = p.band ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t lane = threadIdx.x, tx = bid % p.tiles_x, ty = bid / p.tiles_x, f = blockIdx.y;
+    if (ty >= p.tiles_y) return;
     const uint32_t y0 = ty * p.tr, y1 = min (y0 + p.tr, p.h_out);
     // source span of the tile: columns [64 tx, 64 tx + 64) and rows [y0, y1) scaled by the ratios
     const uint32_t TC = p.tc, cpl = TC / 64u;                  // columns per tile / per lane
@@ -59,6 +62,7 @@ int main (int argc, char **argv)
     P p; p.w_in = atoi (argv [1]); p.h_in = atoi (argv [2]); p.bpp = atoi (argv [3]); p.stride = atoi (argv [4]);
     p.w_out = atoi (argv [5]); p.h_out = atoi (argv [6]); p.tr = atoi (argv [7]); const uint32_t frames = atoi (argv [8]);
     p.tc = argc > 9 ? atoi (argv [9]) : 64;
+    p.band = argc > 10 ? atoi (argv [10]) : 0;
     p.tiles_x = (p.w_out + p.tc - 1) / p.tc; p.tiles_y = (p.h_out + p.tr - 1) / p.tr;
     p.frame_in = ((size_t) p.stride * p.h_in + 4095) & ~(size_t) 4095; p.frame_out = (size_t) p.w_out * p.h_out * 4;
     uint8_t *src; uint32_t *dst, *sink;
@@ -67,7 +71,7 @@ int main (int argc, char **argv)
     const uint32_t span = (uint32_t) ((uint64_t) p.tc * p.w_in / p.w_out) + 3;
     const uint32_t lds_bytes = 2 * ((span * p.bpp + 47u) & ~15u) + 64;
     hipEvent_t e0, e1; CK (hipEventCreate (&e0)); CK (hipEventCreate (&e1));
-    const dim3 grid (p.tiles_x * p.tiles_y, frames);
+    const dim3 grid ((p.tiles_x * p.tiles_y + 7u) & ~7u, frames);
     for (int i = 0; i < 200; i++) hipLaunchKernelGGL (k_pattern, grid, dim3 (64), lds_bytes, 0, p, sink);
     hipEventRecord (e0, 0);
     const int it = 50;
@@ -75,7 +79,7 @@ int main (int argc, char **argv)
     hipEventRecord (e1, 0); hipEventSynchronize (e1);
     float ms = 0; (void) hipEventElapsedTime (&ms, e0, e1);
     const double bytes = (double) frames * ((double) p.w_in * p.h_in * p.bpp + (double) p.w_out * p.h_out * 4);
-    printf ("%ux%u (%u B/px, stride %u) -> %ux%u x%u, %u-column x %u-row tiles: %.1f us, %.0f GB/s algorithmic (%.1f %% of 8 TB/s)\n",
-            p.w_in, p.h_in, p.bpp, p.stride, p.w_out, p.h_out, frames, p.tc, p.tr, ms * 1e3 / it, bytes / (ms * 1e-3 / it) / 1e9, bytes / (ms * 1e-3 / it) / 8e12 * 100);
+    printf ("%s%ux%u (%u B/px, stride %u) -> %ux%u x%u, %u-column x %u-row tiles: %.1f us, %.0f GB/s algorithmic (%.1f %% of 8 TB/s)\n",
+            p.band ? "[XCD bands] " : "", p.w_in, p.h_in, p.bpp, p.stride, p.w_out, p.h_out, frames, p.tc, p.tr, ms * 1e3 / it, bytes / (ms * 1e-3 / it) / 1e9, bytes / (ms * 1e-3 / it) / 8e12 * 100);
     return 0;
 }
