@@ -118,8 +118,8 @@ __global__ void __launch_bounds__ (64) k_dma_wide (const uint8_t *src, uint32_t 
     if (acc == 0x12345679u) *sink = acc;
 }
 
-template <int DEPTH, bool TO_LDS>
-__global__ void __launch_bounds__ (64) k_reg (const uint8_t *src, uint32_t *sink)
+template <int DEPTH, bool TO_LDS, bool STORE = false>
+__global__ void __launch_bounds__ (64) k_reg (const uint8_t *src, uint32_t *sink, uint32_t *dst = nullptr)
 {
     const uint32_t lane = threadIdx.x, tx = blockIdx.x % TILES_X, ty = blockIdx.x / TILES_X;
     const uintptr_t base = ((uintptr_t) src + (size_t) ty * TILE_ROWS * STRIDE + (size_t) tx * SEG);
@@ -141,7 +141,9 @@ __global__ void __launch_bounds__ (64) k_reg (const uint8_t *src, uint32_t *sink
         {
             *reinterpret_cast<u32x4 *> (lds + (r & 1) * 1568 + lane * 16) = b [0];
             if (lane < 33) *reinterpret_cast<u32x4 *> (lds + (r & 1) * 1568 + 1024 + lane * 16) = b [1];
-            acc ^= *reinterpret_cast<const uint32_t *> (lds + (r & 1) * 1568 + lane * 24);
+            const uint32_t v = *reinterpret_cast<const uint32_t *> (lds + (r & 1) * 1568 + lane * 24);
+            acc ^= v;
+            if (STORE) __builtin_nontemporal_store (v, dst + ((size_t) (ty * TILE_ROWS + r) * TILES_X + tx) * 64 + lane);
         }
         else
             acc ^= b [0].x ^ b [0].w ^ b [1].y;
@@ -187,6 +189,9 @@ int main ()
     run ("registers depth 2 -> ds_write", [&] { hipLaunchKernelGGL ((k_reg<2, true>), dim3 (grid), dim3 (64), 2 * 1568, 0, src, sink); });
     run ("registers depth 4 -> ds_write", [&] { hipLaunchKernelGGL ((k_reg<4, true>), dim3 (grid), dim3 (64), 2 * 1568, 0, src, sink); });
     run ("registers depth 8 -> ds_write", [&] { hipLaunchKernelGGL ((k_reg<8, true>), dim3 (grid), dim3 (64), 2 * 1568, 0, src, sink); });
+    run ("registers depth 2 -> ds_write + nt 256-B store per row", [&] { hipLaunchKernelGGL ((k_reg<2, true, true>), dim3 (grid), dim3 (64), 2 * 1568, 0, src, sink, dst); });
+    run ("registers depth 4 -> ds_write + nt 256-B store per row", [&] { hipLaunchKernelGGL ((k_reg<4, true, true>), dim3 (grid), dim3 (64), 2 * 1568, 0, src, sink, dst); });
+    run ("registers depth 8 -> ds_write + nt 256-B store per row", [&] { hipLaunchKernelGGL ((k_reg<8, true, true>), dim3 (grid), dim3 (64), 2 * 1568, 0, src, sink, dst); });
     run ("registers depth 4, no LDS", [&] { hipLaunchKernelGGL ((k_reg<4, false>), dim3 (grid), dim3 (64), 0, 0, src, sink); });
     run ("registers depth 8, no LDS", [&] { hipLaunchKernelGGL ((k_reg<8, false>), dim3 (grid), dim3 (64), 0, 0, src, sink); });
     run ("registers depth 16 (whole tile), no LDS", [&] { hipLaunchKernelGGL ((k_reg<16, false>), dim3 (grid), dim3 (64), 0, 0, src, sink); });
