@@ -99,21 +99,62 @@ const char *smol_hip_strerror (int err);
 
 int smol_hip_device_count (void);
 
-/* A plan binds a job to one device and owns streams + staging buffers. */
+/* A plan binds a job to one device. It owns the intermediate image of the two-pass
+ * box filter for the device-pointer entry (allocated once, by smol_hip_plan_prepare()
+ * or on the first call that needs it); the host-pointer entries borrow one of the
+ * device's staging lanes (streams + slabs) per call. */
 int smol_hip_plan_create (const SmolHipJob *job, int device, SmolHipPlan **plan_out);
 void smol_hip_plan_destroy (SmolHipPlan *plan);
+
+/* Allocates whatever smol_hip_scale_rows_device() could need for this plan now, so that
+ * later calls are purely asynchronous launches (legal under stream capture). Optional. */
+int smol_hip_plan_prepare (SmolHipPlan *plan);
 
 /* Host-pointer entry (what smol_scale_batch() calls): copies the needed input
  * rows to the device, runs the kernels, copies rows [first_row, first_row+n_rows)
  * back to dest_host (row first_row at offset 0, rowstride_out apart; bytes
- * between rows are left untouched). Thread-safe on one plan. Synchronous. */
+ * between rows are left untouched). Thread-safe on one plan. Synchronous.
+ *
+ * The strip is cut into chunks of output rows that flow through three side streams of
+ * a staging lane -- H2D of chunk k+1, the kernels of chunk k and D2H of chunk k-1 run
+ * concurrently (events order them; nothing else synchronises until the end). With
+ * page-locked host memory (smol_hip_host_register / hipHostMalloc) every copy is a true
+ * asynchronous DMA; pageable memory works too, the runtime then stages the copies. */
 int smol_hip_scale_rows_host (SmolHipPlan *plan,
                               const void *pixels_in_host, uint32_t rowstride_in,
                               void *dest_host, uint32_t rowstride_out,
                               uint32_t first_row, uint32_t n_rows);
 
+/* The same over several devices: rows [first_row, first_row+n_rows) are cut into one
+ * strip per plan (ceil (n_rows / n_plans) rows each -- the reference's worker-thread
+ * rule, test.c:870-877), every strip goes through its own plan's device as above, all
+ * strips in flight together. Rows are independent, so nothing is exchanged between
+ * devices. plans [i] may name the same device more than once. With page-locked host
+ * memory one host thread drives all devices asynchronously; with pageable memory the
+ * strips are handed to the library's persistent worker threads (created once). */
+int smol_hip_scale_rows_host_multi (SmolHipPlan *const *plans, uint32_t n_plans,
+                                    const void *pixels_in_host, uint32_t rowstride_in,
+                                    void *dest_host, uint32_t rowstride_out,
+                                    uint32_t first_row, uint32_t n_rows);
+
+/* As smol_hip_scale_rows_host(), but the source image already lives in the memory of GPU
+ * `src_device' (device pointer): the slab of input rows travels GPU -> GPU over xGMI
+ * (hipMemcpyPeerAsync) instead of host -> GPU. src_device may equal the plan's device. */
+int smol_hip_scale_rows_peer (SmolHipPlan *plan, int src_device,
+                              const void *pixels_in_dev, uint32_t rowstride_in,
+                              void *dest_host, uint32_t rowstride_out,
+                              uint32_t first_row, uint32_t n_rows);
+
+/* Page-lock / unlock a caller-owned host range for the calls above (hipHostRegister).
+ * Worth it when the same buffers serve many calls: locking costs about as much as one
+ * transfer of the range. */
+int smol_hip_host_register (void *host_ptr, uint64_t n_bytes);
+int smol_hip_host_unregister (void *host_ptr);
+
 /* Device-pointer entry: input image and output strip already live in device
- * memory. Asynchronous on `hip_stream' (a hipStream_t, NULL = default stream). */
+ * memory. Asynchronous on `hip_stream' (a hipStream_t, NULL = default stream): no
+ * allocation and no synchronisation once the plan is prepared. Concurrent calls on one
+ * plan are fine for disjoint row ranges of the same source image. */
 int smol_hip_scale_rows_device (SmolHipPlan *plan,
                                 const void *pixels_in_dev, uint32_t rowstride_in,
                                 void *dest_dev, uint32_t rowstride_out,
@@ -140,6 +181,31 @@ void smol_hip_batch_destroy (SmolHipBatch *batch);
  * the batch on a private stream, bracketed by hipEvents recorded on that same
  * stream. Returns total milliseconds for the timed launches. */
 int smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_total);
+/* The same with one event between consecutive launches: ms_each [i] = duration of timed
+ * launch i (for min / median). */
+int smol_hip_batch_time_each (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_each);
+
+/* A batch spread over several GPUs by image: image i belongs to devices [i % n_devices]
+ * and its src/dst must be device pointers valid there (thumbnails: no image is split).
+ * One descriptor table and one stream per listed device; launch fans out from the
+ * calling thread (launches are asynchronous, no helper threads), sync waits for every
+ * device. A device may be listed more than once. */
+typedef struct SmolHipBatchMulti SmolHipBatchMulti;
+int smol_hip_batch_create_multi (const SmolHipImage *images, uint32_t n_images,
+                                 const int *devices, uint32_t n_devices,
+                                 SmolHipBatchMulti **batch_out);
+int smol_hip_batch_multi_launch (SmolHipBatchMulti *batch);
+int smol_hip_batch_multi_sync (SmolHipBatchMulti *batch);
+/* `warmup' + `iters' launches on every device concurrently; ms_per_device [d] = that
+ * device's hipEvent time for its `iters' launches; returns after all devices finished. */
+int smol_hip_batch_multi_time (SmolHipBatchMulti *batch, uint32_t warmup, uint32_t iters,
+                               float *ms_per_device);
+void smol_hip_batch_multi_destroy (SmolHipBatchMulti *batch);
+
+/* Releases what the library holds per process: staging lanes (streams, slabs, events)
+ * of every device and the worker threads. Lanes are also released when the last plan
+ * on a device is destroyed. Call with no smol_hip_* call in flight. */
+void smol_hip_shutdown (void);
 
 /* Device memory helpers so that hosts without a HIP binding (ctypes, cgo...)
  * can stage buffers. */

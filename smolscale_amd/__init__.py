@@ -94,7 +94,12 @@ EXPORTS = {
     "smol_hip_device_count": (_int, []),
     "smol_hip_plan_create": (_int, [ctypes.POINTER(SmolHipJob), _int, ctypes.POINTER(_vp)]),
     "smol_hip_plan_destroy": (None, [_vp]),
+    "smol_hip_plan_prepare": (_int, [_vp]),
     "smol_hip_scale_rows_host": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32]),
+    "smol_hip_scale_rows_host_multi": (_int, [ctypes.POINTER(_vp), _u32, _vp, _u32, _vp, _u32, _u32, _u32]),
+    "smol_hip_scale_rows_peer": (_int, [_vp, _int, _vp, _u32, _vp, _u32, _u32, _u32]),
+    "smol_hip_host_register": (_int, [_vp, _u64]),
+    "smol_hip_host_unregister": (_int, [_vp]),
     "smol_hip_scale_rows_device": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp]),
     "smol_hip_batch_create": (_int, [ctypes.POINTER(SmolHipImage), _u32, _int, ctypes.POINTER(_vp)]),
     "smol_hip_batch_launch": (_int, [_vp, _vp]),
@@ -102,6 +107,14 @@ EXPORTS = {
     "smol_hip_batch_info": (_int, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_char_p)]),
     "smol_hip_batch_destroy": (None, [_vp]),
     "smol_hip_batch_time": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
+    "smol_hip_batch_time_each": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
+    "smol_hip_batch_create_multi": (_int, [ctypes.POINTER(SmolHipImage), _u32, ctypes.POINTER(_int), _u32,
+                                           ctypes.POINTER(_vp)]),
+    "smol_hip_batch_multi_launch": (_int, [_vp]),
+    "smol_hip_batch_multi_sync": (_int, [_vp]),
+    "smol_hip_batch_multi_time": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
+    "smol_hip_batch_multi_destroy": (None, [_vp]),
+    "smol_hip_shutdown": (None, []),
     "smol_hip_malloc": (_int, [_int, _u64, ctypes.POINTER(_vp)]),
     "smol_hip_free": (_int, [_int, _vp]),
     "smol_hip_memcpy_h2d": (_int, [_int, _vp, _vp, _u64]),
@@ -234,6 +247,12 @@ class HipBatch:
         check(lib().smol_hip_batch_time(self._h, warmup, iters, ctypes.byref(ms)), "smol_hip_batch_time")
         return ms.value
 
+    def time_each(self, warmup, iters):
+        """Per-launch durations in ms (one hipEvent between consecutive launches)."""
+        ms = (ctypes.c_float * iters)()
+        check(lib().smol_hip_batch_time_each(self._h, warmup, iters, ms), "smol_hip_batch_time_each")
+        return list(ms)
+
     def info(self):
         n = _u32(0)
         name = ctypes.c_char_p()
@@ -244,6 +263,91 @@ class HipBatch:
         if self._h:
             lib().smol_hip_batch_destroy(self._h)
             self._h = None
+
+
+class HipBatchMulti:
+    """smol_hip_batch_*_multi(): image i runs on devices[i % len(devices)] (device pointers there)."""
+
+    def __init__(self, images, devices):
+        arr = (SmolHipImage * len(images))(*images)
+        devs = (_int * len(devices))(*devices)
+        self.n_devices = len(devices)
+        self._h = _vp()
+        check(lib().smol_hip_batch_create_multi(arr, len(images), devs, len(devices), ctypes.byref(self._h)),
+              "smol_hip_batch_create_multi")
+
+    def launch(self):
+        check(lib().smol_hip_batch_multi_launch(self._h), "smol_hip_batch_multi_launch")
+
+    def sync(self):
+        check(lib().smol_hip_batch_multi_sync(self._h), "smol_hip_batch_multi_sync")
+
+    def time(self, warmup, iters):
+        ms = (ctypes.c_float * self.n_devices)()
+        check(lib().smol_hip_batch_multi_time(self._h, warmup, iters, ms), "smol_hip_batch_multi_time")
+        return list(ms)
+
+    def destroy(self):
+        if self._h:
+            lib().smol_hip_batch_multi_destroy(self._h)
+            self._h = None
+
+
+class HipPlan:
+    """smol_hip_plan_*() and the row-range entries of include/smol_hip.h."""
+
+    def __init__(self, job, device=0):
+        self.job = job
+        self.device = device
+        self._h = _vp()
+        check(lib().smol_hip_plan_create(ctypes.byref(job), device, ctypes.byref(self._h)), "smol_hip_plan_create")
+
+    def prepare(self):
+        check(lib().smol_hip_plan_prepare(self._h), "smol_hip_plan_prepare")
+
+    def scale_rows_host(self, src, rowstride_in, dst, rowstride_out, first_row, n_rows):
+        check(lib().smol_hip_scale_rows_host(self._h, _as_u8(src).ctypes.data, rowstride_in,
+                                             dst.ctypes.data, rowstride_out, first_row, n_rows),
+              "smol_hip_scale_rows_host")
+
+    def scale_rows_device(self, src_ptr, rowstride_in, dst_ptr, rowstride_out, first_row, n_rows, stream=None):
+        check(lib().smol_hip_scale_rows_device(self._h, src_ptr, rowstride_in, dst_ptr, rowstride_out,
+                                               first_row, n_rows, stream), "smol_hip_scale_rows_device")
+
+    def scale_rows_peer(self, src_device, src_ptr, rowstride_in, dst, rowstride_out, first_row, n_rows):
+        check(lib().smol_hip_scale_rows_peer(self._h, src_device, src_ptr, rowstride_in,
+                                             dst.ctypes.data, rowstride_out, first_row, n_rows),
+              "smol_hip_scale_rows_peer")
+
+    def destroy(self):
+        if self._h:
+            lib().smol_hip_plan_destroy(self._h)
+            self._h = None
+
+
+def scale_rows_host_multi(plans, src, rowstride_in, dst, rowstride_out, first_row, n_rows):
+    """smol_hip_scale_rows_host_multi(): one output-row strip per plan (device), all in flight together."""
+    arr = (_vp * len(plans))(*[p._h for p in plans])
+    check(lib().smol_hip_scale_rows_host_multi(arr, len(plans), _as_u8(src).ctypes.data, rowstride_in,
+                                               dst.ctypes.data, rowstride_out, first_row, n_rows),
+          "smol_hip_scale_rows_host_multi")
+
+
+class PinnedArray:
+    """A page-locked numpy uint8 buffer: host memory registered with smol_hip_host_register()."""
+
+    def __init__(self, n_bytes):
+        # page-aligned backing store; registration pins whole pages
+        self._raw = np.zeros(int(n_bytes) + 8192, np.uint8)
+        off = (-self._raw.ctypes.data) % 4096
+        self.array = self._raw[off:off + int(n_bytes)]
+        check(lib().smol_hip_host_register(self.array.ctypes.data, int(n_bytes)), "smol_hip_host_register")
+        self._registered = True
+
+    def free(self):
+        if self._registered:
+            lib().smol_hip_host_unregister(self.array.ctypes.data)
+            self._registered = False
 
 
 class DeviceBuffer:

@@ -10,11 +10,15 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "smol_hip.h"
@@ -99,99 +103,155 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
 }
 
 /* One job, descriptor by value. The two-pass box filter needs an intermediate image:
- * `scratch' (caller-owned, at least box2_tmp_bytes + 64) if given; otherwise a
- * temporary allocation released after the stream has drained. (hipMallocAsync /
- * hipFreeAsync would avoid the drain, but on this ROCm build kernels reading such an
- * allocation intermittently saw stale data: 1048 of 4000 randomized cases wrong,
- * none with plain hipMalloc -- tests/exp/fuzz_box2_gpu.py.) */
+ * `scratch' is caller-owned (plan, staging lane or batch), at least box2_tmp_bytes + 64
+ * bytes for the job's rows, and is indexed from the job's own first source row
+ * (tmp_row0). Nothing is allocated, freed or synchronised here, so the launch is
+ * asynchronous and legal under stream capture. */
 hipError_t
 launch_single (JobDev &jd, hipStream_t s, void *scratch = nullptr)
 {
     const KClass k = classify (jd);
 
-    if (k != KC_BOX2)
-        return launch_class (k, nullptr, 1, jd, jd.w_out, jd.n_rows, s);
-
-    void *tmp = scratch;
-    hipError_t e = hipSuccess;
-    if (!tmp)
-        e = hipMalloc (&tmp, box2_tmp_bytes (jd) + 64);
-    if (e != hipSuccess)
-        return e;
-    jd.tmp = static_cast<uint8_t *> (tmp);
-    e = launch_class (k, nullptr, 1, jd, jd.w_out, jd.n_rows, s);
-    if (!scratch)
+    if (k == KC_BOX2)
     {
-        const hipError_t e2 = hipStreamSynchronize (s);
-        (void) hipFree (tmp);
-        if (e == hipSuccess)
-            e = e2;
+        if (!scratch)
+            return hipErrorInvalidValue;
+        jd.tmp = static_cast<uint8_t *> (scratch);
     }
-    return e;
+    return launch_class (k, nullptr, 1, jd, jd.w_out, jd.n_rows, s);
 }
 
-/* ---- per-device lanes: stream + grow-only staging buffers ---------------- */
+/* first_row + n_rows <= height, without wrapping */
+inline bool
+rows_ok (uint32_t first_row, uint32_t n_rows, uint32_t height)
+{
+    return first_row < height && n_rows <= height - first_row;
+}
+
+/* ---- per-device staging lanes ------------------------------------------------
+ * A lane = three side streams (H2D / kernels / D2H), a pool of ordering events and
+ * grow-only device slabs. A host-pointer call borrows one lane for its duration. */
+
+constexpr int N_LANES = 4;
+constexpr int MAX_DEVICES = 16;
+constexpr uint32_t MAX_CHUNKS = 32;
+constexpr size_t CHUNK_BYTES = 8u << 20;        /* host<->device bytes per pipeline chunk, about */
 
 struct Lane
 {
     std::mutex mtx;
     bool ready = false;
-    hipStream_t stream = nullptr;
+    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+    hipEvent_t ev_in [MAX_CHUNKS] = {}, ev_k [MAX_CHUNKS] = {};
     void *src_buf = nullptr;  size_t src_cap = 0;
     void *dst_buf = nullptr;  size_t dst_cap = 0;
     void *tmp_buf = nullptr;  size_t tmp_cap = 0;      /* intermediate image of the two-pass box filter */
 };
 
-constexpr int N_LANES = 4;
-constexpr int MAX_DEVICES = 16;
-
 struct DeviceState
 {
     Lane lanes [N_LANES];
     std::atomic<unsigned> next { 0 };
+    std::mutex ref_mtx;
+    int plans = 0;                                      /* live plans on this device */
 };
 
 DeviceState g_devices [MAX_DEVICES];
 
 int
-lane_prepare_tmp (Lane &ln, size_t need)
+grow (void *&buf, size_t &cap, size_t need)
 {
-    if (need > ln.tmp_cap)
-    {
-        if (ln.tmp_buf)
-            HIP_TRY (hipFree (ln.tmp_buf));
-        ln.tmp_buf = nullptr; ln.tmp_cap = 0;
-        HIP_TRY (hipMalloc (&ln.tmp_buf, need));
-        ln.tmp_cap = need;
-    }
+    if (need <= cap)
+        return 0;
+    if (buf)
+        HIP_TRY (hipFree (buf));
+    buf = nullptr; cap = 0;
+    HIP_TRY (hipMalloc (&buf, need));
+    cap = need;
     return 0;
 }
 
 int
-lane_prepare (Lane &ln, size_t src_need, size_t dst_need)
+lane_prepare (Lane &ln, size_t src_need, size_t dst_need, size_t tmp_need)
 {
     if (!ln.ready)
     {
-        HIP_TRY (hipStreamCreateWithFlags (&ln.stream, hipStreamNonBlocking));
+        HIP_TRY (hipStreamCreateWithFlags (&ln.s_in, hipStreamNonBlocking));
+        HIP_TRY (hipStreamCreateWithFlags (&ln.s_k, hipStreamNonBlocking));
+        HIP_TRY (hipStreamCreateWithFlags (&ln.s_out, hipStreamNonBlocking));
+        for (uint32_t i = 0; i < MAX_CHUNKS; i++)
+        {
+            HIP_TRY (hipEventCreateWithFlags (&ln.ev_in [i], hipEventDisableTiming));
+            HIP_TRY (hipEventCreateWithFlags (&ln.ev_k [i], hipEventDisableTiming));
+        }
         ln.ready = true;
     }
-    if (src_need > ln.src_cap)
+    int rc = grow (ln.src_buf, ln.src_cap, src_need);
+    if (!rc) rc = grow (ln.dst_buf, ln.dst_cap, dst_need);
+    if (!rc && tmp_need) rc = grow (ln.tmp_buf, ln.tmp_cap, tmp_need);
+    return rc;
+}
+
+/* caller holds ln.mtx (or nobody can: shutdown) and the device is current */
+void
+lane_release (Lane &ln)
+{
+    if (ln.ready)
     {
-        if (ln.src_buf)
-            HIP_TRY (hipFree (ln.src_buf));
-        ln.src_buf = nullptr; ln.src_cap = 0;
-        HIP_TRY (hipMalloc (&ln.src_buf, src_need));
-        ln.src_cap = src_need;
+        (void) hipStreamSynchronize (ln.s_in);
+        (void) hipStreamSynchronize (ln.s_k);
+        (void) hipStreamSynchronize (ln.s_out);
+        for (uint32_t i = 0; i < MAX_CHUNKS; i++)
+        {
+            if (ln.ev_in [i]) (void) hipEventDestroy (ln.ev_in [i]);
+            if (ln.ev_k [i]) (void) hipEventDestroy (ln.ev_k [i]);
+            ln.ev_in [i] = ln.ev_k [i] = nullptr;
+        }
+        (void) hipStreamDestroy (ln.s_in);
+        (void) hipStreamDestroy (ln.s_k);
+        (void) hipStreamDestroy (ln.s_out);
+        ln.s_in = ln.s_k = ln.s_out = nullptr;
+        ln.ready = false;
     }
-    if (dst_need > ln.dst_cap)
+    if (ln.src_buf) (void) hipFree (ln.src_buf);
+    if (ln.dst_buf) (void) hipFree (ln.dst_buf);
+    if (ln.tmp_buf) (void) hipFree (ln.tmp_buf);
+    ln.src_buf = ln.dst_buf = ln.tmp_buf = nullptr;
+    ln.src_cap = ln.dst_cap = ln.tmp_cap = 0;
+}
+
+void
+device_release_lanes (int device)
+{
+    if (hipSetDevice (device) != hipSuccess)
+        return;
+    for (Lane &ln : g_devices [device].lanes)
     {
-        if (ln.dst_buf)
-            HIP_TRY (hipFree (ln.dst_buf));
-        ln.dst_buf = nullptr; ln.dst_cap = 0;
-        HIP_TRY (hipMalloc (&ln.dst_buf, dst_need));
-        ln.dst_cap = dst_need;
+        std::lock_guard<std::mutex> guard (ln.mtx);
+        lane_release (ln);
     }
-    return 0;
+}
+
+void
+lane_drain (Lane &ln)
+{
+    if (!ln.ready)
+        return;
+    (void) hipStreamSynchronize (ln.s_in);
+    (void) hipStreamSynchronize (ln.s_k);
+    (void) hipStreamSynchronize (ln.s_out);
+}
+
+bool
+host_ptr_is_pinned (const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes (&attr, p) != hipSuccess)
+    {
+        (void) hipGetLastError ();      /* unregistered host memory reports an error: not sticky */
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
 }
 
 } /* namespace */
@@ -200,7 +260,415 @@ struct SmolHipPlan
 {
     SmolHipJob job;
     int device;
+    std::mutex mtx;
+    void *box_scratch = nullptr;        /* device-pointer entry: whole-image intermediate of the two-pass box filter */
+    size_t box_cap = 0;
 };
+
+namespace {
+
+/* Whole-image intermediate for the device-pointer entry, indexed by absolute source row so
+ * that concurrent calls for disjoint strips of one image share it safely (a boundary row
+ * two strips both need gets the same bytes from both). */
+int
+plan_box_scratch (SmolHipPlan *plan, void **out)
+{
+    const SmolHipJob &j = plan->job;
+    const size_t need = (size_t) j.height_in * j.width_out * 8 + 64;
+    std::lock_guard<std::mutex> guard (plan->mtx);
+
+    if (!plan->box_scratch)
+    {
+        HIP_TRY (hipMalloc (&plan->box_scratch, need));
+        plan->box_cap = need;
+    }
+    *out = plan->box_scratch;
+    return 0;
+}
+
+/* One strip through a lane: issue (asynchronous) and finish (wait). The lane's mutex is
+ * held from a successful issue until finish. */
+struct Strip
+{
+    SmolHipPlan *plan = nullptr;
+    const uint8_t *src = nullptr;       /* host rows, or device rows on GPU `src_device' */
+    int src_device = -1;                /* -1: host memory */
+    uint32_t rowstride_in = 0;
+    uint8_t *dest = nullptr;            /* host: output row `first' at offset 0 */
+    uint32_t rowstride_out = 0;
+    uint32_t first = 0, n = 0;
+    Lane *lane = nullptr;               /* set while issued */
+    int rc = 0;
+};
+
+int
+strip_issue_locked (Strip &st, Lane &ln)
+{
+    SmolHipPlan *plan = st.plan;
+    const SmolHipJob &job = plan->job;
+    uint32_t r0, r1;
+    int rc = smol_hip_input_row_range (&job, st.first, st.n, &r0, &r1);
+    if (rc)
+        return rc;
+
+    const TypeInfo &ti = k_types [job.pixel_type_in];
+    const TypeInfo &to = k_types [job.pixel_type_out];
+    const size_t in_row_bytes = (size_t) job.width_in * ti.bpp;
+    const size_t out_row_bytes = (size_t) job.width_out * to.bpp;
+    const size_t n_in_rows = (size_t) r1 - r0 + 1;
+    const bool peer = st.src_device >= 0;
+    /* Host rows are re-pitched to 16-byte multiples on the device whatever the host strides
+     * are, so kernels see aligned rows even for odd host layouts (the reference copies odd
+     * rows to an aligned temporary: smolscale-generic.c:1623-1634). A slab that comes from
+     * another GPU keeps the caller's stride and its alignment within 16 bytes (one
+     * contiguous peer copy). */
+    const size_t src_pitch = peer ? st.rowstride_in : align_up (in_row_bytes, 16);
+    const size_t dst_pitch = align_up (out_row_bytes, 16);
+    const size_t src_skew = peer ? ((uintptr_t) (st.src + (size_t) r0 * st.rowstride_in) & 15u) : 0;
+
+    if (src_pitch > 0xffffffffu || dst_pitch > 0xffffffffu)
+        return SMOL_HIP_E_INVALID;
+
+    HIP_TRY (hipSetDevice (plan->device));
+
+    /* the two-pass box filter keeps its intermediate image in the lane */
+    size_t tmp_need = 0;
+    {
+        JobDev probe;
+        fill_jobdev (probe, job, ln.src_buf ? ln.src_buf : (void *) 16, (uint32_t) src_pitch,
+                     ln.dst_buf ? ln.dst_buf : (void *) 16, (uint32_t) dst_pitch, st.first, st.n);
+        if (box2_setup (probe))
+            tmp_need = box2_tmp_bytes (probe) + 64;
+    }
+    rc = lane_prepare (ln, n_in_rows * src_pitch + 64 + 16, (size_t) st.n * dst_pitch + 64, tmp_need);
+    if (rc)
+        return rc;
+
+    /* chunks of output rows: about CHUNK_BYTES of host<->device traffic each */
+    const size_t total = n_in_rows * in_row_bytes + (size_t) st.n * out_row_bytes;
+    uint32_t n_chunks = (uint32_t) ((total + CHUNK_BYTES - 1) / CHUNK_BYTES);
+    if (n_chunks > MAX_CHUNKS) n_chunks = MAX_CHUNKS;
+    if (n_chunks > st.n) n_chunks = st.n;
+    if (n_chunks < 1) n_chunks = 1;
+    const uint32_t rows_per_chunk = (st.n + n_chunks - 1) / n_chunks;
+
+    uint8_t *slab = static_cast<uint8_t *> (ln.src_buf) + src_skew;
+    /* Row 0 of the virtual source image lies r0 rows before the slab. */
+    const uint8_t *virt_src = slab - (size_t) r0 * src_pitch;
+    uint32_t copied_to = r0;            /* input rows [r0, copied_to) are on their way */
+    hipError_t e = hipSuccess;
+
+    for (uint32_t c = 0, done = 0; done < st.n && e == hipSuccess; c++)
+    {
+        const uint32_t rows = (st.n - done < rows_per_chunk) ? st.n - done : rows_per_chunk;
+        uint32_t a, b;
+
+        rc = smol_hip_input_row_range (&job, st.first + done, rows, &a, &b);
+        if (rc)
+            break;
+        if (b + 1 > copied_to)
+        {
+            const uint32_t from = copied_to, cnt = b + 1 - copied_to;
+            uint8_t *d = slab + (size_t) (from - r0) * src_pitch;
+            const uint8_t *s = st.src + (size_t) from * st.rowstride_in;
+
+            if (peer)
+            {
+                /* whole rows incl. the gaps between them, except after the very last one */
+                const size_t bytes = (size_t) (cnt - 1) * st.rowstride_in + in_row_bytes;
+                e = hipMemcpyPeerAsync (d, plan->device, s, st.src_device, bytes, ln.s_in);
+            }
+            else
+                e = hipMemcpy2DAsync (d, src_pitch, s, st.rowstride_in, in_row_bytes, cnt,
+                                      hipMemcpyHostToDevice, ln.s_in);
+            copied_to = b + 1;
+            if (e != hipSuccess)
+                break;
+        }
+        if ((e = hipEventRecord (ln.ev_in [c], ln.s_in)) != hipSuccess) break;
+        if ((e = hipStreamWaitEvent (ln.s_k, ln.ev_in [c], 0)) != hipSuccess) break;
+
+        JobDev jd;
+        fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch,
+                     static_cast<uint8_t *> (ln.dst_buf) + (size_t) done * dst_pitch, (uint32_t) dst_pitch,
+                     st.first + done, rows);
+        if ((e = launch_single (jd, ln.s_k, ln.tmp_buf)) != hipSuccess) break;
+        if ((e = hipEventRecord (ln.ev_k [c], ln.s_k)) != hipSuccess) break;
+        if ((e = hipStreamWaitEvent (ln.s_out, ln.ev_k [c], 0)) != hipSuccess) break;
+        e = hipMemcpy2DAsync (st.dest + (size_t) done * st.rowstride_out, st.rowstride_out,
+                              static_cast<uint8_t *> (ln.dst_buf) + (size_t) done * dst_pitch, dst_pitch,
+                              out_row_bytes, rows, hipMemcpyDeviceToHost, ln.s_out);
+        done += rows;
+    }
+
+    if (rc || e != hipSuccess)
+    {
+        lane_drain (ln);                /* nothing of the caller's memory stays in flight */
+        return rc ? rc : -(int) e;
+    }
+    return 0;
+}
+
+/* Borrow a lane of the plan's device and issue the strip. `may_block': wait for a lane
+ * when all are taken (otherwise return 1 = try again later). */
+int
+strip_issue (Strip &st, bool may_block)
+{
+    DeviceState &ds = g_devices [st.plan->device];
+    const unsigned start = ds.next.fetch_add (1);
+    Lane *ln = nullptr;
+
+    for (int i = 0; i < N_LANES && !ln; i++)
+    {
+        Lane &cand = ds.lanes [(start + i) % N_LANES];
+        if (cand.mtx.try_lock ())
+            ln = &cand;
+    }
+    if (!ln)
+    {
+        if (!may_block)
+            return 1;
+        ln = &ds.lanes [start % N_LANES];
+        ln->mtx.lock ();
+    }
+
+    st.rc = strip_issue_locked (st, *ln);
+    if (st.rc)
+    {
+        ln->mtx.unlock ();
+        return st.rc;
+    }
+    st.lane = ln;
+    return 0;
+}
+
+int
+strip_finish (Strip &st)
+{
+    if (!st.lane)
+        return st.rc;
+    Lane &ln = *st.lane;
+    hipError_t e = hipSetDevice (st.plan->device);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize (ln.s_out);    /* the last D2H follows every kernel, every kernel its H2D */
+    if (e != hipSuccess)
+        lane_drain (ln);
+    st.lane = nullptr;
+    ln.mtx.unlock ();
+    if (e != hipSuccess)
+        st.rc = -(int) e;
+    return st.rc;
+}
+
+/* ---- persistent worker threads (pageable host memory: copies block their caller) ---- */
+
+struct StripCall
+{
+    Strip *strips;
+    uint32_t n;
+    std::atomic<uint32_t> next { 0 };
+    std::atomic<uint32_t> done { 0 };
+    std::mutex mtx;
+    std::condition_variable cv;
+};
+
+void
+strip_call_help (StripCall &call)
+{
+    for (;;)
+    {
+        const uint32_t i = call.next.fetch_add (1);
+        if (i >= call.n)
+            return;
+        Strip &st = call.strips [i];
+        if (strip_issue (st, true) == 0)
+            strip_finish (st);
+        if (call.done.fetch_add (1) + 1 == call.n)
+        {
+            std::lock_guard<std::mutex> g (call.mtx);
+            call.cv.notify_all ();
+        }
+    }
+}
+
+struct WorkerPool
+{
+    std::mutex mtx;
+    std::condition_variable cv;
+    std::deque<StripCall *> queue;      /* calls that still have unclaimed strips */
+    std::vector<std::thread> threads;
+    bool stop = false;
+
+    void run ()
+    {
+        for (;;)
+        {
+            StripCall *call;
+            {
+                std::unique_lock<std::mutex> lk (mtx);
+                for (;;)
+                {
+                    while (!queue.empty () && queue.front ()->next.load () >= queue.front ()->n)
+                        queue.pop_front ();             /* nothing left to claim in it */
+                    if (stop)
+                        return;
+                    if (!queue.empty ())
+                        break;
+                    cv.wait (lk);
+                }
+                call = queue.front ();
+                call_enter (call);      /* under `mtx': the owner cannot retire it in between */
+            }
+            strip_call_help (*call);
+            call_leave (call);
+        }
+    }
+
+    /* owner-side lifetime: a call may be destroyed once no helper is inside it */
+    std::mutex life_mtx;
+    std::condition_variable life_cv;
+    std::vector<std::pair<StripCall *, int>> inside;
+
+    void call_enter (StripCall *c)
+    {
+        std::lock_guard<std::mutex> g (life_mtx);
+        for (auto &p : inside)
+            if (p.first == c) { p.second++; return; }
+        inside.emplace_back (c, 1);
+    }
+    void call_leave (StripCall *c)
+    {
+        std::lock_guard<std::mutex> g (life_mtx);
+        for (size_t i = 0; i < inside.size (); i++)
+            if (inside [i].first == c && --inside [i].second == 0)
+            {
+                inside.erase (inside.begin () + (long) i);
+                break;
+            }
+        life_cv.notify_all ();
+    }
+    void call_retire (StripCall *c)
+    {
+        {
+            std::lock_guard<std::mutex> g (mtx);
+            for (size_t i = 0; i < queue.size (); i++)
+                if (queue [i] == c) { queue.erase (queue.begin () + (long) i); break; }
+        }
+        std::unique_lock<std::mutex> lk (life_mtx);
+        life_cv.wait (lk, [&] {
+            for (auto &p : inside) if (p.first == c) return false;
+            return true; });
+    }
+};
+
+std::mutex g_pool_mtx;
+WorkerPool *g_pool = nullptr;           /* heap object, never destroyed at exit (threads may be parked in it) */
+
+WorkerPool *
+pool_get (uint32_t want_threads)
+{
+    std::lock_guard<std::mutex> g (g_pool_mtx);
+    if (!g_pool)
+        g_pool = new (std::nothrow) WorkerPool;
+    if (!g_pool)
+        return nullptr;
+    if (want_threads > (uint32_t) MAX_DEVICES)
+        want_threads = MAX_DEVICES;
+    try
+    {
+        while (g_pool->threads.size () < want_threads)
+            g_pool->threads.emplace_back ([p = g_pool] { p->run (); });
+    }
+    catch (...)
+    {
+        /* no thread available: the caller works through its strips itself */
+    }
+    return g_pool;
+}
+
+void
+pool_shutdown ()
+{
+    WorkerPool *p;
+    {
+        std::lock_guard<std::mutex> g (g_pool_mtx);
+        p = g_pool;
+        g_pool = nullptr;
+    }
+    if (!p)
+        return;
+    {
+        std::lock_guard<std::mutex> g (p->mtx);
+        p->stop = true;
+    }
+    p->cv.notify_all ();
+    for (std::thread &t : p->threads)
+        t.join ();
+    delete p;
+}
+
+int
+run_strips (Strip *strips, uint32_t n, bool pinned)
+{
+    int rc = 0;
+
+    if (n == 1)
+    {
+        rc = strip_issue (strips [0], true);
+        return rc ? rc : strip_finish (strips [0]);
+    }
+
+    if (pinned)
+    {
+        /* one thread drives every device: issue all strips, then wait for each. When a
+         * device is listed more often than it has lanes, finish what is pending first. */
+        uint32_t issued_from = 0;
+        for (uint32_t i = 0; i < n; i++)
+        {
+            int r = strip_issue (strips [i], false);
+            if (r == 1)
+            {
+                for (uint32_t j = issued_from; j < i; j++)
+                    if (strip_finish (strips [j]) && !rc)
+                        rc = strips [j].rc;
+                issued_from = i;
+                r = strip_issue (strips [i], true);
+            }
+            if (r && !rc)
+                rc = r;
+        }
+        for (uint32_t j = issued_from; j < n; j++)
+            if (strip_finish (strips [j]) && !rc)
+                rc = strips [j].rc;
+        return rc;
+    }
+
+    StripCall call;
+    call.strips = strips;
+    call.n = n;
+    WorkerPool *pool = pool_get (n - 1);
+    if (pool)
+    {
+        {
+            std::lock_guard<std::mutex> g (pool->mtx);
+            pool->queue.push_back (&call);
+        }
+        pool->cv.notify_all ();
+    }
+    strip_call_help (call);             /* the caller works too: progress never depends on the pool */
+    {
+        std::unique_lock<std::mutex> lk (call.mtx);
+        call.cv.wait (lk, [&] { return call.done.load () == call.n; });
+    }
+    if (pool)
+        pool->call_retire (&call);
+    for (uint32_t i = 0; i < n; i++)
+        if (strips [i].rc && !rc)
+            rc = strips [i].rc;
+    return rc;
+}
+
+} /* namespace */
 
 struct SmolHipBatch
 {
@@ -210,6 +678,7 @@ struct SmolHipBatch
     void *scratch = nullptr;               /* intermediate images of the two-pass box jobs */
     hipStream_t tstream = nullptr;         /* smol_hip_batch_time: stream and events, created once */
     hipEvent_t te0 = nullptr, te1 = nullptr;
+    std::vector<hipEvent_t> tev;           /* smol_hip_batch_time_each */
     struct Group { KClass k; uint32_t first, count; JobDev rep; uint32_t max_w_out, max_rows, max_lds; };
     std::vector<Group> groups;
     uint64_t dominant_units = 0;
@@ -218,6 +687,11 @@ struct SmolHipBatch
     hipGraph_t graph = nullptr;            /* optional: one kernel node per image */
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = false;
+};
+
+struct SmolHipBatchMulti
+{
+    std::vector<SmolHipBatch *> parts;     /* one per listed device (entries with no image: nullptr) */
 };
 
 extern "C" {
@@ -246,6 +720,10 @@ smol_hip_plan_create (const SmolHipJob *job, int device, SmolHipPlan **plan_out)
         return SMOL_HIP_E_INVALID;
     p->job = *job;
     p->device = device;
+    {
+        std::lock_guard<std::mutex> g (g_devices [device].ref_mtx);
+        g_devices [device].plans++;
+    }
     *plan_out = p;
     return 0;
 }
@@ -253,7 +731,34 @@ smol_hip_plan_create (const SmolHipJob *job, int device, SmolHipPlan **plan_out)
 void
 smol_hip_plan_destroy (SmolHipPlan *plan)
 {
+    if (!plan)
+        return;
+    const int device = plan->device;
+    if (plan->box_scratch && hipSetDevice (device) == hipSuccess)
+        (void) hipFree (plan->box_scratch);
     delete plan;
+
+    /* the last plan on a device takes the staging lanes with it */
+    bool last;
+    {
+        std::lock_guard<std::mutex> g (g_devices [device].ref_mtx);
+        last = --g_devices [device].plans == 0;
+    }
+    if (last)
+        device_release_lanes (device);
+}
+
+int
+smol_hip_plan_prepare (SmolHipPlan *plan)
+{
+    if (!plan)
+        return SMOL_HIP_E_INVALID;
+    const SmolHipJob &j = plan->job;
+    if (j.filter_h != SMOL_HIP_FILTER_BOX || j.filter_v != SMOL_HIP_FILTER_BOX)
+        return 0;
+    HIP_TRY (hipSetDevice (plan->device));
+    void *p;
+    return plan_box_scratch (plan, &p);
 }
 
 int
@@ -267,14 +772,27 @@ smol_hip_scale_rows_device (SmolHipPlan *plan,
         return SMOL_HIP_E_INVALID;
     if (n_rows == 0)
         return 0;
-    if (first_row + n_rows > plan->job.height_out)
+    if (!rows_ok (first_row, n_rows, plan->job.height_out))
         return SMOL_HIP_E_INVALID;
 
     HIP_TRY (hipSetDevice (plan->device));
 
     JobDev jd;
     fill_jobdev (jd, plan->job, pixels_in_dev, rowstride_in, dest_dev, rowstride_out, first_row, n_rows);
-    HIP_TRY (launch_single (jd, static_cast<hipStream_t> (hip_stream)));
+    void *scratch = nullptr;
+    {
+        JobDev probe = jd;
+        if (classify (probe) == KC_BOX2)
+        {
+            int rc = plan_box_scratch (plan, &scratch);
+            if (rc)
+                return rc;
+            /* the kernels index the intermediate image from the job's first source row:
+             * shift the base so that row r of the image always lands at r * w_out * 8 */
+            scratch = static_cast<uint8_t *> (scratch) + (size_t) probe.tmp_row0 * probe.w_out * 8;
+        }
+    }
+    HIP_TRY (launch_single (jd, static_cast<hipStream_t> (hip_stream), scratch));
     return 0;
 }
 
@@ -284,67 +802,117 @@ smol_hip_scale_rows_host (SmolHipPlan *plan,
                           void *dest_host, uint32_t rowstride_out,
                           uint32_t first_row, uint32_t n_rows)
 {
-    if (!plan || !pixels_in_host || !dest_host)
+    return smol_hip_scale_rows_host_multi (&plan, 1, pixels_in_host, rowstride_in,
+                                           dest_host, rowstride_out, first_row, n_rows);
+}
+
+int
+smol_hip_scale_rows_host_multi (SmolHipPlan *const *plans, uint32_t n_plans,
+                                const void *pixels_in_host, uint32_t rowstride_in,
+                                void *dest_host, uint32_t rowstride_out,
+                                uint32_t first_row, uint32_t n_rows)
+{
+    if (!plans || !n_plans || n_plans > (uint32_t) MAX_DEVICES || !pixels_in_host || !dest_host)
+        return SMOL_HIP_E_INVALID;
+    for (uint32_t i = 0; i < n_plans; i++)
+        if (!plans [i])
+            return SMOL_HIP_E_INVALID;
+    if (n_rows == 0)
+        return 0;
+    if (!rows_ok (first_row, n_rows, plans [0]->job.height_out))
+        return SMOL_HIP_E_INVALID;
+
+    Strip strips [MAX_DEVICES];
+    const uint32_t per = (n_rows + n_plans - 1) / n_plans;
+    uint32_t n_strips = 0, done = 0;
+
+    for (uint32_t i = 0; i < n_plans && done < n_rows; i++)
+    {
+        Strip &st = strips [n_strips++];
+        st.plan = plans [i];
+        st.src = static_cast<const uint8_t *> (pixels_in_host);
+        st.rowstride_in = rowstride_in;
+        st.dest = static_cast<uint8_t *> (dest_host) + (size_t) rowstride_out * done;
+        st.rowstride_out = rowstride_out;
+        st.first = first_row + done;
+        st.n = (n_rows - done < per) ? n_rows - done : per;
+        done += st.n;
+    }
+
+    bool pinned = false;
+    if (n_strips > 1)
+    {
+        HIP_TRY (hipSetDevice (plans [0]->device));
+        pinned = host_ptr_is_pinned (pixels_in_host) && host_ptr_is_pinned (dest_host);
+    }
+    return run_strips (strips, n_strips, pinned);
+}
+
+int
+smol_hip_scale_rows_peer (SmolHipPlan *plan, int src_device,
+                          const void *pixels_in_dev, uint32_t rowstride_in,
+                          void *dest_host, uint32_t rowstride_out,
+                          uint32_t first_row, uint32_t n_rows)
+{
+    if (!plan || !pixels_in_dev || !dest_host || src_device < 0 || src_device >= smol_hip_device_count ())
         return SMOL_HIP_E_INVALID;
     if (n_rows == 0)
         return 0;
-
-    const SmolHipJob &job = plan->job;
-    uint32_t r0, r1;
-    int rc = smol_hip_input_row_range (&job, first_row, n_rows, &r0, &r1);
-    if (rc)
-        return rc;
-
-    HIP_TRY (hipSetDevice (plan->device));
-
-    const TypeInfo &ti = k_types [job.pixel_type_in];
-    const TypeInfo &to = k_types [job.pixel_type_out];
-    const size_t in_row_bytes = (size_t) job.width_in * ti.bpp;
-    const size_t out_row_bytes = (size_t) job.width_out * to.bpp;
-    /* Device rows are re-pitched to 16-byte multiples whatever the host strides
-     * are, so kernels see aligned rows even for odd host layouts (the reference
-     * copies odd rows to an aligned temporary: smolscale-generic.c:1623-1634). */
-    const size_t src_pitch = align_up (in_row_bytes, 16);
-    const size_t dst_pitch = align_up (out_row_bytes, 16);
-    const size_t n_in_rows = (size_t) r1 - r0 + 1;
-
-    if (src_pitch > 0xffffffffu || dst_pitch > 0xffffffffu)
+    if (!rows_ok (first_row, n_rows, plan->job.height_out))
         return SMOL_HIP_E_INVALID;
 
-    DeviceState &ds = g_devices [plan->device];
-    Lane &ln = ds.lanes [ds.next.fetch_add (1) % N_LANES];
-    std::lock_guard<std::mutex> guard (ln.mtx);
-
-    rc = lane_prepare (ln, n_in_rows * src_pitch + 64, (size_t) n_rows * dst_pitch + 64);
-    if (rc)
-        return rc;
-
-    const uint8_t *host_src = static_cast<const uint8_t *> (pixels_in_host) + (size_t) r0 * rowstride_in;
-    HIP_TRY (hipMemcpy2DAsync (ln.src_buf, src_pitch, host_src, rowstride_in,
-                               in_row_bytes, n_in_rows, hipMemcpyHostToDevice, ln.stream));
-
-    /* Row 0 of the virtual source image lies r0 rows before the slab. */
-    const uint8_t *virt_src = static_cast<const uint8_t *> (ln.src_buf) - (size_t) r0 * src_pitch;
-    JobDev jd;
-    fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch, ln.dst_buf, (uint32_t) dst_pitch,
-                 first_row, n_rows);
+    if (src_device != plan->device)
     {
-        /* the two-pass box filter keeps its intermediate image in the lane */
-        JobDev probe = jd;
-        if (classify (probe) == KC_BOX2)
+        int can = 0;
+        HIP_TRY (hipDeviceCanAccessPeer (&can, plan->device, src_device));
+        if (can)
         {
-            rc = lane_prepare_tmp (ln, box2_tmp_bytes (probe) + 64);
-            if (rc)
-                return rc;
-            HIP_TRY (launch_single (jd, ln.stream, ln.tmp_buf));
+            HIP_TRY (hipSetDevice (plan->device));
+            const hipError_t e = hipDeviceEnablePeerAccess (src_device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                return -(int) e;
+            (void) hipGetLastError ();
         }
-        else
-            HIP_TRY (launch_single (jd, ln.stream));
+        /* without peer access the runtime stages the copy through the host */
     }
-    HIP_TRY (hipMemcpy2DAsync (dest_host, rowstride_out, ln.dst_buf, dst_pitch,
-                               out_row_bytes, n_rows, hipMemcpyDeviceToHost, ln.stream));
-    HIP_TRY (hipStreamSynchronize (ln.stream));
+
+    Strip st;
+    st.plan = plan;
+    st.src = static_cast<const uint8_t *> (pixels_in_dev);
+    st.src_device = src_device;
+    st.rowstride_in = rowstride_in;
+    st.dest = static_cast<uint8_t *> (dest_host);
+    st.rowstride_out = rowstride_out;
+    st.first = first_row;
+    st.n = n_rows;
+    return run_strips (&st, 1, false);
+}
+
+int
+smol_hip_host_register (void *host_ptr, uint64_t n_bytes)
+{
+    if (!host_ptr || !n_bytes)
+        return SMOL_HIP_E_INVALID;
+    HIP_TRY (hipHostRegister (host_ptr, n_bytes, hipHostRegisterPortable));
     return 0;
+}
+
+int
+smol_hip_host_unregister (void *host_ptr)
+{
+    if (!host_ptr)
+        return SMOL_HIP_E_INVALID;
+    HIP_TRY (hipHostUnregister (host_ptr));
+    return 0;
+}
+
+void
+smol_hip_shutdown (void)
+{
+    pool_shutdown ();
+    const int n = smol_hip_device_count ();
+    for (int d = 0; d < n && d < MAX_DEVICES; d++)
+        device_release_lanes (d);
 }
 
 /* ---- batches -------------------------------------------------------------- */
@@ -360,20 +928,28 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
 
     HIP_TRY (hipSetDevice (device));
 
-    std::vector<JobDev> jobs (n_images);
-    std::vector<KClass> cls (n_images);
+    std::vector<JobDev> jobs;
+    std::vector<KClass> cls;
+    jobs.reserve (n_images);
+    cls.reserve (n_images);
 
     for (uint32_t i = 0; i < n_images; i++)
     {
         const SmolHipImage &im = images [i];
 
-        if (im.job.pixel_type_in >= 10 || im.job.pixel_type_out >= 10 || !im.src || !im.dst
-            || im.first_row + im.n_rows > im.job.height_out)
+        if (im.job.pixel_type_in >= 10 || im.job.pixel_type_out >= 10)
             return SMOL_HIP_E_INVALID;
-        fill_jobdev (jobs [i], im.job, im.src, im.rowstride_in, im.dst, im.rowstride_out,
+        if (im.n_rows == 0)
+            continue;                   /* an empty strip (more ranks than rows): nothing to launch */
+        if (!im.src || !im.dst || !rows_ok (im.first_row, im.n_rows, im.job.height_out))
+            return SMOL_HIP_E_INVALID;
+        JobDev jd;
+        fill_jobdev (jd, im.job, im.src, im.rowstride_in, im.dst, im.rowstride_out,
                      im.first_row, im.n_rows);
-        cls [i] = classify (jobs [i]);
+        cls.push_back (classify (jd));
+        jobs.push_back (jd);
     }
+    n_images = (uint32_t) jobs.size ();
 
     SmolHipBatch *b = new (std::nothrow) SmolHipBatch;
     if (!b)
@@ -483,9 +1059,9 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                     }
         }
     }
-    if (e == hipSuccess)
+    if (e == hipSuccess && !sorted.empty ())
         e = hipMalloc (reinterpret_cast<void **> (&b->jobs_dev), sorted.size () * sizeof (JobDev));
-    if (e == hipSuccess)
+    if (e == hipSuccess && !sorted.empty ())
         e = hipMemcpy (b->jobs_dev, sorted.data (), sorted.size () * sizeof (JobDev), hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
@@ -595,6 +1171,8 @@ smol_hip_batch_destroy (SmolHipBatch *batch)
             (void) hipEventDestroy (batch->te1);
             (void) hipStreamDestroy (batch->tstream);
         }
+        for (hipEvent_t ev : batch->tev)
+            (void) hipEventDestroy (ev);
         if (batch->graph_exec)
             (void) hipGraphExecDestroy (batch->graph_exec);
         if (batch->graph)
@@ -603,40 +1181,206 @@ smol_hip_batch_destroy (SmolHipBatch *batch)
     delete batch;
 }
 
+namespace {
+
+/* the timing stream and its events live with the batch: creating a stream costs a few
+ * hundred microseconds, which a caller timing K launches would see as a fixed overhead */
 int
-smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_total)
+batch_timing_setup (SmolHipBatch *batch)
 {
-    if (!batch || !ms_total || !iters)
-        return SMOL_HIP_E_INVALID;
-
     HIP_TRY (hipSetDevice (batch->device));
-
-    /* the timing stream and its events live with the batch: creating a stream costs a few
-     * hundred microseconds, which a caller timing K launches would see as a fixed overhead */
     if (!batch->tstream)
     {
         HIP_TRY (hipStreamCreateWithFlags (&batch->tstream, hipStreamNonBlocking));
         HIP_TRY (hipEventCreate (&batch->te0));
         HIP_TRY (hipEventCreate (&batch->te1));
     }
-    const hipStream_t s = batch->tstream;
-    const hipEvent_t e0 = batch->te0, e1 = batch->te1;
+    return 0;
+}
 
-    int rc = 0;
+/* warm-up launches, wait, e0, `iters' launches, e1 -- all asynchronous after the wait */
+int
+batch_time_issue (SmolHipBatch *batch, uint32_t warmup, uint32_t iters)
+{
+    int rc = batch_timing_setup (batch);
+    const hipStream_t s = batch->tstream;
+
     for (uint32_t i = 0; i < warmup && !rc; i++)
         rc = smol_hip_batch_launch (batch, s);
-    if (!rc)
-    {
-        HIP_TRY (hipStreamSynchronize (s));
-        HIP_TRY (hipEventRecord (e0, s));
-        for (uint32_t i = 0; i < iters && !rc; i++)
-            rc = smol_hip_batch_launch (batch, s);
-        HIP_TRY (hipEventRecord (e1, s));
-        HIP_TRY (hipEventSynchronize (e1));
-        HIP_TRY (hipEventElapsedTime (ms_total, e0, e1));
-    }
-
+    if (rc)
+        return rc;
+    HIP_TRY (hipStreamSynchronize (s));
+    HIP_TRY (hipEventRecord (batch->te0, s));
+    for (uint32_t i = 0; i < iters && !rc; i++)
+        rc = smol_hip_batch_launch (batch, s);
+    HIP_TRY (hipEventRecord (batch->te1, s));
     return rc;
+}
+
+int
+batch_time_collect (SmolHipBatch *batch, float *ms_total)
+{
+    HIP_TRY (hipSetDevice (batch->device));
+    HIP_TRY (hipEventSynchronize (batch->te1));
+    HIP_TRY (hipEventElapsedTime (ms_total, batch->te0, batch->te1));
+    return 0;
+}
+
+} /* namespace */
+
+int
+smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_total)
+{
+    if (!batch || !ms_total || !iters)
+        return SMOL_HIP_E_INVALID;
+
+    int rc = batch_time_issue (batch, warmup, iters);
+    const int rc2 = batch_time_collect (batch, ms_total);
+    return rc ? rc : rc2;
+}
+
+int
+smol_hip_batch_time_each (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_each)
+{
+    if (!batch || !ms_each || !iters)
+        return SMOL_HIP_E_INVALID;
+
+    int rc = batch_timing_setup (batch);
+    if (rc)
+        return rc;
+    while (batch->tev.size () < (size_t) iters + 1)
+    {
+        hipEvent_t ev;
+        HIP_TRY (hipEventCreate (&ev));
+        batch->tev.push_back (ev);
+    }
+    const hipStream_t s = batch->tstream;
+
+    for (uint32_t i = 0; i < warmup && !rc; i++)
+        rc = smol_hip_batch_launch (batch, s);
+    if (rc)
+        return rc;
+    HIP_TRY (hipStreamSynchronize (s));
+    HIP_TRY (hipEventRecord (batch->tev [0], s));
+    for (uint32_t i = 0; i < iters && !rc; i++)
+    {
+        rc = smol_hip_batch_launch (batch, s);
+        HIP_TRY (hipEventRecord (batch->tev [i + 1], s));
+    }
+    HIP_TRY (hipEventSynchronize (batch->tev [iters]));
+    for (uint32_t i = 0; i < iters; i++)
+        HIP_TRY (hipEventElapsedTime (&ms_each [i], batch->tev [i], batch->tev [i + 1]));
+    return rc;
+}
+
+/* ---- a batch over several devices (image i -> devices [i % n_devices]) ------------- */
+
+int
+smol_hip_batch_create_multi (const SmolHipImage *images, uint32_t n_images,
+                             const int *devices, uint32_t n_devices,
+                             SmolHipBatchMulti **batch_out)
+{
+    if (!images || !n_images || !devices || !n_devices || n_devices > (uint32_t) MAX_DEVICES || !batch_out)
+        return SMOL_HIP_E_INVALID;
+
+    SmolHipBatchMulti *m = new (std::nothrow) SmolHipBatchMulti;
+    if (!m)
+        return SMOL_HIP_E_INVALID;
+    m->parts.assign (n_devices, nullptr);
+
+    std::vector<SmolHipImage> mine;
+    for (uint32_t d = 0; d < n_devices; d++)
+    {
+        mine.clear ();
+        for (uint32_t i = d; i < n_images; i += n_devices)
+            mine.push_back (images [i]);
+        if (mine.empty ())
+            continue;
+        const int rc = smol_hip_batch_create (mine.data (), (uint32_t) mine.size (), devices [d], &m->parts [d]);
+        if (rc)
+        {
+            smol_hip_batch_multi_destroy (m);
+            return rc;
+        }
+        /* every part runs on a stream of its own, the one its timing helper uses too */
+        const int rc2 = batch_timing_setup (m->parts [d]);
+        if (rc2)
+        {
+            smol_hip_batch_multi_destroy (m);
+            return rc2;
+        }
+    }
+    *batch_out = m;
+    return 0;
+}
+
+int
+smol_hip_batch_multi_launch (SmolHipBatchMulti *batch)
+{
+    if (!batch)
+        return SMOL_HIP_E_INVALID;
+    int rc = 0;
+    for (SmolHipBatch *b : batch->parts)
+        if (b)
+        {
+            const int r = smol_hip_batch_launch (b, b->tstream);
+            if (r && !rc)
+                rc = r;
+        }
+    return rc;
+}
+
+int
+smol_hip_batch_multi_sync (SmolHipBatchMulti *batch)
+{
+    if (!batch)
+        return SMOL_HIP_E_INVALID;
+    for (SmolHipBatch *b : batch->parts)
+        if (b)
+        {
+            HIP_TRY (hipSetDevice (b->device));
+            HIP_TRY (hipStreamSynchronize (b->tstream));
+        }
+    return 0;
+}
+
+int
+smol_hip_batch_multi_time (SmolHipBatchMulti *batch, uint32_t warmup, uint32_t iters, float *ms_per_device)
+{
+    if (!batch || !ms_per_device || !iters)
+        return SMOL_HIP_E_INVALID;
+
+    int rc = 0;
+    /* every device first gets its whole queue (warm-up, e0, launches, e1), then all are collected:
+     * the devices run concurrently, the host thread only feeds them */
+    for (SmolHipBatch *b : batch->parts)
+        if (b)
+        {
+            const int r = batch_time_issue (b, warmup, iters);
+            if (r && !rc)
+                rc = r;
+        }
+    for (size_t d = 0; d < batch->parts.size (); d++)
+    {
+        ms_per_device [d] = 0.0f;
+        if (batch->parts [d])
+        {
+            const int r = batch_time_collect (batch->parts [d], &ms_per_device [d]);
+            if (r && !rc)
+                rc = r;
+        }
+    }
+    return rc;
+}
+
+void
+smol_hip_batch_multi_destroy (SmolHipBatchMulti *batch)
+{
+    if (!batch)
+        return;
+    for (SmolHipBatch *b : batch->parts)
+        smol_hip_batch_destroy (b);
+    delete batch;
 }
 
 /* ---- memory helpers ---------------------------------------------------------- */

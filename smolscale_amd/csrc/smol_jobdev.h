@@ -12,6 +12,16 @@
 
 namespace smolhip {
 
+/* Tuning / ablation knobs (SMOL_TILE_ROWS, SMOL_NO_UP, SMOL_TILE_DBG ...) exist only in
+ * builds made with -DSMOL_TUNING (make EXTRA=-DSMOL_TUNING, used by tests/exp and tools/
+ * sweeps). The shipped library never looks at the environment on the dispatch path, so a
+ * stray variable cannot change which kernel runs or what it computes. */
+#ifdef SMOL_TUNING
+inline const char *tune_env (const char *name) { return getenv (name); }
+#else
+inline const char *tune_env (const char *) { return nullptr; }
+#endif
+
 enum : uint8_t { F_COPY = 0, F_ONE = 1, F_BILINEAR = 2, F_BOX = 3 };
 
 /* LDS copy of the parity tables: four inverse tables (4 x 1 KB), from_srgb (512 B), to_srgb (2 KB)
@@ -56,7 +66,7 @@ struct JobDev
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
     uint8_t box2_vlpc;             /* k_boxv: lanes per output pixel (1 or 8)           */
     uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
-    uint8_t dbg;                   /* timing ablations (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores */
+    uint8_t dbg;                   /* -DSMOL_TUNING builds only (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores; else 0 */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
@@ -93,7 +103,7 @@ tile_ok (const JobDev &d)
 inline bool
 wtile_ok (const JobDev &d)
 {
-    if (!d.wide || d.filter_h == F_BOX || d.filter_v == F_BOX || getenv ("SMOL_NO_WTILE"))
+    if (!d.wide || d.filter_h == F_BOX || d.filter_v == F_BOX || tune_env ("SMOL_NO_WTILE"))
         return false;
     /* Measured (profiles/r01b_wide_kernels.log): converting each staged pixel once
      * pays when pixels or rows are re-used -- magnification (2.2-3x over k_general)
@@ -123,7 +133,7 @@ tile_setup (JobDev &d)
     if (!d.wide && d.out3_ok && d.w_out >= 256 && d.filter_v != F_BOX
         && d.filter_h == F_BILINEAR && d.halv_h <= 1)
         d.tile_cpl = 4;
-    if (const char *e = getenv ("SMOL_TILE_CPL"))
+    if (const char *e = tune_env ("SMOL_TILE_CPL"))
         if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX)
             d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
     uint64_t cols = 64u * d.tile_cpl;
@@ -134,7 +144,7 @@ tile_setup (JobDev &d)
     {
         /* narrow boxes: one lane per column; wide ones: 8 lanes per column, 8 columns per tile */
         uint64_t lpc8_min = 24;                 /* ratio above which a column gets 8 lanes */
-        if (const char *e = getenv ("SMOL_TILE_BOX_LPC8_MIN"))
+        if (const char *e = tune_env ("SMOL_TILE_BOX_LPC8_MIN"))
             lpc8_min = (uint64_t) atoi (e);
         box_lpc = (d.step_x > (lpc8_min << 16)) ? 8 : 1;
         cols = 64u / box_lpc;
@@ -155,10 +165,12 @@ tile_setup (JobDev &d)
 
     d.span_px = (uint32_t) span_px;
     uint32_t budget = TILE_LDS_BUDGET;
-    if (const char *e = getenv ("SMOL_TILE_LDS_BUDGET"))
+    if (const char *e = tune_env ("SMOL_TILE_LDS_BUDGET"))
         budget = (uint32_t) atoi (e);
-    if (const char *e = getenv ("SMOL_TILE_DBG"))
+#ifdef SMOL_TUNING
+    if (const char *e = tune_env ("SMOL_TILE_DBG"))
         d.dbg = (uint8_t) atoi (e);
+#endif
     uint32_t rows = budget / (d.span_chunks * 16);
     if (rows < 2 && 2 * d.span_chunks * 16 <= 8192)
         rows = 2;                   /* one-row groups leave the wave waiting on every row */
@@ -177,7 +189,7 @@ tile_setup (JobDev &d)
         th = (d.step_y < ((uint64_t) 1 << 32)) ? 32 : (d.halv_v ? (16u >> d.halv_v) : 8u);   /* measured: 8 beats 16 without halvings */
     else
         th = (d.filter_v == F_ONE) ? 32 : 16;
-    if (const char *e = getenv ("SMOL_TILE_ROWS"))
+    if (const char *e = tune_env ("SMOL_TILE_ROWS"))
         th = (uint32_t) atoi (e);
     if (th > (128u >> (d.filter_v == F_BILINEAR ? d.halv_v : 0)))
         th = 128u >> (d.filter_v == F_BILINEAR ? d.halv_v : 0);     /* <= 128 vertical samples per tile */
@@ -197,7 +209,7 @@ tile_setup (JobDev &d)
          * when every pixel feeds one tap, premultiply at the tap and keep the
          * double-buffered DMA staging */
         const bool reuse = d.filter_h != F_BILINEAR || d.step_x < ((uint64_t) 1 << 32)
-                           || getenv ("SMOL_TILE_PREMUL_STAGE");
+                           || tune_env ("SMOL_TILE_PREMUL_STAGE");
         tapsel = reuse ? 1 : 2;
     }
     else
@@ -215,8 +227,8 @@ tile_setup (JobDev &d)
         out = 2;
 
     d.tile_variant = (uint8_t) ((tapsel << 5) | (hm << 2) | out);
-    d.tile_band = ((d.w_out + cols - 1) / cols >= 64 && !getenv ("SMOL_NO_TILE_BAND"));
-    d.tile_vcopy = (d.filter_v == F_COPY && d.tile_cpl == 1 && hm >= 1 && hm <= 3 && !getenv ("SMOL_NO_TILE_VCOPY"));
+    d.tile_band = ((d.w_out + cols - 1) / cols >= 64 && !tune_env ("SMOL_NO_TILE_BAND"));
+    d.tile_vcopy = (d.filter_v == F_COPY && d.tile_cpl == 1 && hm >= 1 && hm <= 3 && !tune_env ("SMOL_NO_TILE_VCOPY"));
     d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
     d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);
 }
@@ -320,7 +332,7 @@ pow2x_setup (JobDev &d)
         return false;
     if (d.w_in != (d.w_out << (d.halv_h + 1)) || d.h_in != (d.h_out << (d.halv_v + 1)))
         return false;
-    if (getenv ("SMOL_NO_POW2X"))
+    if (tune_env ("SMOL_NO_POW2X"))
         return false;
 
     const uint32_t opt = pow2x_opt (d);
@@ -377,14 +389,14 @@ up_setup (JobDev &d)
         return false;
     if (d.step_x >= ((uint64_t) 1 << 32) || d.step_y >= ((uint64_t) 1 << 32) || d.step_x == 0 || d.step_y == 0)
         return false;
-    if (d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_UP") || (flavour >= 2 && getenv ("SMOL_NO_UP_GEN")))
+    if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_UP") || (flavour >= 2 && tune_env ("SMOL_NO_UP_GEN")))
         return false;
 
     d.up_wide = (uint8_t) flavour;
     uint64_t tr = (((uint64_t) ((flavour ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
     if (tr > 64)
         tr = 64;
-    if (const char *e = getenv ("SMOL_UP_ROWS"))
+    if (const char *e = tune_env ("SMOL_UP_ROWS"))
         if ((uint64_t) atoi (e) >= 1 && (uint64_t) atoi (e) < tr)
             tr = (uint64_t) atoi (e);
     d.tile_rows = (uint16_t) tr;
@@ -439,7 +451,7 @@ down_setup (JobDev &d)
         return false;
     if (d.step_x < ((uint64_t) 1 << 32) || d.step_y < ((uint64_t) 1 << 32))
         return false;
-    if (d.w_in < 2 || d.h_in < 2 || getenv ("SMOL_NO_DOWN"))
+    if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_DOWN"))
         return false;
 
     const bool aligned32 = d.bpp_in == 4 && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0;
@@ -450,11 +462,11 @@ down_setup (JobDev &d)
         mode = 2;
     else
         mode = 1;
-    if (mode && getenv ("SMOL_NO_DOWN_GEN"))
+    if (mode && tune_env ("SMOL_NO_DOWN_GEN"))
         return false;
 
     /* one sample per column and a wide enough image: 4 columns per lane (mode 0 only) */
-    const uint32_t cpl = (mode == 0 && d.halv_h == 0 && d.w_out >= 256 && !getenv ("SMOL_DOWN_CPL1")) ? 4 : 1;
+    const uint32_t cpl = (mode == 0 && d.halv_h == 0 && d.w_out >= 256 && !tune_env ("SMOL_DOWN_CPL1")) ? 4 : 1;
 
     /* source pixels a tile can reach, rounded up to whole 4-pixel chunks */
     uint64_t span = ((((uint64_t) (64u * cpl) << d.halv_h) * d.step_x) >> 32) + 3;
@@ -466,7 +478,7 @@ down_setup (JobDev &d)
     d.span_px = (uint32_t) span;
 
     uint32_t th = 16u >> d.halv_v;              /* <= 128 vertical samples per tile */
-    if (const char *e = getenv ("SMOL_DOWN_ROWS"))
+    if (const char *e = tune_env ("SMOL_DOWN_ROWS"))
         th = (uint32_t) atoi (e);
     if (th > (128u >> d.halv_v))
         th = 128u >> d.halv_v;
@@ -516,10 +528,10 @@ constexpr uint32_t BOXH_ROWS_HOST = 8;
 inline bool
 box2_setup (JobDev &d)
 {
-    if (d.filter_h != F_BOX || d.filter_v != F_BOX || getenv ("SMOL_NO_BOX2") || d.n_rows == 0)
+    if (d.filter_h != F_BOX || d.filter_v != F_BOX || tune_env ("SMOL_NO_BOX2") || d.n_rows == 0)
         return false;
     uint64_t min_ratio = 12;
-    if (const char *e = getenv ("SMOL_BOX2_MIN"))
+    if (const char *e = tune_env ("SMOL_BOX2_MIN"))
         min_ratio = (uint64_t) atoi (e);
     if (!d.wide && d.step_y < (min_ratio << 16))
         return false;
@@ -531,7 +543,7 @@ box2_setup (JobDev &d)
     /* pass 1: 64 columns per wave, or 8 columns with 8 lanes each when a column's span is very
      * wide (then 64 columns' worth of a row would not fit the LDS either) */
     uint64_t lpc8_min = 48;
-    if (const char *e = getenv ("SMOL_BOX2_LPC8_MIN"))
+    if (const char *e = tune_env ("SMOL_BOX2_LPC8_MIN"))
         lpc8_min = (uint64_t) atoi (e);
     const uint32_t lpc = (d.step_x > (lpc8_min << 16)) ? 8u : 1u;
 

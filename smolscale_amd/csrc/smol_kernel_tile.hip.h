@@ -667,7 +667,12 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     uint32_t nrows = (row_last - gfirst + 1 < J.group_rows) ? row_last - gfirst + 1 : J.group_rows;
     uint32_t cur = 0;
 
-    const bool dbg_notaps = J.dbg & 1, dbg_nostage = J.dbg & 2, dbg_nostore = J.dbg & 4;
+#ifdef SMOL_TUNING
+    const uint32_t dbg = J.dbg;         /* timing ablations: never in the shipped library */
+#else
+    constexpr uint32_t dbg = 0;
+#endif
+    const bool dbg_notaps = dbg & 1, dbg_nostage = dbg & 2, dbg_nostore = dbg & 4;
     uint32_t stores_since_dma = 0;      /* output rows stored since the last DMA issue (>= 1 store each) */
 
     if (DMA && !dbg_nostage)
@@ -684,7 +689,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
              * than `stores_since_dma' (a lower bound of the stores issued since) are
              * outstanding retires the DMA without draining the stores. Then start the
              * next group into the other buffer so it streams in during the consume. */
-            if (J.dbg & 8)
+            if (dbg & 8)
                 smol_wait_vmcnt0 ();
             else
                 smol_wait_vmcnt_le (stores_since_dma);

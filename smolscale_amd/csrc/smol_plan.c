@@ -198,7 +198,8 @@ smol_hip_input_row_range (const SmolHipJob *job, uint32_t first_row, uint32_t n_
 {
     uint32_t a, b, f;
 
-    if (!job || n_rows == 0 || first_row + n_rows > job->height_out)
+    /* first_row + n_rows <= height_out, written so that it cannot wrap */
+    if (!job || n_rows == 0 || first_row >= job->height_out || n_rows > job->height_out - first_row)
         return SMOL_HIP_E_INVALID;
 
     switch (job->filter_v)

@@ -14,7 +14,6 @@
  * library reports why on stderr and abort()s -- the reference's own reaction to
  * an unusable configuration (smolscale.c:779-780, 812-813). No CPU fallback. */
 
-#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -39,8 +38,7 @@ struct SmolScaleCtx
     void *user_data;
 
     const SmolBackend *backend;
-    void *backend_state;            /* SmolHipPlan * of the first device        */
-    void *more_plans [SMOL_MAX_DEVICES - 1];   /* further devices (row sharding) */
+    SmolHipPlan *plans [SMOL_MAX_DEVICES];  /* one per device (row sharding)      */
     int n_plans;
 };
 
@@ -60,44 +58,62 @@ struct SmolBackend
 /* Which GPUs a context uses. SMOL_HIP_DEVICES="0,1,2,3" or "all": output rows of
  * every batch are split into one strip per listed device (the reference's own
  * strip rule for its worker threads, test.c:870-877) and the strips run
- * concurrently, each on its device's stream -- rows are independent, so there is
- * no exchange between devices. A device may be listed more than once.
- * Without it, SMOL_HIP_DEVICE=<n> (default 0) selects a single GPU. */
+ * concurrently, each through its device's side streams -- rows are independent, so
+ * there is no exchange between devices. A device may be listed more than once.
+ * Without it, SMOL_HIP_DEVICE=<n> (default 0) selects a single GPU.
+ * Returns the number of devices, or a negative error for a malformed list. */
+static int
+parse_device (const char **p, int count, int *out)
+{
+    char *end;
+    long v;
+
+    v = strtol (*p, &end, 10);
+    if (end == *p || v < 0 || v >= count)
+        return SMOL_HIP_E_INVALID;
+    *out = (int) v;
+    *p = end;
+    return 0;
+}
+
 static int
 hip_devices_from_env (int *devices)
 {
     const char *e = getenv ("SMOL_HIP_DEVICES");
+    int count = smol_hip_device_count ();
     int n = 0;
+
+    if (count < 1)
+        return SMOL_HIP_E_NO_DEVICE;
+    if (count > SMOL_MAX_DEVICES)
+        count = SMOL_MAX_DEVICES;
 
     if (e && *e)
     {
         if (!strcmp (e, "all"))
         {
-            int count = smol_hip_device_count ();
-            for (n = 0; n < count && n < SMOL_MAX_DEVICES; n++)
+            for (n = 0; n < count; n++)
                 devices [n] = n;
+            return n;
         }
-        else
+        while (*e)
         {
-            const char *p = e;
-            while (*p && n < SMOL_MAX_DEVICES)
-            {
-                devices [n++] = atoi (p);
-                while (*p && *p != ',')
-                    p++;
-                if (*p == ',')
-                    p++;
-            }
+            if (n == SMOL_MAX_DEVICES || parse_device (&e, count, &devices [n]))
+                return SMOL_HIP_E_INVALID;
+            n++;
+            if (*e == ',')
+                e++;
+            else if (*e)
+                return SMOL_HIP_E_INVALID;
         }
+        return n ? n : SMOL_HIP_E_INVALID;
     }
 
-    if (n == 0)
-    {
-        e = getenv ("SMOL_HIP_DEVICE");
-        devices [0] = e ? atoi (e) : 0;
-        n = 1;
-    }
-    return n;
+    devices [0] = 0;
+    e = getenv ("SMOL_HIP_DEVICE");
+    if (e && *e && (parse_device (&e, count, &devices [0]) || *e))
+        return SMOL_HIP_E_INVALID;
+    return 1;
 }
 
 static void
@@ -105,11 +121,8 @@ hip_backend_fini (SmolScaleCtx *ctx)
 {
     int i;
 
-    if (ctx->backend_state)
-        smol_hip_plan_destroy ((SmolHipPlan *) ctx->backend_state);
-    for (i = 0; i + 1 < ctx->n_plans; i++)
-        smol_hip_plan_destroy ((SmolHipPlan *) ctx->more_plans [i]);
-    ctx->backend_state = NULL;
+    for (i = 0; i < ctx->n_plans; i++)
+        smol_hip_plan_destroy (ctx->plans [i]);
     ctx->n_plans = 0;
 }
 
@@ -127,88 +140,30 @@ hip_backend_init (SmolScaleCtx *ctx)
         return rc;
 
     n = hip_devices_from_env (devices);
+    if (n < 0)
+        return n;
     ctx->n_plans = 0;
     for (i = 0; i < n; i++)
     {
-        SmolHipPlan *plan = NULL;
-
-        rc = smol_hip_plan_create (&job, devices [i], &plan);
+        rc = smol_hip_plan_create (&job, devices [i], &ctx->plans [i]);
         if (rc)
         {
             hip_backend_fini (ctx);
             return rc;
         }
-        if (i == 0)
-            ctx->backend_state = plan;
-        else
-            ctx->more_plans [i - 1] = plan;
         ctx->n_plans = i + 1;
     }
     return 0;
 }
 
-typedef struct
-{
-    const SmolScaleCtx *ctx;
-    SmolHipPlan *plan;
-    void *dest;
-    uint32_t first, n;
-    int rc;
-}
-HipStrip;
-
-static void *
-hip_strip_worker (void *arg)
-{
-    HipStrip *s = arg;
-
-    s->rc = smol_hip_scale_rows_host (s->plan, s->ctx->pixels_in, s->ctx->rowstride_in,
-                                      s->dest, s->ctx->rowstride_out, s->first, s->n);
-    return NULL;
-}
-
+/* One strip per device, all in flight together; the shim fans them out (asynchronous
+ * streams for page-locked memory, its persistent worker threads otherwise). */
 static int
 hip_backend_batch (const SmolScaleCtx *ctx, void *dest, uint32_t first, uint32_t n)
 {
-    HipStrip strips [SMOL_MAX_DEVICES];
-    pthread_t tids [SMOL_MAX_DEVICES];
-    uint32_t rows, done = 0;
-    int n_strips = 0, i, rc = 0;
-
-    if (ctx->n_plans <= 1 || n < (uint32_t) ctx->n_plans)
-        return smol_hip_scale_rows_host ((SmolHipPlan *) ctx->backend_state,
-                                         ctx->pixels_in, ctx->rowstride_in,
-                                         dest, ctx->rowstride_out, first, n);
-
-    rows = (n + (uint32_t) ctx->n_plans - 1) / (uint32_t) ctx->n_plans;
-    for (i = 0; i < ctx->n_plans && done < n; i++)
-    {
-        HipStrip *s = &strips [n_strips];
-
-        s->ctx = ctx;
-        s->plan = (SmolHipPlan *) (i == 0 ? ctx->backend_state : ctx->more_plans [i - 1]);
-        s->first = first + done;
-        s->n = (n - done < rows) ? n - done : rows;
-        s->dest = (char *) dest + (size_t) ctx->rowstride_out * done;
-        s->rc = 0;
-        done += s->n;
-        if (pthread_create (&tids [n_strips], NULL, hip_strip_worker, s) != 0)
-        {
-            hip_strip_worker (s);          /* no thread available: run it here */
-            tids [n_strips] = (pthread_t) 0;
-            if (s->rc && !rc)
-                rc = s->rc;
-            continue;
-        }
-        n_strips++;
-    }
-    for (i = 0; i < n_strips; i++)
-    {
-        pthread_join (tids [i], NULL);
-        if (strips [i].rc && !rc)
-            rc = strips [i].rc;
-    }
-    return rc;
+    return smol_hip_scale_rows_host_multi ((SmolHipPlan *const *) ctx->plans, (uint32_t) ctx->n_plans,
+                                           ctx->pixels_in, ctx->rowstride_in,
+                                           dest, ctx->rowstride_out, first, n);
 }
 
 static const SmolBackend hip_backend =

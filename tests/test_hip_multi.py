@@ -1,0 +1,239 @@
+"""GPU parity tests for the multi-device and staging entry points of include/smol_hip.h
+(SURVEY 8e): row strips over several device entries with pageable and page-locked host
+memory, the chunked three-stream pipeline, GPU->GPU slabs, image-level sharding of a
+thumbnail batch, and the asynchronous device-pointer box path. One GPU is enough: a
+device may be listed several times. Everything is compared byte for byte with the oracle.
+"""
+import ctypes
+import random
+import threading
+
+import numpy as np
+import pytest
+
+import helpers as H
+import smolscale_amd as sm
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not H.have_gpu(), reason="needs a HIP device")]
+
+# (t_in, w_in, h_in, t_out, w_out, h_out, srgb): one job per vertical filter class, plus
+# the two-pass box filter (lane-owned intermediate image) and a 24-bit odd-stride source
+JOBS = [
+    (0, 2048, 1536, 0, 512, 384, 0),        # bilinear 1H/1H (k_pow2)
+    (4, 640, 360, 1, 1920, 1080, 0),        # magnification (k_up)
+    (8, 3001, 2001, 0, 1200, 2001, 0),      # vertical COPY, 24-bit in (k_tile)
+    (0, 2000, 1500, 2, 150, 90, 0),         # box/box, ratio >= 12 (k_boxh + k_boxv)
+    (5, 1000, 700, 6, 333, 250, 1),         # sRGB-linear minification
+    (0, 512, 1, 0, 300, 40, 0),             # vertical ONE: every strip needs input row 0 only
+]
+
+
+def _want(spec, src, stride_in=None):
+    t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+    return H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, stride_in=stride_in)
+
+
+@pytest.mark.parametrize("n_dev_entries", [1, 2, 3, 7])
+def test_rows_over_several_device_entries_pageable(n_dev_entries):
+    """smol_hip_scale_rows_host_multi(): pageable host memory -> strips run on the library's worker threads."""
+    for spec in JOBS:
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+        src = H.make_input(t_in, w_in, h_in, seed=3, pad=16)
+        want = _want(spec, src)
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        plans = [sm.HipPlan(job, 0) for _ in range(n_dev_entries)]
+        got = np.full(h_out * w_out * H.bpp(t_out), 0xA5, np.uint8)
+        sm.scale_rows_host_multi(plans, src, w_in * H.bpp(t_in), got, w_out * H.bpp(t_out), 0, h_out)
+        assert np.array_equal(got, want), (spec, n_dev_entries)
+        for p in plans:
+            p.destroy()
+
+
+def test_rows_over_several_device_entries_pinned_and_odd_strides():
+    """Page-locked host memory: one thread drives every strip asynchronously (more strips than a
+    device has lanes included); odd strides and a row range that is not the whole image."""
+    for spec in JOBS:
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+        stride_in = w_in * H.bpp(t_in) + 7
+        stride_out = w_out * H.bpp(t_out) + 5
+        raw = H.make_input(t_in, w_in, h_in, seed=4, stride=stride_in, pad=16)
+        pin_src = sm.PinnedArray(raw.size)
+        pin_src.array[:] = raw
+        pin_dst = sm.PinnedArray(h_out * stride_out)
+        want = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, srgb,
+                              stride_in=stride_in, stride_out=stride_out)
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        for n_entries in (2, 6):
+            plans = [sm.HipPlan(job, 0) for _ in range(n_entries)]
+            first = h_out // 5
+            n = h_out - first - (1 if h_out > 3 else 0)
+            pin_dst.array[:] = 0xA5
+            sm.scale_rows_host_multi(plans, pin_src.array, stride_in,
+                                     pin_dst.array[first * stride_out:], stride_out, first, n)
+            got = H.rows_view(pin_dst.array[first * stride_out:], n, w_out * H.bpp(t_out), stride_out)
+            ref = H.rows_view(want[first * stride_out:], n, w_out * H.bpp(t_out), stride_out)
+            assert np.array_equal(got, ref), (spec, n_entries)
+            # bytes between rows and outside the range stay untouched
+            assert np.all(pin_dst.array[:first * stride_out] == 0xA5)
+            gaps = np.lib.stride_tricks.as_strided(pin_dst.array[first * stride_out + w_out * H.bpp(t_out):],
+                                                   (n - 1, 5), (stride_out, 1))
+            assert np.all(gaps == 0xA5)
+            for p in plans:
+                p.destroy()
+        pin_src.free()
+        pin_dst.free()
+
+
+def test_chunk_pipeline_large_strip_max_width():
+    """A strip large enough for many pipeline chunks: the C4 geometry (65535-wide RGB8, odd stride,
+    vertical COPY) on a reduced height, against the oracle."""
+    w_in, h_in, w_out, h_out = 65535, 256, 8192, 256
+    src = H.make_input(8, w_in, h_in, seed=0, valid=False, pad=16)
+    want = H.oracle_scale(src, 8, w_in, h_in, 0, w_out, h_out)
+    job = H.plan_job(8, w_in, h_in, 0, w_out, h_out, 0)
+    plans = [sm.HipPlan(job, 0) for _ in range(2)]
+    got = np.zeros(h_out * w_out * 4, np.uint8)
+    sm.scale_rows_host_multi(plans, src, w_in * 3, got, w_out * 4, 0, h_out)
+    assert np.array_equal(got, want)
+    for p in plans:
+        p.destroy()
+
+
+def test_source_slab_from_a_gpu_peer_copy():
+    """smol_hip_scale_rows_peer(): the source image lives in GPU memory (any alignment); the slab
+    goes GPU -> GPU and the strip comes back to the host."""
+    for spec in JOBS:
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+        for skew in (0, 5):
+            stride_in = w_in * H.bpp(t_in) + (3 if skew else 0)
+            src = H.make_input(t_in, w_in, h_in, seed=6, stride=stride_in, pad=16)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, stride_in=stride_in)
+            dsrc = sm.DeviceBuffer(src.size + 64)
+            dsrc.upload(src, offset=skew)
+            plan = sm.HipPlan(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb), 0)
+            first, n = h_out // 3, h_out - h_out // 3
+            got = np.zeros(n * w_out * H.bpp(t_out), np.uint8)
+            plan.scale_rows_peer(0, dsrc.ptr + skew, stride_in, got, w_out * H.bpp(t_out), first, n)
+            assert np.array_equal(got, want[first * w_out * H.bpp(t_out):]), (spec, skew)
+            plan.destroy()
+            dsrc.free()
+
+
+def test_thumbnail_batch_sharded_by_image_over_device_entries():
+    """Config 5's multi-GPU form: image i -> devices[i % G]. 48 mixed-type 256^2 -> 64^2
+    thumbnails over 1, 2 and 3 entries of device 0, byte-equal to the oracle."""
+    rng = random.Random(77)
+    n_img = 48
+    specs, srcs, images, dbufs = [], [], [], []
+    for i in range(n_img):
+        t_in, t_out = rng.randrange(10), rng.randrange(10)
+        src = H.make_input(t_in, 256, 256, seed=100 + i, valid=True, pad=16)
+        dsrc = sm.DeviceBuffer(src.size)
+        dsrc.upload(src)
+        ddst = sm.DeviceBuffer(64 * 64 * H.bpp(t_out))
+        im = sm.SmolHipImage()
+        im.job = H.plan_job(t_in, 256, 256, t_out, 64, 64, 0)
+        im.src, im.dst = dsrc.ptr, ddst.ptr
+        im.rowstride_in, im.rowstride_out = 256 * H.bpp(t_in), 64 * H.bpp(t_out)
+        im.first_row, im.n_rows = 0, 64
+        specs.append((t_in, t_out))
+        srcs.append(src)
+        images.append(im)
+        dbufs.append((dsrc, ddst))
+    wants = [H.oracle_scale(src, t_in, 256, 256, t_out, 64, 64) for (t_in, t_out), src in zip(specs, srcs)]
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        for _, ddst in dbufs:
+            ddst.fill(0)
+        mb = sm.HipBatchMulti(images, devices)
+        mb.launch()
+        mb.sync()
+        for want, (_, ddst), spec in zip(wants, dbufs, specs):
+            assert np.array_equal(ddst.download(), want), (spec, devices)
+        ms = mb.time(1, 3)
+        assert len(ms) == len(devices) and all(m > 0 for m in ms)
+        mb.destroy()
+    for dsrc, ddst in dbufs:
+        dsrc.free()
+        ddst.free()
+
+
+def test_device_pointer_box_path_is_asynchronous_and_capturable():
+    """Two-pass box jobs through smol_hip_scale_rows_device(): the plan owns the intermediate image,
+    so launches neither allocate nor synchronise -- several strips queued back to back on one stream,
+    and the same launch recorded into a hipGraph (stream capture forbids allocation and syncs)."""
+    import torch
+    t_in, w_in, h_in, t_out, w_out, h_out = 0, 2000, 1500, 2, 150, 90
+    src = H.make_input(t_in, w_in, h_in, seed=8, pad=16)
+    want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out)
+    dev = torch.device("cuda", 0)
+    dsrc = torch.from_numpy(src).to(dev)
+    ddst = torch.zeros(h_out * w_out * 4, dtype=torch.uint8, device=dev)
+    plan = sm.HipPlan(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0), 0)
+    plan.prepare()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    # three strips queued without waiting in between
+    for first, n in ((0, 30), (30, 31), (61, 29)):
+        plan.scale_rows_device(dsrc.data_ptr(), w_in * 4, ddst.data_ptr() + first * w_out * 4, w_out * 4,
+                               first, n, stream=stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(ddst.cpu().numpy(), want)
+    # under capture
+    ddst.zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        plan.scale_rows_device(dsrc.data_ptr(), w_in * 4, ddst.data_ptr(), w_out * 4, 0, h_out,
+                               stream=torch.cuda.current_stream().cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(ddst.cpu().numpy(), want)
+    plan.destroy()
+
+
+def test_concurrent_callers_share_lanes_and_shutdown_releases_them():
+    """8 threads x multi-entry calls on one GPU (lanes are borrowed per call), then
+    smol_hip_shutdown() and a further call (lanes and workers come back on demand)."""
+    spec = JOBS[0]
+    t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+    src = H.make_input(t_in, w_in, h_in, seed=11, pad=16)
+    want = _want(spec, src)
+    job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+    plans = [sm.HipPlan(job, 0) for _ in range(3)]
+    outs = [np.zeros(h_out * w_out * 4, np.uint8) for _ in range(8)]
+    errs = []
+
+    def work(i):
+        try:
+            sm.scale_rows_host_multi(plans, src, w_in * 4, outs[i], w_out * 4, 0, h_out)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for o in outs:
+        assert np.array_equal(o, want)
+    sm.lib().smol_hip_shutdown()
+    again = np.zeros(h_out * w_out * 4, np.uint8)
+    sm.scale_rows_host_multi(plans, src, w_in * 4, again, w_out * 4, 0, h_out)
+    assert np.array_equal(again, want)
+    for p in plans:
+        p.destroy()
+
+
+def test_row_range_arguments_that_wrap_are_rejected():
+    job = H.plan_job(0, 64, 64, 0, 32, 32, 0)
+    plan = sm.HipPlan(job, 0)
+    buf = np.zeros(64 * 64 * 4 + 16, np.uint8)
+    out = np.zeros(32 * 32 * 4, np.uint8)
+    lib = sm.lib()
+    rc = lib.smol_hip_scale_rows_host(plan._h, buf.ctypes.data, 256, out.ctypes.data, 128, 0xFFFFFFFF, 2)
+    assert rc == -10001
+    rc = lib.smol_hip_scale_rows_host(plan._h, buf.ctypes.data, 256, out.ctypes.data, 128, 31, 2)
+    assert rc == -10001
+    a, b = ctypes.c_uint32(), ctypes.c_uint32()
+    rc = lib.smol_hip_input_row_range(ctypes.byref(job), 0xFFFFFFFF, 2, ctypes.byref(a), ctypes.byref(b))
+    assert rc == -10001
+    plan.destroy()

@@ -145,3 +145,14 @@ def test_input_row_range_is_tight_and_sufficient():
                 assert r0 == rows.min() and r1 == rows.max() + 1
             else:
                 assert r0 == int(tab[first, 0]) and r1 == int(tab[first + n, 0])
+
+
+def test_input_row_range_rejects_ranges_that_wrap_32_bits():
+    """first_row + n_rows must not be evaluated modulo 2^32 (a wrapped sum once passed the check)."""
+    import ctypes
+    job = H.plan_job(0, 64, 64, 0, 32, 32, 0)
+    a, b = ctypes.c_uint32(), ctypes.c_uint32()
+    fn = H.product().smol_hip_input_row_range
+    for first, n in ((0xFFFFFFFF, 2), (0xFFFFFFF0, 0x20), (32, 1), (31, 2), (0, 33), (0, 0)):
+        assert fn(ctypes.byref(job), first, n, ctypes.byref(a), ctypes.byref(b)) == -10001, (first, n)
+    assert fn(ctypes.byref(job), 31, 1, ctypes.byref(a), ctypes.byref(b)) == 0
