@@ -3,25 +3,35 @@
 (BASELINE.json configs[1]; the reference picks BILINEAR_1H on both axes for it).
 
 One "step" = one pass of the hot path over one batch of synthetic frames that are
-already resident in HBM: a single smol_hip_batch_launch() of 8*N distinct frames,
-where N = number of ranks and rank r produces output-row strip r of every frame
+already resident in HBM: a single smol_hip_batch_launch() of FRAMES_PER_GPU*N distinct
+frames, where N = number of ranks and rank r produces output-row strip r of every frame
 (row ranges shard with no exchange). Per-rank bytes are therefore the
-same at every N (weak scaling) and at N = 1 the batch is 8 whole frames = 570 MB
-of algorithmic traffic per launch -- more than the 256 MiB Infinity Cache, so the
-input really streams from HBM.
+same at every N (weak scaling) and at N = 1 the batch is FRAMES_PER_GPU whole frames --
+several times the 256 MiB Infinity Cache, so the input really streams from HBM.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0. PyTorch is plumbing only (device memory, barrier).
+Other BASELINE configs as the timed workload (same launch forms, same JSON contract):
+
+    --config c4      65535x4096 RGB8 -> 8192x4096 RGBA8, ONE image, output rows sharded over
+                     the ranks (strong scaling); adds an "e2e" object: the same strip from host
+                     memory through smol_hip_scale_rows_host (PCIe inclusive)
+    --config c5mix   10 000 thumbnails 256^2 -> 64^2, pixel types drawn from the 10x10 table,
+                     image i on rank i % N (strong scaling)
+
+Every rank compares a sample of what it produced with the oracle (the checker; never the
+thing measured) and the verdicts are reduced into the line. Prints ONE JSON line on rank 0.
+PyTorch is plumbing only (device memory, process group).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import statistics
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,21 +45,36 @@ import smolscale_amd as sm  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 W_IN = H_IN = 4096
 W_OUT = H_OUT = 1024
-FRAMES_PER_GPU = 8
+FRAMES_PER_GPU = 32              # 2 GiB of input per launch: 8x the Infinity Cache (profiles/r02_frames_sensitivity.txt)
 PIX_TYPE = sm.SMOL_PIXEL_RGBA8_PREMULTIPLIED
+
+
+def checker():
+    """tests/helpers.py: the oracle and (when prebuilt) the real reference -- test infrastructure,
+    used here only to check results and for the cpu_baseline leg."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    return H
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(seconds_budget=12.0):
     """The REAL reference (oracle/_ref, AVX2 build, all host cores, the reference's
     own strip-per-thread pattern test.c:838-883) on a bounded sample of the same
     workload; falls back to the oracle port when oracle/_ref is absent."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import helpers as H
-
+    H = checker()
     n_threads = os.cpu_count() or 1
     src = H.make_input(PIX_TYPE, W_IN, H_IN, seed=0, valid=True, pad=16)
     dst = np.zeros(W_OUT * H_OUT * 4 + 16, np.uint8)
-    info = {}
 
     def run_ref(kind, threads, budget):
         """Calibrate on a few frames, then time one pthread run sized to ~budget seconds."""
@@ -71,7 +96,7 @@ def cpu_baseline(seconds_budget=12.0):
         n, total = run_ref("avx2", n_threads, seconds_budget * 0.5)
         info = {
             "value": round(n * W_OUT * H_OUT / total / 1e6, 1), "unit": "Mpix/s",
-            "cores": n_threads, "kind": "reference",
+            "cores": n_threads, "kind": "reference", "cpu_model": cpu_model(),
             "sample": "%d frames 4096x4096->1024x1024 RGBA8 premul through the reference's AVX2 backend "
                       "(oracle/_ref, gcc -O2 -mavx2): %d pthreads, one output-row strip each via smol_scale_batch "
                       "(test.c:838-883 pattern), %.1f s wall" % (n, n_threads, total),
@@ -94,51 +119,219 @@ def cpu_baseline(seconds_budget=12.0):
         total = time.perf_counter() - t0
         info = {
             "value": round(n * W_OUT * H_OUT / total / 1e6, 1), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": "%d frames 4096x4096->1024x1024 through the scalar C oracle (oracle/smol_oracle.c), %.1f s" % (n, total),
         }
-    return info, src, want
+    return info, want
 
 
-# The other BASELINE.json configs, single GPU, device resident: not the metric (that is config 2
-# above) -- reported beside it so that the driver's own run records them. name: (type_in, w_in,
-# h_in, stride_in, type_out, w_out, h_out, images per launch)
+# --------------------------------------------------------------------------------------- #
+# workloads: each builds this rank's share as a device-resident batch                     #
+# --------------------------------------------------------------------------------------- #
+
+class Work:
+    """This rank's share of one step: a batch (None when the rank has nothing to do), the
+    algorithmic bytes one launch of it moves, the whole job's pixel counts, and a checker."""
+    batch = None
+    bytes_per_launch = 0
+    out_pix_per_step = 0        # whole job, all ranks
+    in_pix_per_step = 0
+    scaling = "weak"
+    workload = ""
+    config = None
+    keep = None                 # tensors the batch points into
+
+    def check(self):            # -> True / False / None (nothing to check on this rank)
+        return None
+
+
+def _image(job, src_ptr, dst_ptr, s_in, s_out, first, n):
+    im = sm.SmolHipImage()
+    im.job = job
+    im.src, im.dst = src_ptr, dst_ptr
+    im.rowstride_in, im.rowstride_out = s_in, s_out
+    im.first_row, im.n_rows = first, n
+    return im
+
+
+def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out, h_out, n_frames, seed0_frame):
+    """n_frames images, rank r producing output-row strip r of each from the slab of input rows
+    that strip needs (virtual row 0 addressing). Frame 0 is the seeded checker frame."""
+    H = checker()
+    w = Work()
+    bpp_in, bpp_out = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
+    s_out = w_out * bpp_out
+    job = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+    first_row, n_rows, r0, r1 = sm.shard(job, rank, world)
+    w.config = {"rows_per_rank": n_rows}
+    if n_rows == 0:
+        return w, job                   # more ranks than rows: this rank only joins the barriers
+    slab_rows = r1 - r0 + 1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x9E3779B9 + rank)
+    src = torch.randint(0, 256, (n_frames, slab_rows * s_in + 64), dtype=torch.uint8, device=dev, generator=gen)
+    dst = torch.zeros((n_frames, n_rows * s_out + 64), dtype=torch.uint8, device=dev)
+    frame0 = seed0_frame()
+    src[0, :slab_rows * s_in].copy_(torch.from_numpy(frame0[r0 * s_in:(r1 + 1) * s_in]))
+    images = [_image(job, src[f].data_ptr() - r0 * s_in, dst[f].data_ptr(), s_in, s_out, first_row, n_rows)
+              for f in range(n_frames)]
+    torch.cuda.synchronize()
+    w.batch = sm.HipBatch(images, device=local_rank)
+    w.keep = (src, dst)
+    # every source pixel of the strip read once, every destination pixel written once (SURVEY 8d):
+    # the strip's share of the input is n_rows/h_out of it (halo rows are re-reads, not counted)
+    w.bytes_per_launch = n_frames * (w_in * bpp_in * h_in * n_rows // h_out + n_rows * w_out * bpp_out)
+
+    def check(n_check=None):
+        n = n_rows if n_check is None else min(n_rows, n_check)
+        want = H.oracle_scale(frame0, t_in, w_in, h_in, t_out, w_out, h_out, stride_in=s_in, first=first_row, n=n)
+        got = dst[0, :n * s_out].cpu().numpy()
+        return bool(np.array_equal(got, want))
+    w.check = check
+    return w, job
+
+
+def work_c2(rank, world, dev, local_rank, frames_per_gpu):
+    H = checker()
+    n_frames = frames_per_gpu * world
+    w, _ = work_rows(rank, world, dev, local_rank, PIX_TYPE, W_IN, H_IN, W_IN * 4, PIX_TYPE, W_OUT, H_OUT, n_frames,
+                     lambda: H.make_input(PIX_TYPE, W_IN, H_IN, seed=0, valid=True, pad=16))
+    w.out_pix_per_step = n_frames * W_OUT * H_OUT
+    w.in_pix_per_step = n_frames * W_IN * H_IN
+    w.scaling = "weak"
+    w.workload = ("4096x4096->1024x1024 RGBA8 premultiplied (reference filter: BILINEAR_1H x BILINEAR_1H), "
+                  "batch of %d distinct frames per step resident in HBM, output-row strips sharded over %d rank(s)"
+                  % (n_frames, world))
+    w.config["frames_per_step"] = n_frames
+    return w
+
+
+C4 = (8, 65535, 4096, 65535 * 3, 0, 8192, 4096)
+
+
+def work_c4(rank, world, dev, local_rank):
+    H = checker()
+    t_in, w_in, h_in, s_in, t_out, w_out, h_out = C4
+    frame = {}
+
+    def seed0():
+        if "f" not in frame:
+            frame["f"] = H.make_input(t_in, w_in, h_in, seed=0, valid=False, stride=s_in, pad=16)
+        return frame["f"]
+    w, job = work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out, h_out, 1, seed0)
+    full = w.check
+    w.check = lambda: full(32) if w.batch is not None else None     # 32 rows of the strip against the oracle
+    w.out_pix_per_step = w_out * h_out
+    w.in_pix_per_step = w_in * h_in
+    w.scaling = "strong"
+    w.workload = ("65535x4096 RGB8 (rowstride 196605) -> 8192x4096 RGBA8 (BILINEAR_2H x COPY), one image resident in HBM, "
+                  "output rows sharded over %d rank(s)" % world)
+    w.host_frame = seed0
+    w.job = job
+    return w
+
+
+def work_c5mix(rank, world, dev, local_rank, n_total=10000):
+    """Thumbnails with (type_in, type_out) drawn uniformly from the 10x10 table; image i belongs
+    to rank i % world. All of a rank's thumbnails live in one arena per side."""
+    H = checker()
+    w = Work()
+    rng = np.random.default_rng(20260202)
+    types = rng.integers(0, 10, size=(n_total, 2))
+    mine = list(range(rank, n_total, world))
+    slot_in, slot_out = 256 * 256 * 4, 64 * 64 * 4
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED + rank)
+    src = torch.randint(0, 256, (len(mine), slot_in), dtype=torch.uint8, device=dev, generator=gen)
+    dst = torch.zeros((len(mine), slot_out), dtype=torch.uint8, device=dev)
+    jobs = {}
+    images, algo = [], 0
+    n_check = min(24, len(mine))
+    seeded = []
+    for k, i in enumerate(mine):
+        t_in, t_out = int(types[i, 0]), int(types[i, 1])
+        if (t_in, t_out) not in jobs:
+            jobs[(t_in, t_out)] = sm.plan_job(t_in, 256, 256, t_out, 64, 64, 0)
+        bi, bo = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
+        if k < n_check:
+            f = H.make_input(t_in, 256, 256, seed=i, valid=True, pad=0)
+            src[k, :f.size].copy_(torch.from_numpy(f))
+            seeded.append((k, t_in, t_out, f))
+        images.append(_image(jobs[(t_in, t_out)], src[k].data_ptr(), dst[k].data_ptr(), 256 * bi, 64 * bo, 0, 64))
+        algo += 256 * 256 * bi + 64 * 64 * bo
+    torch.cuda.synchronize()
+    if images:
+        w.batch = sm.HipBatch(images, device=local_rank)
+    w.keep = (src, dst)
+    w.bytes_per_launch = algo
+    w.out_pix_per_step = n_total * 64 * 64
+    w.in_pix_per_step = n_total * 256 * 256
+    w.scaling = "strong"
+    w.workload = ("%d thumbnails 256x256->64x64, (type_in, type_out) drawn uniformly from the 10x10 pixel-type table, "
+                  "image i on rank i %% %d, one descriptor-table launch per kernel entry point" % (n_total, world))
+    w.config = {"images_per_rank": len(mine)}
+
+    def check():
+        ok = True
+        for k, t_in, t_out, f in seeded:
+            want = H.oracle_scale(f, t_in, 256, 256, t_out, 64, 64)
+            ok = ok and bool(np.array_equal(dst[k, :want.size].cpu().numpy(), want))
+        return ok if seeded else None
+    w.check = check
+    return w
+
+
+# The other BASELINE.json configs + the BOX row, single GPU, device resident: not the metric (that is
+# config 2 above) -- reported beside it so that the driver's own run records all six SURVEY 8(d) rows.
+# name: (type_in, w_in, h_in, stride_in, type_out, w_out, h_out, images per launch); type -1 = mixed
 OTHER_CONFIGS = {
     "C1 640x480->320x240 RGBA8 premul x384": (0, 640, 480, None, 0, 320, 240, 384),
     "C3 1920x1080 RGBA unassociated->7680x4320 RGBA premul x4": (4, 1920, 1080, None, 0, 7680, 4320, 4),
     "C4 65535x4096 RGB8 (stride 196605)->8192x4096 RGBA8 x1": (8, 65535, 4096, 65535 * 3, 0, 8192, 4096, 1),
     "C5 256x256->64x64 RGBA8 premul x10000": (0, 256, 256, None, 0, 64, 64, 10000),
+    "C5mix 256x256->64x64 x10000, pixel types drawn from the 10x10 table": (-1, 256, 256, None, -1, 64, 64, 10000),
+    "BOX 4096x4096->448x448 RGBA8 premul x8": (0, 4096, 4096, None, 0, 448, 448, 8),
 }
 
 
+def stats_us(ms_each):
+    us = sorted(m * 1e3 for m in ms_each)
+    return {"min": round(us[0], 2), "median": round(statistics.median(us), 2), "mean": round(sum(us) / len(us), 2)}
+
+
 def other_configs(dev, local_rank):
-    """Time the other BASELINE configs with synthetic device-resident data (hipEvents, after
+    """Time the other configs with synthetic device-resident data (hipEvents on the launch stream, after
     0.2 s of warm-up load each). Any failure is reported in place of the numbers."""
     out = {}
-    for name, (t_in, w_in, h_in, stride_in, t_out, w_out, h_out, n_img) in OTHER_CONFIGS.items():
+    for name, (t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_img) in OTHER_CONFIGS.items():
         try:
-            bpp_in, bpp_out = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
-            s_in, s_out = stride_in or w_in * bpp_in, w_out * bpp_out
-            src = torch.randint(0, 256, (n_img, h_in * s_in + 64), dtype=torch.uint8, device=dev)
-            dst = torch.zeros((n_img, h_out * s_out + 64), dtype=torch.uint8, device=dev)
-            job = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
-            images = []
+            rng = np.random.default_rng(20260202)
+            slot_in = h_in * (stride_in or w_in * 4) + 64
+            slot_out = h_out * w_out * 4 + 64
+            src = torch.randint(0, 256, (n_img, slot_in), dtype=torch.uint8, device=dev)
+            dst = torch.zeros((n_img, slot_out), dtype=torch.uint8, device=dev)
+            jobs, images, algo = {}, [], 0
             for i in range(n_img):
-                im = sm.SmolHipImage()
-                im.job = job
-                im.src, im.dst = src[i].data_ptr(), dst[i].data_ptr()
-                im.rowstride_in, im.rowstride_out = s_in, s_out
-                im.first_row, im.n_rows = 0, h_out
-                images.append(im)
+                t_in = int(rng.integers(0, 10)) if t_in0 < 0 else t_in0
+                t_out = int(rng.integers(0, 10)) if t_out0 < 0 else t_out0
+                if (t_in, t_out) not in jobs:
+                    jobs[(t_in, t_out)] = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+                bi, bo = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
+                images.append(_image(jobs[(t_in, t_out)], src[i].data_ptr(), dst[i].data_ptr(),
+                                     stride_in or w_in * bi, w_out * bo, 0, h_out))
+                algo += w_in * h_in * bi + w_out * h_out * bo
             torch.cuda.synchronize()
             b = sm.HipBatch(images, device=local_rank)
             n_launches, kname = b.info()
             probe = b.time(2, 5) / 5
-            ms = b.time(int(200.0 / max(probe, 1e-3)), 20) / 20
-            algo = n_img * (w_in * h_in * bpp_in + w_out * h_out * bpp_out)
-            gbs = algo / (ms * 1e-3) / 1e9
-            out[name] = {"kernel": kname, "launches": n_launches, "step_us": round(ms * 1e3, 1),
+            each = b.time_each(int(200.0 / max(probe, 1e-3)), 20)
+            st = stats_us(each)
+            gbs = algo / (st["mean"] * 1e-6) / 1e9
+            out[name] = {"kernel": kname, "launches": n_launches, "step_us": st["mean"],
+                         "step_us_min": st["min"], "step_us_median": st["median"],
                          "GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
-                         "Mpix_out_per_s": round(n_img * w_out * h_out / (ms * 1e-3) / 1e6, 1)}
+                         "frac_of_peak_best": round(algo / (st["min"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "Mpix_out_per_s": round(n_img * w_out * h_out / (st["mean"] * 1e-6) / 1e6, 1)}
             b.destroy()
             del src, dst
         except Exception as e:                      # noqa: BLE001 -- a side table must not break the bench line
@@ -147,17 +340,91 @@ def other_configs(dev, local_rank):
     return out
 
 
+def kernel_source_digest():
+    """sha256 over the sources of the headline kernel: a counter capture is only quoted for the code it was taken on."""
+    h = hashlib.sha256()
+    for f in ("smol_kernels.hip.h", "smol_k_stream.hip", "smol_jobdev.h"):
+        with open(os.path.join(ROOT, "smolscale_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(bytes_per_launch):
+    """HBM bytes per launch from the last rocprofv3 --pmc capture (profiles/traffic_latest.json), quoted only when
+    it was taken on the same kernel sources and the same bytes per launch; never measured by this run."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        t = json.load(open(tpath))
+    except Exception:                               # noqa: BLE001
+        return None, "no capture on file"
+    if t.get("kernel_source_digest") != kernel_source_digest():
+        return None, "capture on file (%s) predates the current kernel sources" % t.get("source", "?")
+    if t.get("algorithmic_bytes_per_launch") != bytes_per_launch:
+        return None, "capture on file (%s) is for a different launch size" % t.get("source", "?")
+    return t.get("hbm_bytes_per_launch"), "static: %s, commit %s (rocprofv3 --pmc, not this run)" % (
+        t.get("source", "?"), t.get("commit", "?"))
+
+
+def e2e_c4(w, local_rank, reps=3):
+    """The strip of --config c4 from HOST memory through smol_hip_scale_rows_host(): PCIe inclusive,
+    page-locked and pageable, checked against the device-resident result."""
+    t_in, w_in, h_in, s_in, t_out, w_out, h_out = C4
+    rank_first = w.batch_first
+    n_rows = w.config["rows_per_rank"]
+    frame = w.host_frame()
+    plan = sm.HipPlan(w.job, local_rank)
+    out = {}
+    ref = w.keep[1][0, :n_rows * w_out * 4].cpu().numpy()
+    bytes_moved = n_rows * (w_in * 3 + w_out * 4)
+    for mode in ("pinned", "pinned_hostalloc", "pageable"):
+        if mode == "pinned":                        # caller's memory page-locked in place (hipHostRegister)
+            hsrc = sm.PinnedArray(frame.size)
+            hsrc.array[:] = frame
+            hdst = sm.PinnedArray(n_rows * w_out * 4)
+            a_src, a_dst = hsrc.array, hdst.array
+        elif mode == "pinned_hostalloc":            # memory that was allocated page-locked (hipHostMalloc)
+            tsrc = torch.empty(frame.size, dtype=torch.uint8, pin_memory=True)
+            tdst = torch.empty(n_rows * w_out * 4, dtype=torch.uint8, pin_memory=True)
+            a_src, a_dst = tsrc.numpy(), tdst.numpy()
+            a_src[:] = frame
+        else:
+            a_src, a_dst = frame, np.zeros(n_rows * w_out * 4, np.uint8)
+        plan.scale_rows_host(a_src, s_in, a_dst, w_out * 4, rank_first, n_rows)        # warm-up: lanes, slabs
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            plan.scale_rows_host(a_src, s_in, a_dst, w_out * 4, rank_first, n_rows)
+            ts.append(time.perf_counter() - t0)
+        ok = bool(np.array_equal(a_dst, ref))
+        best = min(ts)
+        out[mode] = {"ms": round(best * 1e3, 3), "GBps_over_pcie": round(bytes_moved / best / 1e9, 1),
+                     "Mpix_out_per_s": round(n_rows * w_out / best / 1e6, 1), "equal_to_device_resident": ok}
+        if mode == "pinned":
+            hsrc.free()
+            hdst.free()
+    plan.destroy()
+    out["bytes_over_pcie"] = bytes_moved
+    out["what"] = ("this rank's strip (%d rows) from host memory: chunked H2D / kernels / D2H on three side streams "
+                   "(smol_hip_scale_rows_host), best of %d" % (n_rows, reps))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5mix"],
+                    help="workload timed as the step (default: the headline, BASELINE configs[1])")
+    ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU, help="c2: distinct frames per rank and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the side table of the other BASELINE configs (N=1 only, a few seconds)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the timing barrier (nccl = RCCL)")
+    ap.add_argument("--backend", default="auto",
+                    help="process group for the timing barrier: auto = RCCL ('nccl') when it comes up on every rank, "
+                         "else gloo; or force 'nccl' / 'gloo'")
     ap.add_argument("--share-devices", action="store_true",
-                    help="testing aid: rank r uses GPU r %% device_count (several ranks on one GPU; needs --backend gloo)")
+                    help="testing aid: rank r uses GPU r %% device_count (several ranks on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,93 +439,96 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    # ---- process group: control plane only (barrier + reductions of timings/verdicts) -------
     dist = None
+    fast = None                 # RCCL group when it works everywhere, else None (gloo default group)
+    backend_used = None
     if world > 1:
         import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        dist.init_process_group("gloo")
+        backend_used = "gloo"
+        if args.backend in ("auto", "nccl"):
+            ok = 1
+            try:
+                fast = dist.new_group(backend="nccl")
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=fast)
+                torch.cuda.synchronize()
+                ok = int(float(probe[0]) == world)
+            except Exception:                       # noqa: BLE001 -- e.g. two ranks sharing one GPU
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                backend_used = "nccl"
+            else:
+                fast = None
+                if args.backend == "nccl":
+                    raise SystemExit("bench.py: --backend nccl requested but RCCL did not come up on every rank")
 
     def barrier():
-        if dist is not None:
+        if dist is None:
+            return
+        if fast is not None:
+            dist.barrier(group=fast, device_ids=[local_rank])
+        else:
             dist.barrier()
 
-    # ---- the job and this rank's shard ------------------------------------------------
-    job = sm.plan_job(PIX_TYPE, W_IN, H_IN, PIX_TYPE, W_OUT, H_OUT, 0)
-    first_row, n_rows, r0, r1 = sm.shard(job, rank, world)
-    n_frames = FRAMES_PER_GPU * world
-    in_stride, out_stride = W_IN * 4, W_OUT * 4
-    slab_rows = r1 - r0 + 1
+    # ---- this rank's share of the step ---------------------------------------------------
+    if args.config == "c2":
+        w = work_c2(rank, world, dev, local_rank, args.frames_per_gpu)
+    elif args.config == "c4":
+        w = work_c4(rank, world, dev, local_rank)
+    else:
+        w = work_c5mix(rank, world, dev, local_rank)
+    n_launches, kernel_name = w.batch.info() if w.batch is not None else (0, "")
 
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x9E3779B9 + rank)
-    src = torch.randint(0, 256, (n_frames, slab_rows, in_stride), dtype=torch.uint8, device=dev, generator=gen)
-    dst = torch.zeros((n_frames, n_rows, out_stride), dtype=torch.uint8, device=dev)
-
-    # rank 0 at N=1 replaces frame 0 by the CPU baseline's seeded frame so the GPU
-    # result can be checked against the reference's bytes in the same run
-    cpu = None
-    want = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, frame0, want = cpu_baseline()
-        src[0].copy_(torch.from_numpy(frame0[:H_IN * in_stride].reshape(H_IN, in_stride)))
-
-    images = []
-    for f in range(n_frames):
-        im = sm.SmolHipImage()
-        im.job = job
-        # address of (virtual) input row 0: the slab starts at row r0
-        im.src = src[f].data_ptr() - r0 * in_stride
-        im.dst = dst[f].data_ptr()
-        im.rowstride_in, im.rowstride_out = in_stride, out_stride
-        im.first_row, im.n_rows = first_row, n_rows
-        images.append(im)
-    torch.cuda.synchronize()
-    batch = sm.HipBatch(images, device=local_rank)
-    n_launches, kernel_name = batch.info()
+    def run(n):                 # n launches bracketed by hipEvents on their own stream -> ms
+        return w.batch.time(0, n) if (w.batch is not None and n) else 0.0
 
     # ---- warm-up, then exactly K timed steps --------------------------------------------
-    if args.warmup:
-        batch.time(0, args.warmup)
+    run(args.warmup)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = batch.time(0, args.steps)          # K launches bracketed by hipEvents on their stream
+    kernel_ms = run(args.steps)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-
     elapsed = t1 - t0
+
+    verdict = w.check()
+    cpu = ref_want = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "c2":
+        cpu, ref_want = cpu_baseline()
+    each = w.batch.time_each(2, 20) if w.batch is not None else []
+
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
-
-    verified = None
-    if want is not None:
-        got = dst[0].cpu().numpy().reshape(-1)
-        verified = bool(np.array_equal(got, want))
+        v = torch.tensor([1 if verdict in (True, None) else 0, 1 if verdict is not None else 0], dtype=torch.int32)
+        vmin = v.clone()
+        dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+        vsum = v.clone()
+        dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+        all_ok, n_checked = bool(int(vmin[0])), int(vsum[1])
+    else:
+        all_ok, n_checked = verdict in (True, None), int(verdict is not None)
 
     if rank == 0:
-        out_pix_per_step = n_frames * W_OUT * H_OUT                       # all ranks together
-        in_pix_per_step = n_frames * W_IN * H_IN
-        value = out_pix_per_step * args.steps / elapsed / 1e6
-        # algorithmic bytes ONE launch (this rank) moves: every source pixel of the
-        # strip read once, every destination pixel written once
-        src_rows_algo = n_rows * (H_IN // H_OUT)
-        bytes_per_launch = n_frames * (src_rows_algo * W_IN * 4 + n_rows * W_OUT * 4)
+        value = w.out_pix_per_step * args.steps / elapsed / 1e6
         launch_ms = kernel_ms / args.steps / max(1, n_launches)
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        achieved = w.bytes_per_launch / max(1, n_launches) / (launch_ms * 1e-3) / 1e9 if launch_ms else 0.0
+        traffic, traffic_source = recorded_traffic(w.bytes_per_launch) if args.config == "c2" else (None, "not captured for this config")
+        metric = {"c2": "Mpixels/sec 4K->1K RGBA8 downscale (output pixels)",
+                  "c4": "Mpixels/sec 65535x4096 RGB8 -> 8192x4096 RGBA8 (output pixels)",
+                  "c5mix": "Mpixels/sec 10000 mixed-type 256->64 thumbnails (output pixels)"}[args.config]
+        config = {"workload": w.workload, "launches_per_step": n_launches}
+        config.update(w.config or {})
         line = {
-            "metric": "Mpixels/sec 4K->1K RGBA8 downscale (output pixels)",
+            "metric": metric,
             "value": round(value, 1),
             "unit": "Mpix/s",
             "n_gpus": world,
@@ -266,19 +536,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": w.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {
-                "workload": "4096x4096->1024x1024 RGBA8 premultiplied (reference filter: BILINEAR_1H x BILINEAR_1H), "
-                            "batch of %d distinct frames per step resident in HBM, output-row strips sharded over %d rank(s)"
-                            % (n_frames, world),
-                "frames_per_step": n_frames,
-                "rows_per_rank": n_rows,
-                "launches_per_step": n_launches,
-            },
-            "ref_style_pps_Mpix_s": round((out_pix_per_step + in_pix_per_step) * args.steps / elapsed / 1e6, 1),
+            "config": config,
+            "ref_style_pps_Mpix_s": round((w.out_pix_per_step + w.in_pix_per_step) * args.steps / elapsed / 1e6, 1),
             "roofline": {
                 "bound": "hbm",
                 "kernel": kernel_name,
@@ -287,20 +550,36 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "bytes_per_launch": bytes_per_launch,
+                "traffic_source": traffic_source,
+                "bytes_per_launch": w.bytes_per_launch // max(1, n_launches),
                 "launch_us": round(launch_ms * 1e3, 3),
+                "step_us_each": stats_us(each) if each else None,
             },
+            "verified_vs_oracle": {"all_ranks_ok": all_ok, "ranks_that_checked": n_checked},
         }
-        if world == 1 and not args.no_other_configs:
+        if args.config == "c5mix":
+            line["images_per_s"] = round(10000 * args.steps / elapsed, 1)
+        if backend_used:
+            line["barrier_backend"] = backend_used
+        if args.config == "c4" and w.batch is not None:
+            try:
+                w.batch_first = sm.strip_rows(rank, world, C4[6])[0]
+                line["e2e"] = e2e_c4(w, local_rank)
+            except Exception as e:                  # noqa: BLE001
+                line["e2e"] = {"error": repr(e)}
+        if world == 1 and not args.no_other_configs and args.config == "c2":
             line["other_baseline_configs"] = other_configs(dev, local_rank)
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        if verified is not None:
-            line["bit_exact_vs_reference"] = verified
+        if ref_want is not None:
+            got = w.keep[1][0, :W_OUT * H_OUT * 4].cpu().numpy()
+            line["bit_exact_vs_reference"] = bool(np.array_equal(got, ref_want))
         print(json.dumps(line), flush=True)
 
-    batch.destroy()
+    if w.batch is not None:
+        w.batch.destroy()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -317,14 +317,20 @@ strip_issue_locked (Strip &st, Lane &ln)
     const size_t out_row_bytes = (size_t) job.width_out * to.bpp;
     const size_t n_in_rows = (size_t) r1 - r0 + 1;
     const bool peer = st.src_device >= 0;
-    /* Host rows are re-pitched to 16-byte multiples on the device whatever the host strides
-     * are, so kernels see aligned rows even for odd host layouts (the reference copies odd
-     * rows to an aligned temporary: smolscale-generic.c:1623-1634). A slab that comes from
-     * another GPU keeps the caller's stride and its alignment within 16 bytes (one
-     * contiguous peer copy). */
-    const size_t src_pitch = peer ? st.rowstride_in : align_up (in_row_bytes, 16);
-    const size_t dst_pitch = align_up (out_row_bytes, 16);
-    const size_t src_skew = peer ? ((uintptr_t) (st.src + (size_t) r0 * st.rowstride_in) & 15u) : 0;
+    /* How rows lie in the device slabs. Rows that are (nearly) back to back on the host travel as
+     * ONE linear copy per chunk and keep the caller's stride and 16-byte phase on the device -- a
+     * linear DMA runs at the full link rate, a 2-D copy of odd-width rows at a third of it
+     * (profiles/r02a: 65535-pixel RGB rows, 17 vs 50+ GB/s); the kernels take any alignment. Rows
+     * with real gaps between them are copied row-wise and re-pitched to 16-byte multiples (the
+     * reference copies odd rows to an aligned temporary: smolscale-generic.c:1623-1634). A slab
+     * from another GPU is always one linear peer copy. */
+    const bool lin_in = peer || ((size_t) st.rowstride_in >= in_row_bytes
+                                 && ((size_t) st.rowstride_in - in_row_bytes) * 8 <= in_row_bytes);
+    const bool lin_out = (size_t) st.rowstride_out == out_row_bytes;
+    const size_t src_pitch = lin_in ? st.rowstride_in : align_up (in_row_bytes, 16);
+    const size_t dst_pitch = lin_out ? out_row_bytes : align_up (out_row_bytes, 16);
+    const size_t src_skew = lin_in ? ((uintptr_t) (st.src + (size_t) r0 * st.rowstride_in) & 15u) : 0;
+    const size_t dst_skew = lin_out ? ((uintptr_t) st.dest & 15u) : 0;
 
     if (src_pitch > 0xffffffffu || dst_pitch > 0xffffffffu)
         return SMOL_HIP_E_INVALID;
@@ -340,7 +346,7 @@ strip_issue_locked (Strip &st, Lane &ln)
         if (box2_setup (probe))
             tmp_need = box2_tmp_bytes (probe) + 64;
     }
-    rc = lane_prepare (ln, n_in_rows * src_pitch + 64 + 16, (size_t) st.n * dst_pitch + 64, tmp_need);
+    rc = lane_prepare (ln, n_in_rows * src_pitch + 64 + 16, (size_t) st.n * dst_pitch + 64 + 16, tmp_need);
     if (rc)
         return rc;
 
@@ -372,11 +378,12 @@ strip_issue_locked (Strip &st, Lane &ln)
             uint8_t *d = slab + (size_t) (from - r0) * src_pitch;
             const uint8_t *s = st.src + (size_t) from * st.rowstride_in;
 
-            if (peer)
+            if (lin_in)
             {
                 /* whole rows incl. the gaps between them, except after the very last one */
                 const size_t bytes = (size_t) (cnt - 1) * st.rowstride_in + in_row_bytes;
-                e = hipMemcpyPeerAsync (d, plan->device, s, st.src_device, bytes, ln.s_in);
+                e = peer ? hipMemcpyPeerAsync (d, plan->device, s, st.src_device, bytes, ln.s_in)
+                         : hipMemcpyAsync (d, s, bytes, hipMemcpyHostToDevice, ln.s_in);
             }
             else
                 e = hipMemcpy2DAsync (d, src_pitch, s, st.rowstride_in, in_row_bytes, cnt,
@@ -388,16 +395,18 @@ strip_issue_locked (Strip &st, Lane &ln)
         if ((e = hipEventRecord (ln.ev_in [c], ln.s_in)) != hipSuccess) break;
         if ((e = hipStreamWaitEvent (ln.s_k, ln.ev_in [c], 0)) != hipSuccess) break;
 
+        uint8_t *dchunk = static_cast<uint8_t *> (ln.dst_buf) + dst_skew + (size_t) done * dst_pitch;
         JobDev jd;
-        fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch,
-                     static_cast<uint8_t *> (ln.dst_buf) + (size_t) done * dst_pitch, (uint32_t) dst_pitch,
-                     st.first + done, rows);
+        fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch, dchunk, (uint32_t) dst_pitch, st.first + done, rows);
         if ((e = launch_single (jd, ln.s_k, ln.tmp_buf)) != hipSuccess) break;
         if ((e = hipEventRecord (ln.ev_k [c], ln.s_k)) != hipSuccess) break;
         if ((e = hipStreamWaitEvent (ln.s_out, ln.ev_k [c], 0)) != hipSuccess) break;
-        e = hipMemcpy2DAsync (st.dest + (size_t) done * st.rowstride_out, st.rowstride_out,
-                              static_cast<uint8_t *> (ln.dst_buf) + (size_t) done * dst_pitch, dst_pitch,
-                              out_row_bytes, rows, hipMemcpyDeviceToHost, ln.s_out);
+        if (lin_out)
+            e = hipMemcpyAsync (st.dest + (size_t) done * st.rowstride_out, dchunk, (size_t) rows * out_row_bytes,
+                                hipMemcpyDeviceToHost, ln.s_out);
+        else
+            e = hipMemcpy2DAsync (st.dest + (size_t) done * st.rowstride_out, st.rowstride_out, dchunk, dst_pitch,
+                                  out_row_bytes, rows, hipMemcpyDeviceToHost, ln.s_out);
         done += rows;
     }
 

@@ -3,6 +3,10 @@ import subprocess
 import sys
 
 import pytest
+# torch first: it carries its own copy of the HIP runtime, and a process must settle on ONE copy.
+# Loaded first, torch's is the one the product library then binds to (the order bench.py uses);
+# the other way round torch finds no GPU.
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

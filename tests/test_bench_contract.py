@@ -35,15 +35,55 @@ def test_single_gpu_line():
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
     assert line["bit_exact_vs_reference"] is True
+    assert line["verified_vs_oracle"] == {"all_ranks_ok": True, "ranks_that_checked": 1}
+    assert set(line["roofline"]["step_us_each"]) == {"min", "median", "mean"}
+    assert "traffic_source" in line["roofline"]
+    rows = line["other_baseline_configs"]
+    assert len(rows) == 6 and all("error" not in r for r in rows.values()), rows
+    assert any(k.startswith("BOX") for k in rows) and any(k.startswith("C5mix") for k in rows)
+
+
+def _torchrun(n, port, *extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(H.ROOT, "bench.py"),
+           "--gpus", str(n), "--steps", "5", "--warmup", "2", "--share-devices"] + list(extra)
+    out = subprocess.check_output(cmd, text=True, stderr=subprocess.DEVNULL, timeout=900, env=env)
+    return _last_json_line(out)
 
 
 def test_two_ranks_share_the_gpu_and_report_the_aggregate():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(H.ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--share-devices"]
-    out = subprocess.check_output(cmd, text=True, stderr=subprocess.DEVNULL, timeout=900, env=env)
-    line = _last_json_line(out)
+    """Default --backend auto: RCCL cannot come up with two ranks on one GPU, so the run must agree
+    on gloo by itself; every rank checks its own strip against the oracle."""
+    import bench
+    line = _torchrun(2, 29517)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["frames_per_step"] == 16 and line["config"]["rows_per_rank"] == 512
+    assert line["config"]["frames_per_step"] == 2 * bench.FRAMES_PER_GPU and line["config"]["rows_per_rank"] == 512
     assert line["value"] > 0
+    assert line["barrier_backend"] in ("gloo", "nccl")
+    assert line["verified_vs_oracle"] == {"all_ranks_ok": True, "ranks_that_checked": 2}
+
+
+def test_three_ranks_uneven_strips():
+    line = _torchrun(3, 29519, "--backend", "gloo", "--frames-per-gpu", "4")
+    assert line["n_gpus"] == 3 and line["config"]["rows_per_rank"] == 342
+    assert line["verified_vs_oracle"] == {"all_ranks_ok": True, "ranks_that_checked": 3}
+
+
+def test_config4_rows_sharded_with_end_to_end_numbers():
+    line = _torchrun(2, 29521, "--backend", "gloo", "--config", "c4")
+    assert line["scaling"] == "strong" and line["config"]["rows_per_rank"] == 2048
+    assert line["verified_vs_oracle"] == {"all_ranks_ok": True, "ranks_that_checked": 2}
+    e = line["e2e"]
+    for mode in ("pinned", "pinned_hostalloc", "pageable"):
+        assert e[mode]["equal_to_device_resident"] is True and e[mode]["ms"] > 0
+    assert e["bytes_over_pcie"] == 2048 * (65535 * 3 + 8192 * 4)
+    # PCIe-inclusive time can only be longer than the kernel-only step
+    assert e["pinned"]["ms"] > line["ms_per_step"]
+
+
+def test_config5_mixed_thumbnails_sharded_by_image():
+    line = _torchrun(2, 29523, "--backend", "gloo", "--config", "c5mix")
+    assert line["scaling"] == "strong" and line["config"]["images_per_rank"] == 5000
+    assert line["verified_vs_oracle"] == {"all_ranks_ok": True, "ranks_that_checked": 2}
+    assert line["images_per_s"] > 0

@@ -23,6 +23,7 @@ JOBS = [
     (4, 97, 61, 1, 150, 83, 0),           # magnify, unassoc -> premul
     (8, 300, 200, 2, 33, 17, 0),          # box x 2H... (300/33 > 8 -> box), RGB -> ARGB
     (0, 90, 47, 0, 90, 5, 1),             # copy x box, sRGB (wide)
+    (8, 4095, 40, 0, 512, 40, 0),         # BASELINE config 4's classes (24-bit in, BILINEAR_2H x COPY): disjoint slabs
 ]
 
 
@@ -84,6 +85,69 @@ def test_row_strips_gathered_over_gloo_equal_one_shot(world):
         p.join(120)
         assert p.exitcode == 0
     assert results.get() is True
+
+
+def _thumb_specs(n_total):
+    rng = np.random.default_rng(5)
+    return [(int(a), int(b)) for a, b in rng.integers(0, 10, size=(n_total, 2))]
+
+
+def _worker_images(rank, world, port, results):
+    """BASELINE config 5's multi-GPU form: image i belongs to rank i % world, no image is
+    split, nothing is exchanged; outputs are gathered only to be checked."""
+    import ctypes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total, w_in, w_out = 14, 64, 16
+    specs = _thumb_specs(n_total)
+    slot = w_out * w_out * 4
+    per_rank = (n_total + world - 1) // world
+    mine = np.zeros(per_rank * slot, np.uint8)
+    for k, i in enumerate(range(rank, n_total, world)):
+        t_in, t_out = specs[i]
+        src = H.make_input(t_in, w_in, w_in, seed=i, valid=True, pad=16)
+        job = H.plan_job(t_in, w_in, w_in, t_out, w_out, w_out, 0)
+        out = np.zeros(slot + 16, np.uint8)
+        kc = ctypes.c_int(0)
+        rc = H.emu().emu_scale_rows(ctypes.byref(job), src.ctypes.data, w_in * H.bpp(t_in), out.ctypes.data,
+                                    w_out * H.bpp(t_out), 0, w_out, 0, ctypes.byref(kc))
+        assert rc == 0
+        mine[k * slot:(k + 1) * slot] = out[:slot]
+    gathered = [torch.zeros(per_rank * slot, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(mine))
+    if rank == 0:
+        ok = True
+        for i, (t_in, t_out) in enumerate(specs):
+            src = H.make_input(t_in, w_in, w_in, seed=i, valid=True, pad=16)
+            want = H.oracle_scale(src, t_in, w_in, w_in, t_out, w_out, w_out)
+            got = gathered[i % world].numpy()[(i // world) * slot:(i // world) * slot + want.size]
+            ok = ok and bool(np.array_equal(got, want))
+        results.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_thumbnails_sharded_by_image_over_gloo(world):
+    H.emu()
+    ctx = mp.get_context("spawn")
+    results = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_images, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert results.get() is True
+
+
+def test_more_ranks_than_rows_gives_empty_strips():
+    job = H.plan_job(0, 64, 8, 0, 32, 3, 0)
+    got = [sm.shard(job, r, 8) for r in range(8)]
+    assert sum(n for _, n, _, _ in got) == 3
+    assert all(n == 0 and (r0, r1) == (0, -1) for _, n, r0, r1 in got[3:])
 
 
 def test_strip_rule_and_slabs_cover_everything():
