@@ -75,6 +75,11 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         L::box2 (jobs_dev, rep, n_jobs, jobs_dev ? max_w_out : box2_h_tiles (rep),
                  jobs_dev ? max_rows : box2_v_tiles (rep), jobs_dev ? max_lds : box2_h_lds_bytes (rep), s);
     }
+    else if (k == KC_HSPAN)
+    {
+        /* max_lds carries the group's largest block count; groups share pixel size and halvings */
+        L::hspan (jobs_dev, rep, dim3 (max_lds ? max_lds : hspan_blocks (rep), n_jobs), hspan_lds_bytes (rep), s);
+    }
     else if (k == KC_TILE || k == KC_WTILE)
     {
         /* groups share tile_rows and LDS size */
@@ -1008,6 +1013,8 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_BOX2 && jobs [j].wide != g.rep.wide)
                 continue;
+            if (g.k == KC_HSPAN && (jobs [j].bpp_in != g.rep.bpp_in || jobs [j].halv_h != g.rep.halv_h))
+                continue;
             if (g.count == 65535)
                 break;
             taken [j] = true;
@@ -1036,6 +1043,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if (g.k == KC_POW2X && pow2x_blocks (jobs [j]) > g.max_lds) g.max_lds = pow2x_blocks (jobs [j]);
             if (g.k == KC_UP && up_blocks (jobs [j]) > g.max_lds) g.max_lds = up_blocks (jobs [j]);
             if (g.k == KC_DOWN && down_blocks (jobs [j]) > g.max_lds) g.max_lds = down_blocks (jobs [j]);
+            if (g.k == KC_HSPAN && hspan_blocks (jobs [j]) > g.max_lds) g.max_lds = hspan_blocks (jobs [j]);
             units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
         }
 
@@ -1082,6 +1090,9 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
         return -(int) e;
     }
 
+    /* the representative of a group is its first descriptor as finally laid out (scratch pointers included) */
+    for (SmolHipBatch::Group &g : b->groups)
+        g.rep = sorted [g.first];
     b->jobs_host = sorted;
     *batch_out = b;
     return 0;
@@ -1146,8 +1157,10 @@ smol_hip_batch_launch (SmolHipBatch *batch, void *hip_stream)
         HIP_TRY (hipGraphLaunch (batch->graph_exec, s));
         return 0;
     }
+    /* a group of one travels in the kernel arguments (no descriptor fetch at the head of every workgroup) */
     for (const SmolHipBatch::Group &g : batch->groups)
-        HIP_TRY (launch_class (g.k, batch->jobs_dev + g.first, g.count, g.rep, g.max_w_out, g.max_rows, s, g.max_lds));
+        HIP_TRY (launch_class (g.k, g.count == 1 ? nullptr : batch->jobs_dev + g.first, g.count, g.rep,
+                               g.max_w_out, g.max_rows, s, g.max_lds));
     return 0;
 }
 

@@ -87,7 +87,7 @@ static const TypeInfo k_types [10] = {
     { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
 };
 
-enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_UP, KC_DOWN, KC_BOX2, KC_COUNT };
+enum KClass { KC_GENERAL = 0, KC_GENERAL_WIDE, KC_POW2, KC_TILE, KC_WTILE, KC_WAVEPX, KC_WAVEPX_WIDE, KC_POW2X, KC_UP, KC_DOWN, KC_BOX2, KC_HSPAN, KC_COUNT };
 
 inline size_t align_up (size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -601,6 +601,47 @@ box2_h_lds_bytes (const JobDev &d)
     return (d.wide ? DOWN_LUT_BYTES_FWD : 0u) + 4u * 2u * d.span_chunks * 16u + 32u;
 }
 
+/* k_hspan (smol_kernel_hspan.hip.h): vertical COPY, horizontal bilinear at (nearly) the power-of-two
+ * ratio its halvings imply -- at most two places per row where the sampling grid slips by a pixel
+ * (BASELINE config 4: 65535 -> 8192, BILINEAR_2H, one slip). 64bpp class, any pixel types; 24-bit
+ * input needs at least one halving (a lane's window must be a multiple of 16 bytes). */
+/* rows a workgroup walks. ONE: workgroups then sweep the image in raster order, which is what HBM
+ * wants -- config 4 takes 150 us with 1 row per workgroup, 175 with 2, 188 with 4, 197 with 8, 292
+ * with 64 (tests/exp/hspan_ab.hip, profiles/r02c_hspan_ab.txt); the per-row set-up is 3 % */
+constexpr uint32_t HSPAN_BAND_ROWS = 1;
+
+inline bool
+hspan_setup (JobDev &d)
+{
+    if (d.wide || d.filter_v != F_COPY || d.filter_h != F_BILINEAR || tune_env ("SMOL_NO_HSPAN"))
+        return false;
+    if (d.bpp_in == 3 && d.halv_h == 0)
+        return false;
+    const uint64_t full = (uint64_t) d.w_out << (d.halv_h + 1);
+    const uint64_t diff = full > d.w_in ? full - d.w_in : d.w_in - full;
+    if (diff > 2 || d.w_out < 256 || d.w_in < 4)
+        return false;
+    d.tile_rows = (uint16_t) HSPAN_BAND_ROWS;
+    if (const char *e = tune_env ("SMOL_HSPAN_ROWS"))
+        if (atoi (e) >= 1 && atoi (e) <= 4096)
+            d.tile_rows = (uint16_t) atoi (e);
+    return true;
+}
+
+inline uint32_t
+hspan_blocks (const JobDev &d)
+{
+    return ((d.w_out + 1023u) / 1024u) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
+}
+
+inline uint32_t
+hspan_lds_bytes (const JobDev &d)
+{
+    const uint32_t wb = 4u * (2u << d.halv_h) * d.bpp_in;           /* bytes of a lane's window */
+    const uint32_t nl = (64u * wb + 1023u) / 1024u + 1u;
+    return 4u * (nl * 1024u + 32u);
+}
+
 inline KClass
 classify (JobDev &d)
 {
@@ -614,6 +655,8 @@ classify (JobDev &d)
         return KC_DOWN;
     if (box2_setup (d))
         return KC_BOX2;
+    if (hspan_setup (d))
+        return KC_HSPAN;
     if (tile_ok (d))
         return KC_TILE;
     if (wtile_ok (d))
@@ -635,6 +678,7 @@ kclass_name (KClass k, const JobDev &d)
         case KC_UP: return "k_up_batch";
         case KC_DOWN: return "k_down_batch";
         case KC_BOX2: return "k_boxh_batch + k_boxv_batch";
+        case KC_HSPAN: return "k_hspan_batch";
         case KC_TILE: return "k_tile_batch";
         case KC_WTILE: return "k_wtile_batch";
         case KC_WAVEPX: return "k_wavepx_batch<false>";

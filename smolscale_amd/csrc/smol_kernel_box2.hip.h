@@ -402,7 +402,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__ (256)
 k_boxh_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     boxh_entry<WIDE> (J, smol_dyn_lds);
 }
 
@@ -417,7 +417,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__ (256)
 k_boxv_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     boxv_entry<WIDE> (J, smol_dyn_lds);
 }
 

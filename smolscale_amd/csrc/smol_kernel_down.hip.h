@@ -435,7 +435,7 @@ template <int HC>
 __global__ void __launch_bounds__ (64)
 k_down_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
 }
 
@@ -450,7 +450,7 @@ template <int HX, int MODE>
 __global__ void __launch_bounds__ (256)
 k_downg_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     down_gen_entry<HX, MODE> (J, smol_dyn_lds);
 }
 

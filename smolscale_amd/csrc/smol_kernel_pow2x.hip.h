@@ -352,7 +352,7 @@ template <int H, int IN>
 __global__ void __launch_bounds__ (1024)
 k_pow2x_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];         /* uniform: scalar loads, once */
+    const JobDev J = load_job (jobs, blockIdx.y);         /* uniform: scalar loads, once */
     pow2x_body<H, IN> (J);
 }
 

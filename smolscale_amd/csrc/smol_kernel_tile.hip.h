@@ -965,7 +965,7 @@ k_tile_batch (const JobDev *__restrict__ jobs)
 {
     /* private copy: the descriptor must not be re-read from memory after every
      * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     tile_entry<TS, HM, CPL, VCOPY> (J, smol_dyn_lds);
 }
 

@@ -658,7 +658,7 @@ template <int INK, int OUT>
 __global__ void __launch_bounds__ (64)
 k_up_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     if (OUT == OUT_W16)
         up16_body<INK> (J, smol_dyn_lds);
     else
@@ -669,7 +669,7 @@ template <bool W32>
 __global__ void __launch_bounds__ (256)
 k_upg_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     upg_entry<W32> (J, smol_dyn_lds);
 }
 

@@ -279,7 +279,7 @@ __device__ __forceinline__ void wtile_dispatch (const JobDev &J, uint8_t *sbuf)
 __global__ void __launch_bounds__ (64)
 k_wtile_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     wtile_dispatch (J, smol_dyn_lds);
 }
 

@@ -65,6 +65,34 @@ __device__ __forceinline__ const gbyte *gptr (const void *p)
     return reinterpret_cast<const gbyte *> (reinterpret_cast<uintptr_t> (p));
 }
 
+/* Descriptor `idx' of a device-resident table (idx wave-uniform). Fetched as whole dwords: the
+ * compiler then uses scalar loads (s_load_dwordxN through the scalar cache) and picks the 8- and
+ * 16-bit fields out of SGPRs. A plain struct copy loads every sub-dword member with its own
+ * global_load_ubyte / _ushort -- vector-memory latency at the head of every workgroup: config 4
+ * ran 159 us that way against 149 us with the descriptor in the kernel arguments. */
+struct JobDevRaw { uint32_t w [sizeof (JobDev) / 4]; };
+static_assert (sizeof (JobDev) % 4 == 0 && sizeof (JobDevRaw) == sizeof (JobDev), "JobDev is copied dword-wise");
+
+__device__ __forceinline__ JobDev load_job (const JobDev *jobs, uint32_t idx)
+{
+    JobDevRaw raw;
+    const uint32_t *p = reinterpret_cast<const uint32_t *> (jobs + idx);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof (JobDev) / 4; i++)
+        raw.w [i] = p [i];
+#ifndef SMOL_KERNEL_EMU
+    /* every dword has to exist whole in a scalar register (after all loads have been issued):
+     * keeps the optimiser from narrowing a load to the bytes one field needs, which only vector
+     * loads can fetch */
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof (JobDev) / 4; i++)
+        asm volatile ("" : "+s" (raw.w [i]));
+#endif
+    JobDev J;
+    __builtin_memcpy (&J, &raw, sizeof (J));
+    return J;
+}
+
 /* ------------------------------------------------------------------------- *
  * Per-channel arithmetic                                                    *
  * ------------------------------------------------------------------------- */
@@ -617,7 +645,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__ (GENERAL_BLOCK)
 k_general_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     general_body<WIDE> (J);
 }
 
@@ -698,7 +726,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__ (64)
 k_wavepx_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = jobs [blockIdx.y];
+    const JobDev J = load_job (jobs, blockIdx.y);
     wavepx_body<WIDE> (J);
 }
 
@@ -832,7 +860,7 @@ template <int HX, int HY>
 __global__ void __launch_bounds__ (1024)
 k_pow2_batch (const JobDev *jobs)
 {
-    pow2_body<HX, HY> (jobs [blockIdx.y]);
+    pow2_body<HX, HY> (load_job (jobs, blockIdx.y));
 }
 
 template <int HX, int HY>

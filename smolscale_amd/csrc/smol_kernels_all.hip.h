@@ -7,3 +7,4 @@
 #include "smol_kernel_up.hip.h"
 #include "smol_kernel_down.hip.h"
 #include "smol_kernel_box2.hip.h"
+#include "smol_kernel_hspan.hip.h"

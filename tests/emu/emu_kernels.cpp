@@ -104,7 +104,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
      * must start from the pristine descriptor again */
     const JobDev pristine = J;
     KClass k = classify (J);
-    if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_UP || k == KC_DOWN || k == KC_BOX2 || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
+    if (force_general && (k == KC_POW2 || k == KC_POW2X || k == KC_UP || k == KC_DOWN || k == KC_BOX2 || k == KC_HSPAN || k == KC_TILE || k == KC_WTILE || k == KC_WAVEPX || k == KC_WAVEPX_WIDE))
         k = J.wide ? KC_GENERAL_WIDE : KC_GENERAL;
     if (force_general == 2 && tile_ok (J))
     {
@@ -149,6 +149,13 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
         J.tmp = tmp.data ();
         run_grid_coop (box2_h_tiles (J), 64, box2_h_lds_bytes (J), [&] { k_boxh_one (J); });
         run_grid_coop (box2_v_tiles (J), 64, 0, [&] { k_boxv_one (J); });
+        return 0;
+    }
+
+    if (k == KC_HSPAN)
+    {
+        /* 4 waves per workgroup, each with its private LDS image */
+        run_grid_coop (hspan_blocks (J), 64 * HSPAN_WAVES, hspan_lds_bytes (J), [&] { k_hspan_one (J); });
         return 0;
     }
 
