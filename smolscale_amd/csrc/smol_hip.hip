@@ -50,12 +50,14 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         const uint32_t rx = 2u << rep.halv_h;
         const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
         const uint32_t tcols = max_w_out / opt;
-        L::pow2 (jobs_dev, rep, dim3 (((tcols + 63) / 64) * ((max_rows + 15) / 16), n_jobs), s);
+        const uint32_t by = pow2_block_rows ();
+        L::pow2 (jobs_dev, rep, dim3 ((tcols + 63) / 64, (max_rows + by - 1) / by, n_jobs), by, s);
     }
     else if (k == KC_POW2X)
     {
-        /* max_lds carries the group's largest block count */
-        L::pow2x (jobs_dev, rep, dim3 (max_lds ? max_lds : pow2x_blocks (rep), n_jobs), s);
+        /* max_w_out / max_rows carry the group's largest column / row tile counts (batches) */
+        L::pow2x (jobs_dev, rep, dim3 (jobs_dev ? max_w_out : pow2x_tiles_x (rep),
+                                       jobs_dev ? max_rows : pow2x_tiles_y (rep), n_jobs), s);
     }
     else if (k == KC_DOWN)
     {
@@ -1029,6 +1031,13 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
                 continue;
             }
+            if (g.k == KC_POW2X)
+            {
+                if (pow2x_tiles_x (jobs [j]) > g.max_w_out) g.max_w_out = pow2x_tiles_x (jobs [j]);
+                if (pow2x_tiles_y (jobs [j]) > g.max_rows) g.max_rows = pow2x_tiles_y (jobs [j]);
+                units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
+                continue;
+            }
             if (g.k == KC_UP)
             {
                 if (up_lds_bytes (jobs [j]) > g.max_w_out) g.max_w_out = up_lds_bytes (jobs [j]);
@@ -1040,7 +1049,6 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             else if (jobs [j].w_out > g.max_w_out) g.max_w_out = jobs [j].w_out;
             if (jobs [j].n_rows > g.max_rows) g.max_rows = jobs [j].n_rows;
             if ((g.k == KC_TILE || g.k == KC_WTILE) && tile_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = tile_lds_bytes (jobs [j]);
-            if (g.k == KC_POW2X && pow2x_blocks (jobs [j]) > g.max_lds) g.max_lds = pow2x_blocks (jobs [j]);
             if (g.k == KC_UP && up_blocks (jobs [j]) > g.max_lds) g.max_lds = up_blocks (jobs [j]);
             if (g.k == KC_DOWN && down_blocks (jobs [j]) > g.max_lds) g.max_lds = down_blocks (jobs [j]);
             if (g.k == KC_HSPAN && hspan_blocks (jobs [j]) > g.max_lds) g.max_lds = hspan_blocks (jobs [j]);

@@ -314,6 +314,17 @@ pow2_ok (const JobDev &d)
     return true;
 }
 
+/* k_pow2 workgroup height: output rows (= waves) per workgroup */
+inline uint32_t
+pow2_block_rows ()
+{
+    uint32_t by = 16;
+    if (const char *e = tune_env ("SMOL_POW2_BY"))
+        if (atoi (e) >= 1 && atoi (e) <= 16)
+            by = (uint32_t) atoi (e);
+    return by;
+}
+
 /* k_pow2x geometry: output pixels per lane for this job's kind and ratio */
 inline uint32_t
 pow2x_opt (const JobDev &d)
@@ -360,13 +371,20 @@ pow2x_setup (JobDev &d)
     return true;
 }
 
+/* k_pow2x grid: (column tiles, row tiles) -- a 2-D grid, so no division at the head of a workgroup */
 inline uint32_t
-pow2x_blocks (const JobDev &d)
+pow2x_tiles_x (const JobDev &d)
 {
     const uint32_t tcols = d.w_out / pow2x_opt (d);
     const uint32_t lpr = 1u << d.px_lpr_shift;
+    return (tcols + lpr - 1) / lpr;
+}
+
+inline uint32_t
+pow2x_tiles_y (const JobDev &d)
+{
     const uint32_t rows_per_block = 16u * (64u >> d.px_lpr_shift);
-    return ((tcols + lpr - 1) / lpr) * ((d.n_rows + rows_per_block - 1) / rows_per_block);
+    return (d.n_rows + rows_per_block - 1) / rows_per_block;
 }
 
 /* k_up: bilinear magnification on both axes, 64bpp class. A tile of tile_rows
@@ -393,9 +411,16 @@ up_setup (JobDev &d)
         return false;
 
     d.up_wide = (uint8_t) flavour;
+    d.tile_band = tune_env ("SMOL_NO_UP_BAND") ? 0 : 1;     /* tiles dealt out in XCD bands */
     uint64_t tr = (((uint64_t) ((flavour ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
     if (tr > 64)
         tr = 64;
+    /* 64bpp class: the kernel is bound by its stores, and those want the chip to sweep the output in
+     * (nearly) raster order -- flat tiles. Config 3: 8 rows 89-92 us, 7 or 9 rows 92, 6 rows 98, 12-29
+     * rows 97-104, 4 rows 124 (per-tile set-up); profiles/r02e_up_tile_rows.txt. The table-driven
+     * flavours are bound by arithmetic per tile and keep the tall tiles. */
+    if (flavour == 0 && tr > 8)
+        tr = 8;
     if (const char *e = tune_env ("SMOL_UP_ROWS"))
         if ((uint64_t) atoi (e) >= 1 && (uint64_t) atoi (e) < tr)
             tr = (uint64_t) atoi (e);

@@ -17,23 +17,23 @@ namespace {
  * blockIdx.y) or takes the single descriptor `rep' by value as kernel argument. */
 template <int HX, int HY>
 void
-launch_pow2_one (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
+launch_pow2_one (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t by, hipStream_t s)
 {
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (64, 16), 0, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (64, by), 0, s, jobs_dev);
     else
-        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (64, 16), 0, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (64, by), 0, s, rep);
 }
 
 template <int HX>
 void
-launch_pow2_hy (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
+launch_pow2_hy (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t by, hipStream_t s)
 {
     switch (rep.halv_v)
     {
-        case 0: launch_pow2_one<HX, 0> (jobs_dev, rep, grid, s); break;
-        case 1: launch_pow2_one<HX, 1> (jobs_dev, rep, grid, s); break;
-        default: launch_pow2_one<HX, 2> (jobs_dev, rep, grid, s); break;
+        case 0: launch_pow2_one<HX, 0> (jobs_dev, rep, grid, by, s); break;
+        case 1: launch_pow2_one<HX, 1> (jobs_dev, rep, grid, by, s); break;
+        default: launch_pow2_one<HX, 2> (jobs_dev, rep, grid, by, s); break;
     }
 }
 
@@ -68,13 +68,13 @@ namespace smolhip {
 namespace launch {
 
 void
-pow2 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
+pow2 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t by, hipStream_t s)
 {
     switch (rep.halv_h)
     {
-        case 0: launch_pow2_hy<0> (jobs_dev, rep, grid, s); break;
-        case 1: launch_pow2_hy<1> (jobs_dev, rep, grid, s); break;
-        default: launch_pow2_hy<2> (jobs_dev, rep, grid, s); break;
+        case 0: launch_pow2_hy<0> (jobs_dev, rep, grid, by, s); break;
+        case 1: launch_pow2_hy<1> (jobs_dev, rep, grid, by, s); break;
+        default: launch_pow2_hy<2> (jobs_dev, rep, grid, by, s); break;
     }
 }
 

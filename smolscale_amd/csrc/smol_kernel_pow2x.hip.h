@@ -235,8 +235,7 @@ __device__ __forceinline__ void pow2x_body (const JobDev &J)
     const uint32_t shift = J.px_lpr_shift;                 /* log2 (lanes per output row in a wave) */
     const uint32_t lpr = 1u << shift;
     const uint32_t tcols = J.w_out / C::OPT;
-    const uint32_t tiles_x = (tcols + lpr - 1) >> shift;
-    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t bx = blockIdx.x, by = blockIdx.y;       /* grid = (column tiles, row tiles, jobs) */
     const uint32_t row = ((by * 16 + threadIdx.y) << (6 - shift)) + (lane >> shift);
     const uint32_t tc = (bx << shift) + (lane & (lpr - 1));
     const bool live = row < J.n_rows && tc < tcols;
@@ -352,7 +351,7 @@ template <int H, int IN>
 __global__ void __launch_bounds__ (1024)
 k_pow2x_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = load_job (jobs, blockIdx.y);         /* uniform: scalar loads, once */
+    const JobDev J = load_job (jobs, blockIdx.z);         /* uniform: scalar loads, once */
     pow2x_body<H, IN> (J);
 }
 

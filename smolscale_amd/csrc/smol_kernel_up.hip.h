@@ -82,7 +82,7 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
     /* each XCD (blocks go round-robin over the 8 of them) takes a contiguous band of
      * tiles, so horizontally adjacent tiles are written from the same L2 at about
      * the same time; the host rounds the grid up to a multiple of 8 */
-    const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t bid = J.tile_band ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t tx = bid % tiles_x;
     const uint32_t ty = bid / tiles_x;
     const uint32_t yrel0 = ty * J.tile_rows;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
 
     const uint32_t lane = threadIdx.x;
     const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
-    const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);     /* see up_body */
+    const uint32_t bid = J.tile_band ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;     /* see up_body */
     const uint32_t tx = bid % tiles_x;
     const uint32_t ty = bid / tiles_x;
     const uint32_t yrel0 = ty * J.tile_rows;

@@ -797,10 +797,10 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
     /* Workgroup = 64 thread-columns x 16 output rows, one wave per output row:
      * measured best of the layouts tried (tests/exp/pow2_variants.hip, 83.9 % of
      * 8 TB/s against 79.5 % for 256 x 1), with non-temporal loads AND stores. */
+    /* grid = (column tiles, row tiles, jobs): no division at the head of a workgroup */
     const uint32_t tcols = J.w_out / C::OPT;
-    const uint32_t tiles_x = (tcols + C::BLOCK_X - 1) / C::BLOCK_X;
-    const uint32_t row = (blockIdx.x / tiles_x) * C::BLOCK_Y + threadIdx.y;
-    const uint32_t tc = (blockIdx.x % tiles_x) * C::BLOCK_X + threadIdx.x;
+    const uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
+    const uint32_t tc = blockIdx.x * C::BLOCK_X + threadIdx.x;
 
     if (row >= J.n_rows || tc >= tcols)
         return;
@@ -860,7 +860,7 @@ template <int HX, int HY>
 __global__ void __launch_bounds__ (1024)
 k_pow2_batch (const JobDev *jobs)
 {
-    pow2_body<HX, HY> (load_job (jobs, blockIdx.y));
+    pow2_body<HX, HY> (load_job (jobs, blockIdx.z));
 }
 
 template <int HX, int HY>

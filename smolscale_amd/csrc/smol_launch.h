@@ -13,7 +13,8 @@
 namespace smolhip {
 namespace launch {
 
-void pow2 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s);
+/* grid = (column tiles of 64 thread columns, row tiles of block_rows output rows, jobs) */
+void pow2 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t block_rows, hipStream_t s);
 void pow2x (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s);
 void up (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
 void down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);

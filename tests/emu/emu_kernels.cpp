@@ -55,41 +55,42 @@ static void run_grid (unsigned gx, unsigned gy, unsigned bx, F body)
 }
 
 template <typename F>
-static void run_grid_2d (unsigned gx, unsigned bx, unsigned by, F body)
+static void run_grid_2d (unsigned gx, unsigned bx, unsigned by, F body, unsigned gy = 1)
 {
-    gridDim = { gx, 1, 1 };
+    gridDim = { gx, gy, 1 };
     blockDim = { bx, by, 1 };
-    for (unsigned b = 0; b < gx; b++)
-        for (unsigned ty = 0; ty < by; ty++)
-            for (unsigned t = 0; t < bx; t++)
-            {
-                blockIdx = { b, 0, 0 };
-                threadIdx = { t, ty, 0 };
-                body ();
-            }
+    for (unsigned g2 = 0; g2 < gy; g2++)
+        for (unsigned b = 0; b < gx; b++)
+            for (unsigned ty = 0; ty < by; ty++)
+                for (unsigned t = 0; t < bx; t++)
+                {
+                    blockIdx = { b, g2, 0 };
+                    threadIdx = { t, ty, 0 };
+                    body ();
+                }
 }
 
 template <int HX>
-static void run_pow2_hy (const JobDev &J, unsigned gx)
+static void run_pow2_hy (const JobDev &J, unsigned gx, unsigned gy)
 {
     switch (J.halv_v)
     {
-        case 0: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 0> (J); }); break;
-        case 1: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 1> (J); }); break;
-        default: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 2> (J); }); break;
+        case 0: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 0> (J); }, gy); break;
+        case 1: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 1> (J); }, gy); break;
+        default: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 2> (J); }, gy); break;
     }
 }
 
 template <int H>
-static void run_pow2x_h (const JobDev &J, unsigned gx)
+static void run_pow2x_h (const JobDev &J, unsigned gx, unsigned gy)
 {
     switch (J.px_kind)
     {
-        case PX_N32: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_N32> (J); }); break;
-        case PX_N24: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_N24> (J); }); break;
-        case PX_W32: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W32> (J); }); break;
-        case PX_W16: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W16> (J); }); break;
-        default:     run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W24> (J); }); break;
+        case PX_N32: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_N32> (J); }, gy); break;
+        case PX_N24: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_N24> (J); }, gy); break;
+        case PX_W32: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W32> (J); }, gy); break;
+        case PX_W16: run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W16> (J); }, gy); break;
+        default:     run_grid_2d (gx, 64, 16, [&] { k_pow2x_one<H, PX_W24> (J); }, gy); break;
     }
 }
 
@@ -121,24 +122,24 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
         const uint32_t rx = 2u << J.halv_h;
         const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
         const uint32_t tcols = J.w_out / opt;
-        unsigned gx = ((tcols + 63) / 64) * ((n_rows + 15) / 16);
+        const unsigned gx = (tcols + 63) / 64, gy = (n_rows + 15) / 16;
         switch (J.halv_h)
         {
-            case 0: run_pow2_hy<0> (J, gx); break;
-            case 1: run_pow2_hy<1> (J, gx); break;
-            default: run_pow2_hy<2> (J, gx); break;
+            case 0: run_pow2_hy<0> (J, gx, gy); break;
+            case 1: run_pow2_hy<1> (J, gx, gy); break;
+            default: run_pow2_hy<2> (J, gx, gy); break;
         }
         return 0;
     }
 
     if (k == KC_POW2X)
     {
-        const unsigned gx = pow2x_blocks (J);
+        const unsigned gx = pow2x_tiles_x (J), gy = pow2x_tiles_y (J);
         switch (J.halv_h)
         {
-            case 0: run_pow2x_h<0> (J, gx); break;
-            case 1: run_pow2x_h<1> (J, gx); break;
-            default: run_pow2x_h<2> (J, gx); break;
+            case 0: run_pow2x_h<0> (J, gx, gy); break;
+            case 1: run_pow2x_h<1> (J, gx, gy); break;
+            default: run_pow2x_h<2> (J, gx, gy); break;
         }
         return 0;
     }
