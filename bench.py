@@ -169,8 +169,11 @@ def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out
     slab_rows = r1 - r0 + 1
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x9E3779B9 + rank)
-    src = torch.randint(0, 256, (n_frames, slab_rows * s_in + 64), dtype=torch.uint8, device=dev, generator=gen)
-    dst = torch.zeros((n_frames, n_rows * s_out + 64), dtype=torch.uint8, device=dev)
+    # every frame starts on a 256-byte boundary, as buffers from any device allocator do
+    slot_in = (slab_rows * s_in + 64 + 255) // 256 * 256
+    slot_out = (n_rows * s_out + 64 + 255) // 256 * 256
+    src = torch.randint(0, 256, (n_frames, slot_in), dtype=torch.uint8, device=dev, generator=gen)
+    dst = torch.zeros((n_frames, slot_out), dtype=torch.uint8, device=dev)
     frame0 = seed0_frame()
     src[0, :slab_rows * s_in].copy_(torch.from_numpy(frame0[r0 * s_in:(r1 + 1) * s_in]))
     images = [_image(job, src[f].data_ptr() - r0 * s_in, dst[f].data_ptr(), s_in, s_out, first_row, n_rows)
@@ -306,8 +309,8 @@ def other_configs(dev, local_rank):
     for name, (t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_img) in OTHER_CONFIGS.items():
         try:
             rng = np.random.default_rng(20260202)
-            slot_in = h_in * (stride_in or w_in * 4) + 64
-            slot_out = h_out * w_out * 4 + 64
+            slot_in = (h_in * (stride_in or w_in * 4) + 64 + 255) // 256 * 256      # 256-byte aligned images
+            slot_out = (h_out * w_out * 4 + 64 + 255) // 256 * 256
             src = torch.randint(0, 256, (n_img, slot_in), dtype=torch.uint8, device=dev)
             dst = torch.zeros((n_img, slot_out), dtype=torch.uint8, device=dev)
             jobs, images, algo = {}, [], 0

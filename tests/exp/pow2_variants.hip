@@ -134,6 +134,8 @@ int main()
         {"wrow 64x4 ntS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<4,true>), dim3(W_OUT/64*H_OUT/4, NF), dim3(64,4), 0, s, a, b); }},
         {"wrow 64x8 ntS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<8,true>), dim3(W_OUT/64*H_OUT/8, NF), dim3(64,8), 0, s, a, b); }},
         {"wrow 64x16 ntS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<16,true>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrow 64x16 plainS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<16,false>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrow 64x8 plainS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<8,false>), dim3(W_OUT/64*H_OUT/8, NF), dim3(64,8), 0, s, a, b); }},
         {"REF read-only 16B x4 nt", [](const uint8_t* a, uint8_t* b, hipStream_t s){ size_t n = (size_t)NF*W_IN*H_IN*4/16; hipLaunchKernelGGL(k_read, dim3((unsigned)(n/4/256)), dim3(256), 0, s, (const u32x4*)a, (uint32_t*)b, n); }},
     };
     // reference output
