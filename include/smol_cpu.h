@@ -1,0 +1,29 @@
+/* smol_cpu.h -- C-ABI of the library's CPU backend (a from-scratch AVX2 / AVX-512
+ * implementation of the same resampling path, bit-exact with the reference's generic code,
+ * smolscale-generic.c:185-2318). It is what smol_scale_*() runs on when the caller selects it with
+ * SMOL_BACKEND=cpu (or SMOL_BACKEND=auto on a machine without a usable GPU); the default backend
+ * stays HIP, and a missing GPU then stays a loud failure. */
+
+#ifndef SMOLSCALE_AMD_SMOL_CPU_H
+#define SMOLSCALE_AMD_SMOL_CPU_H
+
+#include <stdint.h>
+#include "smol_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Rows [first_row, first_row + n_rows) of the job planned by smol_hip_plan_job(), host pointers,
+ * row `first_row' written at dest + 0, rowstride_out apart (bytes between rows untouched).
+ * Thread-safe (no shared state). Returns 0 or SMOL_HIP_E_INVALID. */
+int smol_cpu_scale_rows (const SmolHipJob *job,
+                         const void *pixels_in, uint32_t rowstride_in,
+                         void *dest, uint32_t rowstride_out,
+                         uint32_t first_row, uint32_t n_rows);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SMOLSCALE_AMD_SMOL_CPU_H */

@@ -115,6 +115,8 @@ EXPORTS = {
     "smol_hip_batch_multi_time": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
     "smol_hip_batch_multi_destroy": (None, [_vp]),
     "smol_hip_shutdown": (None, []),
+    # include/smol_cpu.h
+    "smol_cpu_scale_rows": (_int, [ctypes.POINTER(SmolHipJob), _vp, _u32, _vp, _u32, _u32, _u32]),
     "smol_hip_malloc": (_int, [_int, _u64, ctypes.POINTER(_vp)]),
     "smol_hip_free": (_int, [_int, _vp]),
     "smol_hip_memcpy_h2d": (_int, [_int, _vp, _vp, _u64]),

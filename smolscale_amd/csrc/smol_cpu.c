@@ -1,0 +1,674 @@
+/* smol_cpu.c -- the library's CPU backend: the whole resampling path on the
+ * host cores, from scratch, behind the same seam as the HIP backend (smolscale_api.c). Never the
+ * default: it runs only when the caller asks for it (SMOL_BACKEND=cpu, or SMOL_BACKEND=auto on a
+ * machine without a usable GPU); with the default SMOL_BACKEND=hip a missing GPU is still a loud
+ * abort().
+ *
+ * What it has to reproduce is the reference's integer fixed-point path; the arithmetic is restated
+ * per channel exactly as the HIP kernels restate it (smol_kernels.hip.h: unpack_word / hsample /
+ * general_pixel / store_px), so that the two backends of this library agree byte for byte with each
+ * other and with the reference's GENERIC implementation:
+ *   unpack    smolscale-generic.c:353-464 (64bpp class), :470-752 (128bpp class)
+ *   horizontal :1290-1611, vertical :1648-2318, pack :758-1164
+ * Known reference inconsistency, decided explicitly: for unassociated -> unassociated (premul16) the
+ * reference's generic packer WRAPS (& 0xff, smolscale-generic.c:290-299) where its AVX2 packer
+ * SATURATES (smolscale-avx2.c:1045-1047). This backend wraps, like the generic code, the oracle and
+ * the HIP kernels.
+ *
+ * Shape: rows. A source row is unpacked to four lanes per pixel, filtered horizontally with
+ * per-column tap tables built once per call from the closed-form sampling positions, and the
+ * horizontally filtered rows meet in the vertical filter through a small row cache (bilinear) or an
+ * accumulator (box). Two code paths:
+ *   - generic: 32-bit lanes, every job (both storage classes, every pixel type, sRGB);
+ *   - fast: the BASELINE class (32-bit premultiplied in and out, bilinear on both axes, 64bpp
+ *     storage -- configs 1, 2 and 5) in packed 16-bit lanes with AVX2 / AVX-512BW intrinsics,
+ *     selected at run time (__builtin_cpu_supports). */
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined (__x86_64__)
+#include <immintrin.h>
+#define SMOL_CPU_X86 1
+#endif
+
+#include "smol_hip.h"
+#include "smol_cpu.h"
+#include "smol_luts.h"
+
+enum { F_COPY = SMOL_HIP_FILTER_COPY, F_ONE = SMOL_HIP_FILTER_ONE, F_BILINEAR = SMOL_HIP_FILTER_BILINEAR, F_BOX = SMOL_HIP_FILTER_BOX };
+
+/* byte position of R,G,B,A per SmolPixelType (smolscale.h:16-36 names the memory order) */
+typedef struct { uint8_t bpp; uint8_t pos [4]; uint8_t unassoc; } TypeInfo;
+
+static const TypeInfo k_types [10] = {
+    { 4, { 0, 1, 2, 3 }, 0 }, { 4, { 2, 1, 0, 3 }, 0 }, { 4, { 1, 2, 3, 0 }, 0 }, { 4, { 3, 2, 1, 0 }, 0 },
+    { 4, { 0, 1, 2, 3 }, 1 }, { 4, { 2, 1, 0, 3 }, 1 }, { 4, { 1, 2, 3, 0 }, 1 }, { 4, { 3, 2, 1, 0 }, 1 },
+    { 3, { 0, 1, 2, 0xff }, 0 }, { 3, { 2, 1, 0, 0xff }, 0 },
+};
+
+typedef struct
+{
+    const SmolHipJob *job;
+    const TypeInfo *ti, *to;
+    int wide, p16, linear, quirk24;
+    uint32_t mask;                      /* lane mask of the storage class: 0xff / 0x00ffffff */
+    /* horizontal tables */
+    uint32_t *h_ofs;                    /* bilinear: source index of sample j; box: first index of box x */
+    uint16_t *h_f;                      /* bilinear: weight F of sample j (0..256)                        */
+    uint32_t *h_last;                   /* box: last index of box x                                       */
+    uint16_t *h_wl, *h_fr;              /* box: left / right edge weights                                 */
+}
+Ctx;
+
+/* ---- per-channel arithmetic (the formulas of smol_kernels.hip.h) ------------------------------- */
+
+static inline uint32_t premul8 (uint32_t c, uint32_t a) { return (((c + 1u) * (a + 1u) - 1u) >> 8) & 0xffu; }
+static inline uint32_t premul8l (uint32_t l, uint32_t a) { return (((l + 1u) * ((a << 3) + 1u) - 1u) >> 11) & 0x7ffu; }
+static inline uint32_t unpremul8 (uint32_t c, uint32_t a) { return (uint32_t) ((((uint64_t) c * smol_inv_p8_lut [a]) >> 13) & 0xffu); }
+
+static inline uint32_t
+lerp (uint32_t p, uint32_t q, uint32_t F, uint32_t mask)
+{
+    int32_t d = ((int32_t) p - (int32_t) q) * (int32_t) F;
+    return (uint32_t) ((d >> 8) + (int32_t) q) & mask;
+}
+
+static inline uint32_t
+box_scale (const Ctx *c, uint32_t acc, uint32_t mul)
+{
+    uint64_t v;
+    if (!c->wide)
+        acc &= 0xffffu;
+    v = (uint64_t) acc * mul + (1u << 23);
+    return (uint32_t) (v >> 24) & (c->wide ? 0xffffu : 0xffu);
+}
+
+static void
+bilin_tap (uint64_t pos, uint32_t dim_in, uint32_t *ofs, uint32_t *F)
+{
+    uint32_t o = (uint32_t) (pos >> 32);
+    if (o >= dim_in - 1) { *ofs = dim_in - 2; *F = 0; }
+    else { *ofs = o; *F = 256u - ((uint32_t) (pos >> 24) & 0xffu); }
+}
+
+static void
+box_span (uint64_t step, uint32_t dim_in, uint32_t k, uint32_t *o0, uint32_t *o1, uint32_t *f_right, uint32_t *w_left)
+{
+    uint64_t b = (uint64_t) k * step, e = b + step;
+    uint32_t last = (uint32_t) (e >> 16);
+    *o0 = (uint32_t) (b >> 16);
+    *o1 = last > dim_in - 1 ? dim_in - 1 : last;
+    *f_right = (uint32_t) (e >> 8) & 0xffu;
+    *w_left = k ? 255u - ((uint32_t) (b >> 8) & 0xffu) : 256u;
+}
+
+/* ---- unpack one row: memory pixels -> four 32-bit lanes (R, G, B, alpha lane) -------------------- */
+
+static void
+unpack_row (const Ctx *c, const uint8_t *src, uint32_t n, uint32_t *out)
+{
+    const TypeInfo *ti = c->ti;
+    const uint32_t bpp = ti->bpp, pr = ti->pos [0], pg = ti->pos [1], pb = ti->pos [2], pa = ti->pos [3];
+    uint32_t i, k;
+
+    for (i = 0; i < n; i++, src += bpp, out += 4)
+    {
+        uint32_t ch [3] = { src [pr], src [pg], src [pb] };
+        const uint32_t a = (bpp == 4) ? src [pa] : 0xffu;
+
+        if (c->wide && c->p16)
+        {
+            for (k = 0; k < 3; k++)
+                out [k] = (c->linear ? smol_from_srgb_lut [ch [k]] : ch [k]) * a;
+            out [3] = (a << 8) | 0x80u;
+            continue;
+        }
+        if (c->wide && c->linear)
+        {
+            for (k = 0; k < 3; k++)
+            {
+                uint32_t v = ch [k];
+                if (bpp == 4 && !ti->unassoc)
+                    v = unpremul8 (v, a);
+                else if (bpp == 3)
+                    v = unpremul8 (v, 0xffu);
+                out [k] = premul8l (smol_from_srgb_lut [v], a);
+            }
+        }
+        else if (ti->unassoc)
+        {
+            for (k = 0; k < 3; k++)
+                out [k] = premul8 (ch [k], a);
+        }
+        else
+        {
+            out [0] = ch [0]; out [1] = ch [1]; out [2] = ch [2];
+        }
+        out [3] = a;
+    }
+}
+
+/* ---- pack one row ---------------------------------------------------------------------------- */
+
+static void
+pack_row (const Ctx *c, const uint32_t *in, uint32_t n, uint8_t *dst)
+{
+    const TypeInfo *to = c->to;
+    const uint32_t bpp = to->bpp;
+    uint32_t i, k;
+
+    for (i = 0; i < n; i++, in += 4, dst += bpp)
+    {
+        uint32_t a, o [3];
+
+        a = (c->wide && c->p16) ? (in [3] >> 8) & 0xffu : in [3] & 0xffu;
+        for (k = 0; k < 3; k++)
+        {
+            const uint32_t s = in [k];
+
+            if (!c->wide || (!c->p16 && !c->linear))
+                o [k] = to->unassoc ? unpremul8 (s, a) : (s & 0xffu);
+            else if (c->p16)
+            {
+                if (c->linear)
+                    o [k] = smol_to_srgb_lut [(uint32_t) (((uint64_t) s * smol_inv_p16l_lut [a]) >> 19) & 0x7ffu];
+                else
+                    o [k] = (uint32_t) (((uint64_t) s * smol_inv_p16_lut [a]) >> 16) & 0xffu;    /* wraps: see the header */
+            }
+            else
+            {
+                const uint32_t u = (uint32_t) (((uint64_t) s * smol_inv_p8l_lut [a]) >> 10) & 0x7ffu;
+
+                if (bpp == 3)
+                    o [k] = c->quirk24 ? smol_to_srgb_lut [s & 0x7ffu] : smol_to_srgb_lut [u];
+                else if (to->unassoc)
+                    o [k] = smol_to_srgb_lut [u];
+                else
+                    o [k] = premul8 (smol_to_srgb_lut [u], a);
+            }
+        }
+        dst [to->pos [0]] = (uint8_t) o [0];
+        dst [to->pos [1]] = (uint8_t) o [1];
+        dst [to->pos [2]] = (uint8_t) o [2];
+        if (bpp == 4)
+            dst [to->pos [3]] = (uint8_t) a;
+    }
+}
+
+/* ---- horizontal filter of one unpacked row ------------------------------------------------------ */
+
+static void
+hfilter_row (const Ctx *c, const uint32_t *u, uint32_t *out)
+{
+    const SmolHipJob *j = c->job;
+    const uint32_t w_out = j->width_out, mask = c->mask;
+    uint32_t x, k;
+
+    if (j->filter_h == F_BILINEAR)
+    {
+        const uint32_t h = j->halvings_h, ns = 1u << h;
+        const uint32_t *ofs = c->h_ofs;
+        const uint16_t *f = c->h_f;
+
+        for (x = 0; x < w_out; x++, out += 4)
+        {
+            uint32_t acc [4] = { 0, 0, 0, 0 }, s;
+
+            for (s = 0; s < ns; s++, ofs++, f++)
+            {
+                const uint32_t *p = u + (size_t) *ofs * 4, *q = p + 4;
+                for (k = 0; k < 4; k++)
+                    acc [k] += lerp (p [k], q [k], *f, mask);
+            }
+            for (k = 0; k < 4; k++)
+                out [k] = (acc [k] >> h) & mask;
+        }
+    }
+    else if (j->filter_h == F_BOX)
+    {
+        for (x = 0; x < w_out; x++, out += 4)
+        {
+            const uint32_t o0 = c->h_ofs [x], o1 = c->h_last [x], wl = c->h_wl [x], fr = c->h_fr [x];
+            uint32_t acc [4] = { 0, 0, 0, 0 }, s;
+
+            for (s = o0; s <= o1; s++)
+            {
+                const uint32_t *p = u + (size_t) s * 4;
+                if (s == o0)
+                    for (k = 0; k < 4; k++) acc [k] += ((p [k] * wl) >> 8) & mask;
+                else if (s == o1)
+                    for (k = 0; k < 4; k++) acc [k] += ((p [k] * fr) >> 8) & mask;
+                else
+                    for (k = 0; k < 4; k++) acc [k] += p [k];
+            }
+            for (k = 0; k < 4; k++)
+                out [k] = box_scale (c, acc [k], j->span_mul_x);
+        }
+    }
+    else if (j->filter_h == F_ONE)
+    {
+        for (x = 0; x < w_out; x++, out += 4)
+            memcpy (out, u, 16);
+    }
+    else
+        memcpy (out, u, (size_t) w_out * 16);
+}
+
+/* ---- horizontally filtered rows on demand -------------------------------------------------------- */
+
+typedef struct
+{
+    const Ctx *c;
+    const uint8_t *src;
+    uint32_t stride;
+    uint32_t *urow;                     /* one unpacked source row                     */
+    uint32_t *hrow [3];                 /* cache of horizontally filtered rows         */
+    uint32_t tag [3];                   /* source row each slot holds (UINT32_MAX: none) */
+    uint32_t next;
+}
+RowSource;
+
+/* `keep': a row handed out a moment ago that must stay valid (NULL: none) */
+static const uint32_t *
+hrow_get (RowSource *rs, uint32_t r, const uint32_t *keep)
+{
+    uint32_t i;
+
+    for (i = 0; i < 3; i++)
+        if (rs->tag [i] == r)
+            return rs->hrow [i];
+    i = rs->next;
+    if (rs->hrow [i] == keep)
+        i = (i + 1) % 3;
+    rs->next = (i + 1) % 3;
+    unpack_row (rs->c, rs->src + (size_t) r * rs->stride, rs->c->job->width_in, rs->urow);
+    hfilter_row (rs->c, rs->urow, rs->hrow [i]);
+    rs->tag [i] = r;
+    return rs->hrow [i];
+}
+
+/* ---- the fast class: 32-bit premultiplied in and out, bilinear on both axes, 64bpp storage --------- */
+
+#ifdef SMOL_CPU_X86
+
+/* horizontal: one source row of 32-bit pixels -> w_out pixels of four 16-bit lanes (memory byte order) */
+__attribute__ ((target ("avx2")))
+static void
+fast_hrow_avx2 (const Ctx *c, const uint8_t *src, uint16_t *out)
+{
+    const SmolHipJob *j = c->job;
+    const uint32_t w_out = j->width_out, h = j->halvings_h, ns = 1u << h;
+    const uint32_t *px = (const uint32_t *) src;        /* may be unaligned: loaded through memcpy below */
+    const uint32_t *ofs = c->h_ofs;
+    const uint16_t *f = c->h_f;
+    const __m128i shift = _mm_cvtsi32_si128 ((int) h);
+    uint32_t x = 0;
+
+    /* four output pixels per iteration: 16 lanes of 16 bits */
+    for (; x + 4 <= w_out; x += 4, out += 16)
+    {
+        __m256i acc = _mm256_setzero_si256 ();
+        uint32_t s;
+
+        for (s = 0; s < ns; s++)
+        {
+            uint32_t p [4], q [4], i;
+            uint64_t fw [4];
+            __m256i vp, vq, vf, vg;
+
+            for (i = 0; i < 4; i++)
+            {
+                const uint32_t o = ofs [(x + i) * ns + s];
+                memcpy (&p [i], (const uint8_t *) px + (size_t) o * 4, 4);
+                memcpy (&q [i], (const uint8_t *) px + (size_t) o * 4 + 4, 4);
+                fw [i] = (uint64_t) f [(x + i) * ns + s] * 0x0001000100010001ull;
+            }
+            vp = _mm256_cvtepu8_epi16 (_mm_loadu_si128 ((const __m128i *) p));
+            vq = _mm256_cvtepu8_epi16 (_mm_loadu_si128 ((const __m128i *) q));
+            vf = _mm256_loadu_si256 ((const __m256i *) fw);
+            vg = _mm256_sub_epi16 (_mm256_set1_epi16 (256), vf);
+            /* (p*F + q*(256-F)) >> 8 == q + (((p-q)*F) >> 8) for 8-bit lanes: at most 255*256, fits 16 bits */
+            acc = _mm256_add_epi16 (acc, _mm256_srli_epi16 (_mm256_add_epi16 (_mm256_mullo_epi16 (vp, vf),
+                                                                              _mm256_mullo_epi16 (vq, vg)), 8));
+        }
+        _mm256_storeu_si256 ((__m256i *) out, _mm256_srl_epi16 (acc, shift));
+    }
+    for (; x < w_out; x++, out += 4)
+    {
+        uint32_t acc [4] = { 0, 0, 0, 0 }, s, k;
+        for (s = 0; s < ns; s++)
+        {
+            const uint8_t *p = src + (size_t) ofs [x * ns + s] * 4;
+            const uint32_t F = f [x * ns + s];
+            for (k = 0; k < 4; k++)
+                acc [k] += lerp (p [k], p [4 + k], F, 0xffu);
+        }
+        for (k = 0; k < 4; k++)
+            out [k] = (uint16_t) (acc [k] >> h);
+    }
+}
+
+/* vertical: acc += (top*F + bot*(256-F)) >> 8 over n 16-bit lanes */
+__attribute__ ((target ("avx2")))
+static void
+fast_vblend_avx2 (const uint16_t *top, const uint16_t *bot, uint32_t F, uint16_t *acc, int first, size_t n)
+{
+    const __m256i vf = _mm256_set1_epi16 ((short) F), vg = _mm256_set1_epi16 ((short) (256 - F));
+    size_t i = 0;
+
+    for (; i + 16 <= n; i += 16)
+    {
+        const __m256i t = _mm256_loadu_si256 ((const __m256i *) (top + i));
+        const __m256i b = _mm256_loadu_si256 ((const __m256i *) (bot + i));
+        __m256i v = _mm256_srli_epi16 (_mm256_add_epi16 (_mm256_mullo_epi16 (t, vf), _mm256_mullo_epi16 (b, vg)), 8);
+        if (!first)
+            v = _mm256_add_epi16 (v, _mm256_loadu_si256 ((const __m256i *) (acc + i)));
+        _mm256_storeu_si256 ((__m256i *) (acc + i), v);
+    }
+    for (; i < n; i++)
+    {
+        const uint16_t v = (uint16_t) ((top [i] * F + bot [i] * (256 - F)) >> 8);
+        acc [i] = first ? v : (uint16_t) (acc [i] + v);
+    }
+}
+
+__attribute__ ((target ("avx512bw")))
+static void
+fast_vblend_avx512 (const uint16_t *top, const uint16_t *bot, uint32_t F, uint16_t *acc, int first, size_t n)
+{
+    const __m512i vf = _mm512_set1_epi16 ((short) F), vg = _mm512_set1_epi16 ((short) (256 - F));
+    size_t i = 0;
+
+    for (; i + 32 <= n; i += 32)
+    {
+        const __m512i t = _mm512_loadu_si512 ((const void *) (top + i));
+        const __m512i b = _mm512_loadu_si512 ((const void *) (bot + i));
+        __m512i v = _mm512_srli_epi16 (_mm512_add_epi16 (_mm512_mullo_epi16 (t, vf), _mm512_mullo_epi16 (b, vg)), 8);
+        if (!first)
+            v = _mm512_add_epi16 (v, _mm512_loadu_si512 ((const void *) (acc + i)));
+        _mm512_storeu_si512 ((void *) (acc + i), v);
+    }
+    for (; i < n; i++)
+    {
+        const uint16_t v = (uint16_t) ((top [i] * F + bot [i] * (256 - F)) >> 8);
+        acc [i] = first ? v : (uint16_t) (acc [i] + v);
+    }
+}
+
+/* (acc >> hv) narrowed to bytes and permuted from input to output channel order */
+__attribute__ ((target ("avx2")))
+static void
+fast_pack_avx2 (const uint16_t *acc, uint32_t hv, const uint8_t perm [4], uint32_t n_px, uint8_t *dst)
+{
+    const __m128i shift = _mm_cvtsi32_si128 ((int) hv);
+    uint8_t sel [32];
+    uint32_t i, k;
+    __m256i vsel;
+
+    for (i = 0; i < 32; i++)
+        sel [i] = (uint8_t) ((i & ~3u) + perm [i & 3u]);
+    vsel = _mm256_loadu_si256 ((const __m256i *) sel);
+    for (i = 0; i + 8 <= n_px; i += 8)
+    {
+        const __m256i a = _mm256_srl_epi16 (_mm256_loadu_si256 ((const __m256i *) (acc + (size_t) i * 4)), shift);
+        const __m256i b = _mm256_srl_epi16 (_mm256_loadu_si256 ((const __m256i *) (acc + (size_t) i * 4 + 16)), shift);
+        /* packus works per 128-bit half: restore the order, then permute bytes inside each pixel */
+        __m256i p = _mm256_permute4x64_epi64 (_mm256_packus_epi16 (a, b), 0xd8);
+        p = _mm256_shuffle_epi8 (p, vsel);
+        _mm256_storeu_si256 ((__m256i *) (dst + (size_t) i * 4), p);
+    }
+    for (; i < n_px; i++)
+        for (k = 0; k < 4; k++)
+            dst [(size_t) i * 4 + k] = (uint8_t) (acc [(size_t) i * 4 + perm [k]] >> hv);
+}
+
+static int
+fast_class_ok (const Ctx *c)
+{
+    const SmolHipJob *j = c->job;
+    return !c->wide && c->ti->bpp == 4 && c->to->bpp == 4 && !c->ti->unassoc && !c->to->unassoc
+           && j->filter_h == F_BILINEAR && j->filter_v == F_BILINEAR && __builtin_cpu_supports ("avx2");
+}
+
+static int
+fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *dest, uint32_t stride_out,
+                 uint32_t first_row, uint32_t n_rows)
+{
+    const SmolHipJob *j = c->job;
+    const uint32_t w_out = j->width_out, hv = j->halvings_v, nsy = 1u << hv;
+    const size_t lanes = (size_t) w_out * 4;
+    const int use512 = __builtin_cpu_supports ("avx512bw");
+    uint16_t *hbuf [3], *acc;
+    uint32_t tag [3] = { UINT32_MAX, UINT32_MAX, UINT32_MAX }, next = 0, y, k;
+    uint8_t perm [4];
+    uint8_t *mem = malloc ((lanes * 4 + 64) * sizeof (uint16_t));
+
+    if (!mem)
+        return SMOL_HIP_E_INVALID;
+    for (k = 0; k < 3; k++)
+        hbuf [k] = (uint16_t *) mem + lanes * k;
+    acc = (uint16_t *) mem + lanes * 3;
+    /* output byte k comes from the input byte that holds the same channel */
+    for (k = 0; k < 4; k++)
+    {
+        uint32_t ch;
+        for (ch = 0; ch < 4; ch++)
+            if (c->to->pos [ch] == k)
+                perm [k] = c->ti->pos [ch];
+    }
+
+    for (y = first_row; y < first_row + n_rows; y++, dest += stride_out)
+    {
+        uint32_t s;
+        for (s = 0; s < nsy; s++)
+        {
+            const uint16_t *rows [2];
+            uint32_t oy, F, t;
+
+            bilin_tap (j->frac0_y + (uint64_t) ((y << hv) + s) * j->step_y, j->height_in, &oy, &F);
+            for (t = 0; t < 2; t++)
+            {
+                uint32_t i, r = oy + t, slot = 3;
+                for (i = 0; i < 3; i++)
+                    if (tag [i] == r)
+                        slot = i;
+                if (slot == 3)
+                {
+                    /* never evict the row fetched a moment ago for this same sample */
+                    slot = next;
+                    if (t == 1 && rows [0] == hbuf [slot])
+                        slot = (slot + 1) % 3;
+                    next = (slot + 1) % 3;
+                    fast_hrow_avx2 (c, src + (size_t) r * stride_in, hbuf [slot]);
+                    tag [slot] = r;
+                }
+                rows [t] = hbuf [slot];
+            }
+            if (use512)
+                fast_vblend_avx512 (rows [0], rows [1], F, acc, s == 0, lanes);
+            else
+                fast_vblend_avx2 (rows [0], rows [1], F, acc, s == 0, lanes);
+        }
+        fast_pack_avx2 (acc, hv, perm, w_out, dest);
+    }
+    free (mem);
+    return 0;
+}
+
+#endif /* SMOL_CPU_X86 */
+
+/* ---- tables ---------------------------------------------------------------------------------------- */
+
+static int
+build_tables (Ctx *c)
+{
+    const SmolHipJob *j = c->job;
+    uint32_t x;
+
+    if (j->filter_h == F_BILINEAR)
+    {
+        const uint32_t n = j->width_out << j->halvings_h;
+        c->h_ofs = malloc ((size_t) n * sizeof (uint32_t));
+        c->h_f = malloc ((size_t) n * sizeof (uint16_t));
+        if (!c->h_ofs || !c->h_f)
+            return SMOL_HIP_E_INVALID;
+        for (x = 0; x < n; x++)
+        {
+            uint32_t o, F;
+            bilin_tap (j->frac0_x + (uint64_t) x * j->step_x, j->width_in, &o, &F);
+            c->h_ofs [x] = o;
+            c->h_f [x] = (uint16_t) F;
+        }
+    }
+    else if (j->filter_h == F_BOX)
+    {
+        const uint32_t n = j->width_out;
+        c->h_ofs = malloc ((size_t) n * sizeof (uint32_t));
+        c->h_last = malloc ((size_t) n * sizeof (uint32_t));
+        c->h_wl = malloc ((size_t) n * sizeof (uint16_t));
+        c->h_fr = malloc ((size_t) n * sizeof (uint16_t));
+        if (!c->h_ofs || !c->h_last || !c->h_wl || !c->h_fr)
+            return SMOL_HIP_E_INVALID;
+        for (x = 0; x < n; x++)
+        {
+            uint32_t o0, o1, fr, wl;
+            box_span (j->step_x, j->width_in, x, &o0, &o1, &fr, &wl);
+            c->h_ofs [x] = o0; c->h_last [x] = o1; c->h_wl [x] = (uint16_t) wl; c->h_fr [x] = (uint16_t) fr;
+        }
+    }
+    return 0;
+}
+
+static void
+free_tables (Ctx *c)
+{
+    free (c->h_ofs); free (c->h_f); free (c->h_last); free (c->h_wl); free (c->h_fr);
+}
+
+/* ---- entry point ------------------------------------------------------------------------------------- */
+
+int
+smol_cpu_scale_rows (const SmolHipJob *job,
+                     const void *pixels_in, uint32_t rowstride_in,
+                     void *dest, uint32_t rowstride_out,
+                     uint32_t first_row, uint32_t n_rows)
+{
+    Ctx c;
+    RowSource rs;
+    uint32_t *mem, *vout, *acc;
+    uint32_t y, k, x;
+    size_t row_lanes_in, row_lanes_out;
+    int rc;
+    uint8_t *drow = dest;
+
+    if (!job || !pixels_in || !dest || job->pixel_type_in >= 10 || job->pixel_type_out >= 10)
+        return SMOL_HIP_E_INVALID;
+    if (n_rows == 0)
+        return 0;
+    if (first_row >= job->height_out || n_rows > job->height_out - first_row)
+        return SMOL_HIP_E_INVALID;
+
+    memset (&c, 0, sizeof (c));
+    c.job = job;
+    c.ti = &k_types [job->pixel_type_in];
+    c.to = &k_types [job->pixel_type_out];
+    c.wide = job->wide; c.p16 = job->premul16; c.linear = job->linear; c.quirk24 = job->quirk24;
+    c.mask = c.wide ? 0x00ffffffu : 0xffu;
+    rc = build_tables (&c);
+    if (rc)
+    {
+        free_tables (&c);
+        return rc;
+    }
+
+#ifdef SMOL_CPU_X86
+    if (fast_class_ok (&c))
+    {
+        rc = fast_scale_rows (&c, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
+        free_tables (&c);
+        return rc;
+    }
+#endif
+
+    row_lanes_in = (size_t) job->width_in * 4;
+    row_lanes_out = (size_t) job->width_out * 4;
+    mem = malloc ((row_lanes_in + row_lanes_out * 5) * sizeof (uint32_t));
+    if (!mem)
+    {
+        free_tables (&c);
+        return SMOL_HIP_E_INVALID;
+    }
+    rs.c = &c; rs.src = pixels_in; rs.stride = rowstride_in; rs.next = 0;
+    rs.urow = mem;
+    for (k = 0; k < 3; k++)
+    {
+        rs.hrow [k] = mem + row_lanes_in + row_lanes_out * k;
+        rs.tag [k] = UINT32_MAX;
+    }
+    vout = mem + row_lanes_in + row_lanes_out * 3;
+    acc = vout + row_lanes_out;
+
+    for (y = first_row; y < first_row + n_rows; y++, drow += rowstride_out)
+    {
+        const uint32_t mask = c.mask;
+
+        if (job->filter_v == F_BILINEAR)
+        {
+            const uint32_t hv = job->halvings_v, nsy = 1u << hv;
+            uint32_t s;
+
+            for (s = 0; s < nsy; s++)
+            {
+                uint32_t oy, F;
+                const uint32_t *top, *bot;
+
+                bilin_tap (job->frac0_y + (uint64_t) ((y << hv) + s) * job->step_y, job->height_in, &oy, &F);
+                top = hrow_get (&rs, oy, NULL);
+                bot = hrow_get (&rs, oy + 1, top);
+                for (x = 0; x < row_lanes_out; x++)
+                {
+                    const uint32_t v = lerp (top [x], bot [x], F, mask);
+                    acc [x] = s ? acc [x] + v : v;
+                }
+            }
+            for (x = 0; x < row_lanes_out; x++)
+                vout [x] = (acc [x] >> hv) & mask;
+        }
+        else if (job->filter_v == F_BOX)
+        {
+            uint32_t y0, y1, w2, w1, r;
+            uint32_t last_w, y_end;
+
+            box_span (job->step_y, job->height_in, y, &y0, &y1, &w2, &w1);
+            /* 128bpp-class rows weight the last row by w2 - 1 and skip it when w2 == 0
+             * (smolscale-generic.c:2236-2253); 64bpp-class rows use w2 as is (:2042-2069) */
+            last_w = c.wide ? (w2 ? w2 - 1 : 0) : w2;
+            y_end = (c.wide && w2 == 0) ? y1 - 1 : y1;
+            memset (acc, 0, row_lanes_out * sizeof (uint32_t));
+            for (r = y0; r <= y_end; r++)
+            {
+                const uint32_t *h = hrow_get (&rs, r, NULL);
+                if (r == y0)
+                    for (x = 0; x < row_lanes_out; x++) acc [x] += ((h [x] * w1) >> 8) & mask;
+                else if (r == y1)
+                    for (x = 0; x < row_lanes_out; x++) acc [x] += ((h [x] * last_w) >> 8) & mask;
+                else
+                    for (x = 0; x < row_lanes_out; x++) acc [x] += h [x];
+            }
+            for (x = 0; x < row_lanes_out; x++)
+                vout [x] = box_scale (&c, acc [x], job->span_mul_y);
+        }
+        else
+        {
+            const uint32_t *h = hrow_get (&rs, job->filter_v == F_ONE ? 0u : y, NULL);
+            memcpy (vout, h, row_lanes_out * sizeof (uint32_t));
+        }
+        pack_row (&c, vout, job->width_out, drow);
+    }
+
+    free (mem);
+    free_tables (&c);
+    return 0;
+}

@@ -10,9 +10,16 @@
  * smolscale-private.h:270-278); a GPU backend takes a whole RANGE of rows per
  * call (`batch_func'), so the row loop lives behind the seam, on the device.
  *
- * There is exactly one backend in this library, HIP. If it cannot run, the
- * library reports why on stderr and abort()s -- the reference's own reaction to
- * an unusable configuration (smolscale.c:779-780, 812-813). No CPU fallback. */
+ * Backends, preferred first: HIP (gfx950) and a from-scratch CPU implementation
+ * (smol_cpu.c). Which ones a context may use is the caller's explicit choice:
+ *   SMOL_BACKEND unset or "hip"  HIP only. If it cannot run, the library reports why on
+ *                                stderr and abort()s -- the reference's own reaction to an
+ *                                unusable configuration (smolscale.c:779-780, 812-813).
+ *                                Nothing falls back silently.
+ *   SMOL_BACKEND=cpu             the CPU backend only.
+ *   SMOL_BACKEND=auto            HIP, else the CPU backend with one line on stderr saying so
+ *                                (the reference's "first capable implementation wins",
+ *                                smolscale.c:790-810). */
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +27,7 @@
 
 #include "smolscale.h"
 #include "smol_hip.h"
+#include "smol_cpu.h"
 
 typedef struct SmolBackend SmolBackend;
 
@@ -40,6 +48,7 @@ struct SmolScaleCtx
     const SmolBackend *backend;
     SmolHipPlan *plans [SMOL_MAX_DEVICES];  /* one per device (row sharding)      */
     int n_plans;
+    SmolHipJob job;                 /* CPU backend: the planned job                */
 };
 
 /* The seam. init() plans the job and acquires backend resources; batch() must
@@ -171,8 +180,53 @@ static const SmolBackend hip_backend =
     "hip-gfx950", hip_backend_init, hip_backend_batch, hip_backend_fini
 };
 
-/* Preferred first, NULL-terminated. */
-static const SmolBackend *const backends [] = { &hip_backend, NULL };
+/* ---- CPU backend (smol_cpu.c) --------------------------------------------------- */
+
+static int
+cpu_backend_init (SmolScaleCtx *ctx)
+{
+    return smol_hip_plan_job (ctx->pixel_type_in, ctx->width_in, ctx->height_in,
+                              ctx->pixel_type_out, ctx->width_out, ctx->height_out,
+                              ctx->with_srgb, &ctx->job);
+}
+
+static int
+cpu_backend_batch (const SmolScaleCtx *ctx, void *dest, uint32_t first, uint32_t n)
+{
+    return smol_cpu_scale_rows (&ctx->job, ctx->pixels_in, ctx->rowstride_in,
+                                dest, ctx->rowstride_out, first, n);
+}
+
+static void
+cpu_backend_fini (SmolScaleCtx *ctx)
+{
+    (void) ctx;
+}
+
+static const SmolBackend cpu_backend =
+{
+    "cpu", cpu_backend_init, cpu_backend_batch, cpu_backend_fini
+};
+
+/* Preferred first, NULL-terminated: the lists SMOL_BACKEND selects from. */
+static const SmolBackend *const backends_hip [] = { &hip_backend, NULL };
+static const SmolBackend *const backends_cpu [] = { &cpu_backend, NULL };
+static const SmolBackend *const backends_auto [] = { &hip_backend, &cpu_backend, NULL };
+
+static const SmolBackend *const *
+backends_from_env (void)
+{
+    const char *e = getenv ("SMOL_BACKEND");
+
+    if (!e || !*e || !strcmp (e, "hip"))
+        return backends_hip;
+    if (!strcmp (e, "cpu"))
+        return backends_cpu;
+    if (!strcmp (e, "auto"))
+        return backends_auto;
+    fprintf (stderr, "smolscale_amd: SMOL_BACKEND=%s is not one of hip, cpu, auto\n", e);
+    abort ();
+}
 
 /* ---- dispatcher -------------------------------------------------------------- */
 
@@ -192,6 +246,7 @@ ctx_init (SmolScaleCtx *ctx,
           uint32_t width_out, uint32_t height_out, uint32_t rowstride_out,
           uint8_t with_srgb, SmolPostRowFunc post_row_func, void *user_data)
 {
+    const SmolBackend *const *backends = backends_from_env ();
     int i, rc = SMOL_HIP_E_NO_DEVICE;
 
     memset (ctx, 0, sizeof (*ctx));
@@ -215,6 +270,17 @@ ctx_init (SmolScaleCtx *ctx,
         if (rc == 0)
         {
             ctx->backend = backends [i];
+            if (i > 0)
+            {
+                /* never silent: say once per process that a later backend took over */
+                static int said;
+                if (!said)
+                {
+                    said = 1;
+                    fprintf (stderr, "smolscale_amd: backend %s is not usable here, using %s (SMOL_BACKEND=auto)\n",
+                             backends [0]->name, backends [i]->name);
+                }
+            }
             return;
         }
     }

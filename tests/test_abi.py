@@ -18,7 +18,7 @@ def declared_functions(header):
 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(sm.LIB_PATH)
-    declared = declared_functions("smolscale.h") | declared_functions("smol_hip.h")
+    declared = declared_functions("smolscale.h") | declared_functions("smol_hip.h") | declared_functions("smol_cpu.h")
     assert len(declared) >= 25
     for name in sorted(declared):
         assert hasattr(lib, name), "declared in include/ but not exported: " + name

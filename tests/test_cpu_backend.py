@@ -1,0 +1,141 @@
+"""The library's CPU backend (smolscale_amd/csrc/smol_cpu.c) against the pinned oracle
+and the reference-captured golden vectors: it is product code, so it gets the parity tests a kernel
+gets -- all 2 800 matrix goldens, the BASELINE digests, a randomized sweep over every pixel-type pair,
+filter class, odd stride and row range, strip splits, concurrency -- and the explicit-selection rules of
+smolscale_api.c (SMOL_BACKEND). Runs without a GPU. Reference: smolscale-generic.c:185-2318;
+wrap-vs-saturate of the premul16 packer: generic wraps (:290-299), AVX2 saturates (smolscale-avx2.c:1045-1047),
+this backend wraps."""
+import ctypes
+import os
+import random
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import cases as C
+import helpers as H
+import smolscale_amd as sm
+from test_oracle_vs_reference import random_case
+
+
+def cpu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb=0, stride_in=None, stride_out=None,
+              first=0, n=None, fill=0xA5):
+    stride_in = stride_in or w_in * H.bpp(t_in)
+    stride_out = stride_out or w_out * H.bpp(t_out)
+    n = h_out - first if n is None else n
+    dst = np.full(n * stride_out, fill, np.uint8)
+    job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+    rc = sm.lib().smol_cpu_scale_rows(ctypes.byref(job), src.ctypes.data, stride_in, dst.ctypes.data, stride_out, first, n)
+    assert rc == 0
+    return dst
+
+
+def test_cpu_backend_matches_every_golden_matrix_vector():
+    n = 0
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb, seed, valid), want in C.matrix_cases():
+        src = H.make_input(t_in, w_in, h_in, seed=seed, valid=valid, pad=16)
+        got = cpu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        n += 1
+    assert n == 2800
+
+
+def test_cpu_backend_baseline_digests():
+    g = C.load_golden("baseline.npz")
+    for name in ("C1", "C2", "C5", "BOX"):
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb, valid, stride_in = [int(v) for v in g[name + "_params"]]
+        src = H.make_input(t_in, w_in, h_in, seed=0, valid=bool(valid), stride=stride_in, pad=16)
+        out = cpu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, stride_in=stride_in)
+        bo = H.bpp(t_out)
+        assert H.fnv1a(out, w_out * bo, h_out, w_out * bo) == int(g[name + "_fnv"][0]), name
+
+
+def test_cpu_backend_random_sweep_vs_oracle():
+    rng = random.Random(424242)
+    for it in range(300):
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout = random_case(rng, 400_000)
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=16)
+        first = rng.randint(0, h_out - 1) if it % 3 == 0 else 0
+        n = rng.randint(1, h_out - first) if it % 3 == 0 else h_out
+        a = cpu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        b = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        rb = w_out * H.bpp(t_out)
+        assert np.array_equal(H.rows_view(a, n, rb, sout), H.rows_view(b, n, rb, sout)), \
+            (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        # bytes between rows stay untouched
+        if sout > rb and n > 1:
+            gaps = np.lib.stride_tricks.as_strided(a[rb:], (n - 1, sout - rb), (sout, 1))
+            assert np.all(gaps == 0xA5)
+
+
+def test_cpu_fast_class_every_channel_order_and_misalignment():
+    """The AVX2 / AVX-512 path (32-bit premultiplied in and out, bilinear on both axes): all 16 order pairs,
+    0-2 halvings per axis, magnification, widths that are not multiples of the vector width, byte-misaligned
+    rows."""
+    rng = random.Random(7)
+    for t_in in range(4):
+        for t_out in range(4):
+            for (w_in, h_in, w_out, h_out) in ((64, 48, 32, 24), (203, 101, 51, 26), (333, 90, 47, 13), (40, 30, 97, 71), (77, 50, 50, 49)):
+                sin = w_in * 4 + rng.choice([0, 1, 3])
+                raw = H.make_input(t_in, w_in, h_in, seed=rng.randrange(1000), valid=True, stride=sin, pad=32)
+                mis = rng.choice([0, 1, 2])
+                buf = np.zeros(raw.size + 8, np.uint8)
+                buf[mis:mis + raw.size] = raw
+                a = cpu_scale(buf[mis:], t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+                b = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+                assert np.array_equal(a, b), (t_in, t_out, w_in, h_in, w_out, h_out)
+
+
+def test_cpu_backend_strips_and_threads():
+    """smolscale.h:71-73: concurrent batches on disjoint rows of one image give the one-shot bytes."""
+    t_in, w_in, h_in, t_out, w_out, h_out = 5, 400, 300, 2, 130, 97
+    src = H.make_input(t_in, w_in, h_in, seed=3, pad=16)
+    want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1)
+    out = np.zeros(h_out * w_out * 4, np.uint8)
+    job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 1)
+
+    def strip(first, n):
+        rc = sm.lib().smol_cpu_scale_rows(ctypes.byref(job), src.ctypes.data, w_in * 4,
+                                          out[first * w_out * 4:].ctypes.data, w_out * 4, first, n)
+        assert rc == 0
+    ts = [threading.Thread(target=strip, args=(f, min(13, h_out - f))) for f in range(0, h_out, 13)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert np.array_equal(out, want)
+
+
+def _run_api(backend, expect_ok=True):
+    """smol_scale_simple() in a child process with SMOL_BACKEND set (the choice is read per context)."""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, helpers as H, smolscale_amd as sm\n"
+        "src = H.make_input(4, 97, 61, seed=1, pad=16)\n"
+        "dst = np.zeros(140 * 233 * 4, np.uint8)\n"
+        "sm.smol_scale_simple(src, 4, 97, 61, 97 * 4, dst, 1, 233, 140, 233 * 4, 0)\n"
+        "want = H.oracle_scale(src, 4, 97, 61, 1, 233, 140)\n"
+        "print('EQUAL' if np.array_equal(dst, want) else 'DIFFERENT')\n" % (H.ROOT, os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ)
+    if backend is None:
+        env.pop("SMOL_BACKEND", None)
+    else:
+        env["SMOL_BACKEND"] = backend
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_public_api_on_the_cpu_backend_when_selected():
+    run = _run_api("cpu")
+    assert run.returncode == 0 and "EQUAL" in run.stdout, run.stdout + run.stderr
+
+
+@pytest.mark.skipif(H.have_gpu(), reason="needs a machine WITHOUT a GPU")
+def test_default_backend_still_fails_loudly_without_a_gpu_and_auto_says_what_it_does():
+    run = _run_api(None)
+    assert run.returncode != 0 and "no usable HIP device" in run.stderr       # abort(), not a silent fallback
+    run = _run_api("auto")
+    assert run.returncode == 0 and "EQUAL" in run.stdout
+    assert "using cpu" in run.stderr                                          # never silent
+    run = _run_api("bogus")
+    assert run.returncode != 0 and "is not one of" in run.stderr

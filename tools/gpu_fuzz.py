@@ -1,7 +1,7 @@
 """Long randomized GPU parity run (every kernel class) against the oracle; prints mismatching cases.
     python tests/exp/gpu_fuzz.py [seed] [n_cases]"""
 import sys, random, time
-sys.path.insert(0, "tests")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 import helpers as H
 from test_oracle_vs_reference import random_case
@@ -13,7 +13,7 @@ rng = random.Random(seed)
 bad = 0; fam_count = {}
 t0 = time.time()
 for it in range(N):
-    fam = rng.choice(["any", "any", "pow2x", "up", "up", "bigw", "thin"])
+    fam = rng.choice(["any", "any", "pow2x", "up", "up", "bigw", "thin", "hspan"])
     srgb = 0
     if fam == "any":
         t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout = random_case(rng, 600_000)
@@ -22,6 +22,12 @@ for it in range(N):
         w_in, h_in = w_out << (h + 1), h_out << (h + 1)
         t_in, t_out, srgb = rng.randrange(10), rng.randrange(10), rng.randrange(2)
         sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 16, 4, 1]); sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 16, 4, 2])
+    elif fam == "hspan":
+        # k_hspan: vertical copy, horizontal bilinear at a nearly power-of-two ratio (BASELINE config 4's class)
+        h = rng.randrange(3); w_out = rng.choice([256, 257, 300, 511, 1024, 1500, 4097]); h_in = h_out = rng.randint(1, 40)
+        w_in = (w_out << (h + 1)) + rng.choice([-2, -1, -1, 0, 1, 1, 2])
+        t_in, t_out, srgb = rng.randrange(10), rng.randrange(10), 0
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 3, 16]); sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4, 16])
     elif fam == "up":
         w_in, h_in = rng.randint(2, 400), rng.randint(2, 200)
         w_out = rng.randint(w_in + 1, min(w_in * 12, 3000)); h_out = rng.randint(h_in + 1, min(h_in * 12, 700))
