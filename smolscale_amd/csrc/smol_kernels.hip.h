@@ -100,13 +100,23 @@ __device__ __forceinline__ JobDev load_job (const JobDev *jobs, uint32_t idx)
 /* unassociated -> premultiplied 8 bit: smolscale-generic.c:238-244 */
 __device__ __forceinline__ uint32_t premul8 (uint32_t c, uint32_t a)
 {
-    return (((c + 1u) * (a + 1u) - 1u) >> 8) & 0xffu;
+    return ((__umul24 (c + 1u, a + 1u) - 1u) >> 8) & 0xffu;
 }
 
 /* linear 11 bit x alpha: smolscale-generic.c:261-269 */
 __device__ __forceinline__ uint32_t premul8l (uint32_t l, uint32_t a)
 {
-    return (((l + 1u) * ((a << 3) + 1u) - 1u) >> 11) & 0x7ffu;
+    return ((__umul24 (l + 1u, (a << 3) + 1u) - 1u) >> 11) & 0x7ffu;
+}
+
+/* (value * inverse) >> shift & mask for the un-premultiply tables. The reference computes the product
+ * in 64 bits; only bits below 32 of it are ever kept (shift + mask width <= 30), every lane value of
+ * either storage class is below 2^24 and every table entry below 2^21 -- so the low 32 bits of a
+ * 24 x 24-bit product (one full-rate v_mul_u32_u24 instead of a v_mul_lo / v_mul_hi pair) are exact.
+ * Table maxima pinned by tests/test_golden.py. */
+__device__ __forceinline__ uint32_t inv_mul (uint32_t v, uint32_t inv)
+{
+    return __umul24 (v, inv);
 }
 
 /* Where the six parity tables are read from. LutConst: the __constant__ copies
@@ -124,7 +134,7 @@ struct LutConst
     /* opaque pixel (alpha = 255), sRGB byte -> premultiplied linear: the chain of unpack_word */
     __device__ __forceinline__ uint32_t opaque_lin (uint32_t v) const
     {
-        const uint32_t u = (uint32_t) ((((uint64_t) v * smol_inv_p8_lut [255]) >> 13) & 0xffu);
+        const uint32_t u = (__umul24 (v, smol_inv_p8_lut [255]) >> 13) & 0xffu;
         return premul8l (smol_from_srgb_lut [u], 255u);
     }
 };
@@ -183,7 +193,7 @@ __device__ __forceinline__ void lut_fill_lds (uint8_t *base, uint32_t tid, uint3
 template <typename L>
 __device__ __forceinline__ uint32_t unpremul8 (uint32_t c, uint32_t a, const L &lut)
 {
-    return (uint32_t) ((((uint64_t) c * lut.inv_p8 (a)) >> 13) & 0xffu);
+    return (inv_mul (c, lut.inv_p8 (a)) >> 13) & 0xffu;
 }
 
 __device__ __forceinline__ uint32_t unpremul8 (uint32_t c, uint32_t a)
@@ -234,7 +244,7 @@ __device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32
             uint32_t v = c [i];
             if (J.linear)
                 v = lut.from_srgb (v);
-            c [i] = v * a;
+            c [i] = __umul24 (v, a);
         }
         c [3] = (a << 8) | 0x80u;
         return;
@@ -337,9 +347,9 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
         else if (J.p16)
         {
             if (J.linear)
-                c [i] = lut.to_srgb ((uint32_t) (((uint64_t) s * lut.inv_p16l (a)) >> 19) & 0x7ffu);
+                c [i] = lut.to_srgb ((inv_mul (s, lut.inv_p16l (a)) >> 19) & 0x7ffu);
             else
-                c [i] = (uint32_t) (((uint64_t) s * lut.inv_p16 (a)) >> 16) & 0xffu;
+                c [i] = (inv_mul (s, lut.inv_p16 (a)) >> 16) & 0xffu;
         }
         else if (!J.linear)
         {
@@ -354,7 +364,7 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
         }
         else
         {
-            uint32_t u = (uint32_t) (((uint64_t) s * lut.inv_p8l (a)) >> 10) & 0x7ffu;
+            uint32_t u = (inv_mul (s, lut.inv_p8l (a)) >> 10) & 0x7ffu;
 
             if (J.bpp_out == 3)
                 c [i] = J.quirk24 ? lut.to_srgb (s & 0x7ffu) : lut.to_srgb (u);

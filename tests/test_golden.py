@@ -89,3 +89,21 @@ def test_opaque_fast_path_constants():
     inv255 = int(luts["inv_p8"][255])
     assert all(((v * inv255) >> 13) & 0xff == v for v in range(256))
     assert all(((((x + 1) * 256) - 1) >> 8) & 0xff == x for x in range(256))      # premul8(x, 255) == x
+
+
+def test_inverse_tables_fit_24_bit_multiplies():
+    """smol_kernels.hip.h inv_mul(): (value * inverse) is formed with one 24 x 24-bit multiply whose low 32 bits
+    are kept; exact because every table entry is below 2^24 (in fact 2^21) and no shift + mask reaches bit 32."""
+    import os
+    luts = np.load(os.path.join(os.path.dirname(__file__), "golden", "luts.npz"))
+    for name, shift, width in (("inv_p8", 13, 8), ("inv_p8l", 10, 11), ("inv_p16", 16, 8), ("inv_p16l", 19, 11)):
+        assert int(luts[name].max()) < (1 << 24), name
+        assert shift + width <= 32
+    # spot-check the identity on the extremes of every table, for lane values up to 2^24 - 1
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([rng.integers(0, 1 << 24, 4096, dtype=np.uint64), np.array([0, 1, 255, 2047, (1 << 24) - 1], np.uint64)])
+    for name, shift, width in (("inv_p8", 13, 8), ("inv_p8l", 10, 11), ("inv_p16", 16, 8), ("inv_p16l", 19, 11)):
+        for inv in np.unique(luts[name]).astype(np.uint64)[[0, 1, -2, -1]]:
+            full = (vals * inv) >> np.uint64(shift) & np.uint64((1 << width) - 1)
+            low32 = ((vals * inv) & np.uint64(0xFFFFFFFF)) >> np.uint64(shift) & np.uint64((1 << width) - 1)
+            assert np.array_equal(full, low32), name

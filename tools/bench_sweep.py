@@ -9,10 +9,16 @@ can be laid beside smolscale's own `results/resize-*-{samples,average}.txt`:
 
 Tests: reps-w-h-scale_min-scale_max-steps = 5-1920-1080-0.01-2-200, 5-3840-2160-0.01-2-200,
 5-7680-4320-0.01-1-200; ARGB8 premultiplied in and out, no sRGB (test.c:20, 785-807).
-Two rows per test:
-    smol-hip       host pointers through smol_scale_new + smol_scale_batch
-                   (PCIe-inclusive, like the reference's in-memory `smol' row)
-    smol-hip-dev   device-resident input/output, kernel time only (hipEvents)
+Rows per test:
+    smol-hip        host pointers through smol_scale_simple (PCIe-inclusive, like the reference's
+                    in-memory `smol' row)
+    smol-hip-dev    device-resident input/output, one kernel per image, F DISTINCT source frames rotated
+                    (F x frame bytes >= 600 MB, F >= 4: more than twice the 256 MB Infinity Cache, so the
+                    row is an HBM number), hipEvents around the F kernels, time per image
+    smol-hip-batch  the same F frames as ONE descriptor-table launch, time per image
+    smol, smol-mt   the reference itself (oracle/_ref, AVX2 build; one thread / every host thread with the
+                    strip pattern of test.c:838-883) -- only through tests/bench_sweep_with_reference.py:
+                    tools/ never loads anything from oracle/
 
     python tools/bench_sweep.py [--out results] [--tests 5-1920-1080-0.01-2-200,...] [--steps N]
 """
@@ -51,12 +57,13 @@ def write_results(out_dir, test, name, samples):
     return sum(pps) / len(pps)
 
 
-def main():
+def main(argv=None, reference_rows=None):
+    """reference_rows (optional): callable (src, w_in, h_in, sizes, reps) -> {row name: samples}"""
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "results"))
     ap.add_argument("--tests", default=DEFAULT_TESTS)
     ap.add_argument("--steps", type=int, default=0, help="override the number of steps (quick runs)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     os.makedirs(args.out, exist_ok=True)
     rng = np.random.default_rng(7)
 
@@ -66,11 +73,17 @@ def main():
         smin, smax = float(smin), float(smax)
         if args.steps:
             n = args.steps
-        src = rng.integers(0, 256, w_in * h_in * 4, dtype=np.uint8)
-        dsrc = sm.DeviceBuffer(src.size + 64)
-        dsrc.upload(src)
-        host, dev = [], []
-        for (w_out, h_out) in steps_of(w_in, h_in, smin, smax, n):
+        frame_bytes = w_in * h_in * 4
+        n_frames = max(4, min(64, -(-600_000_000 // frame_bytes)))
+        src = rng.integers(0, 256, frame_bytes, dtype=np.uint8)
+        dsrcs = []
+        for f in range(n_frames):
+            d = sm.DeviceBuffer(frame_bytes + 64)
+            d.upload(np.roll(src, 4 * f))                    # distinct contents, distinct addresses
+            dsrcs.append(d)
+        sizes = list(steps_of(w_in, h_in, smin, smax, n))
+        host, dev, bat = [], [], []
+        for (w_out, h_out) in sizes:
             dst = np.empty(w_out * h_out * 4, np.uint8)
             # host-pointer row: fastest of `reps' (benchmark_postprocess, test.c:319-340)
             best = 1e9
@@ -79,22 +92,36 @@ def main():
                 sm.smol_scale_simple(src, ARGB_P, w_in, h_in, w_in * 4, dst, ARGB_P, w_out, h_out, w_out * 4, 0)
                 best = min(best, time.perf_counter() - t0)
             host.append((w_out, h_out, best, (w_in * h_in + w_out * h_out) / best))
-            # device-resident row
-            ddst = sm.DeviceBuffer(dst.size + 64)
-            im = sm.SmolHipImage()
-            im.job = sm.plan_job(ARGB_P, w_in, h_in, ARGB_P, w_out, h_out, 0)
-            im.src, im.dst = dsrc.ptr, ddst.ptr
-            im.rowstride_in, im.rowstride_out = w_in * 4, w_out * 4
-            im.first_row, im.n_rows = 0, h_out
-            batch = sm.HipBatch([im])
-            t = min(batch.time(1, reps) / reps for _ in range(2)) * 1e-3
+            # device-resident rows: F frames, each with its own output
+            out_slot = (dst.size + 64 + 255) // 256 * 256
+            ddst = sm.DeviceBuffer(out_slot * n_frames)
+            job = sm.plan_job(ARGB_P, w_in, h_in, ARGB_P, w_out, h_out, 0)
+            images = []
+            for f in range(n_frames):
+                im = sm.SmolHipImage()
+                im.job = job
+                im.src, im.dst = dsrcs[f].ptr, ddst.ptr + f * out_slot
+                im.rowstride_in, im.rowstride_out = w_in * 4, w_out * 4
+                im.first_row, im.n_rows = 0, h_out
+                images.append(im)
+            batch = sm.HipBatch(images)
+            t = min(batch.time(1, 2) / 2 for _ in range(2)) * 1e-3 / n_frames
+            bat.append((w_out, h_out, t, (w_in * h_in + w_out * h_out) / t))
+            batch.use_graph(True)                           # one kernel node per image
+            t = min(batch.time(1, 2) / 2 for _ in range(2)) * 1e-3 / n_frames
             dev.append((w_out, h_out, t, (w_in * h_in + w_out * h_out) / t))
             batch.destroy()
             ddst.free()
-        dsrc.free()
-        a = write_results(args.out, test, "smol-hip (host pointers, PCIe inclusive)", host)
-        b = write_results(args.out, test, "smol-hip-dev (device resident)", dev)
-        print("%s: mean pps host-path %.3e, device-resident %.3e" % (test, a, b), flush=True)
+        for d in dsrcs:
+            d.free()
+        means = {}
+        if reference_rows is not None:
+            for name, samples in reference_rows(src, w_in, h_in, sizes, reps).items():
+                means[name] = write_results(args.out, test, name, samples)
+        means["smol-hip"] = write_results(args.out, test, "smol-hip (host pointers, PCIe inclusive)", host)
+        means["smol-hip-dev"] = write_results(args.out, test, "smol-hip-dev (device resident, %d frames rotated, one kernel per image)" % n_frames, dev)
+        means["smol-hip-batch"] = write_results(args.out, test, "smol-hip-batch (device resident, %d frames in one launch)" % n_frames, bat)
+        print("%s: mean pps " % test + ", ".join("%s %.3e" % kv for kv in means.items()), flush=True)
 
 
 if __name__ == "__main__":
