@@ -13,7 +13,7 @@
 namespace smolhip {
 
 /* Tuning / ablation knobs (SMOL_TILE_ROWS, SMOL_NO_UP, SMOL_TILE_DBG ...) exist only in
- * builds made with -DSMOL_TUNING (make EXTRA=-DSMOL_TUNING, used by tests/exp and tools/
+ * builds made with -DSMOL_TUNING (make EXTRA=-DSMOL_TUNING, used by tools/
  * sweeps). The shipped library never looks at the environment on the dispatch path, so a
  * stray variable cannot change which kernel runs or what it computes. */
 #ifdef SMOL_TUNING
@@ -632,7 +632,7 @@ box2_h_lds_bytes (const JobDev &d)
  * input needs at least one halving (a lane's window must be a multiple of 16 bytes). */
 /* rows a workgroup walks. ONE: workgroups then sweep the image in raster order, which is what HBM
  * wants -- config 4 takes 150 us with 1 row per workgroup, 175 with 2, 188 with 4, 197 with 8, 292
- * with 64 (tests/exp/hspan_ab.hip, profiles/r02c_hspan_ab.txt); the per-row set-up is 3 % */
+ * with 64 (tools/microbench/hspan_ab.hip, profiles/r02c_hspan_ab.txt); the per-row set-up is 3 % */
 constexpr uint32_t HSPAN_BAND_ROWS = 1;
 
 inline bool

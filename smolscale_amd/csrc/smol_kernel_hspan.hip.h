@@ -6,7 +6,7 @@
  * horizontal filter :1290-1322, 1363-1387, 1420-1425, pack :758-906; rows are independent (:2262-2290).
  *
  * Why not k_tile: with a vertical copy there is no vertical state, so 2-D tiles only chop the rows
- * into short segments. Measured floor of the access patterns on config 4 (tests/exp/spanbw.hip,
+ * into short segments. Measured floor of the access patterns on config 4 (tools/microbench/spanbw.hip,
  * stagebw.hip, gatherbw.hip; profiles/r02c_*): 64-column x 16-row tiles with a row pipeline 166-196 us,
  * per-lane gathers straight from global memory 200-270 us, ROW SPANS 156-160 us -- against 143 us for
  * a plain copy of the same bytes.
@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t hspan_g2 (uint32_t gw)
 /* One row of a REGULAR wave: this lane's window starts `sh' + 4 * K bytes into the frames at
  * `fr' (K compile-time: the caller switches on it once per row, wave-uniformly). Column by
  * column, so that only one column's pixels are unpacked at a time. */
-/* VAR: experiment bits (tests/exp/hspan_ab.hip): 1 = no prefetch of the next row, 2 = read all
+/* VAR: experiment bits (tools/microbench/hspan_ab.hip): 1 = no prefetch of the next row, 2 = read all
  * frames up front, 4 = no scheduling barrier between columns. The library instantiates HSPAN_VAR. */
 constexpr int HSPAN_VAR = 0;
 

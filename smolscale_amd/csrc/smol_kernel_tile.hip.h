@@ -252,7 +252,7 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
     if (OUT != OUT_ANY)
     {
         /* NT: the wave's 64 dwords are contiguous (one column per lane) and never read back:
-         * non-temporal (C4 189 -> 184 us; the copy-only skeleton of tests/exp/stagebw.hip shows
+         * non-temporal (C4 189 -> 184 us; the copy-only skeleton of tools/microbench/stagebw.hip shows
          * the same 183 -> 175 us). Strided dword stores (edge tiles of the 4-columns-per-lane
          * variants) must NOT be: partial lines written around the L2 cost ratio 1.5 127 -> 211 us. */
         if (NT)
@@ -514,7 +514,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     /* Workgroups go round-robin over the 8 XCDs, each with its own L2: give every XCD a
      * contiguous band of this job's tiles, so that horizontally adjacent tiles (which share the
      * cache lines at their segment boundaries) meet in one L2 (the copy-only skeleton of
-     * tests/exp/patternbw.hip gains 1-4 % from it; HBM traffic 1.07x -> ~1.0x) */
+     * tools/microbench/patternbw.hip gains 1-4 % from it; HBM traffic 1.07x -> ~1.0x) */
     const uint32_t n_tiles8 = (tiles_x * ((J.n_rows + J.tile_rows - 1) / J.tile_rows) + 7u) & ~7u;
     if (blockIdx.x >= n_tiles8)
         return;

@@ -805,7 +805,7 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
     using C = Pow2Cfg<HX, HY>;
 
     /* Workgroup = 64 thread-columns x 16 output rows, one wave per output row:
-     * measured best of the layouts tried (tests/exp/pow2_variants.hip, 83.9 % of
+     * measured best of the layouts tried (tools/microbench/pow2_variants.hip, 83.9 % of
      * 8 TB/s against 79.5 % for 256 x 1), with non-temporal loads AND stores. */
     /* grid = (column tiles, row tiles, jobs): no division at the head of a workgroup */
     const uint32_t tcols = J.w_out / C::OPT;

@@ -1,5 +1,5 @@
 """Long randomized GPU parity run (every kernel class) against the oracle; prints mismatching cases.
-    python tests/exp/gpu_fuzz.py [seed] [n_cases]"""
+    python tools/fuzz/gpu_fuzz.py [seed] [n_cases]"""
 import sys, random, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np

@@ -1,7 +1,7 @@
 // hspan_ab.hip -- A/B of k_hspan code variants on BASELINE config 4 in ONE process (interleaved rounds,
 // cdna_hip_programming.md rule 24), with the product's own headers: the JobDev is filled by the same
 // host code the library uses. Build (from the repo root):
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Ismolscale_amd/csrc tests/exp/hspan_ab.hip smolscale_amd/csrc/smol_plan.c -x hip -o tests/exp/hspan_ab
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Ismolscale_amd/csrc tools/microbench/hspan_ab.hip smolscale_amd/csrc/smol_plan.c -x hip -o tests/exp/hspan_ab
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>

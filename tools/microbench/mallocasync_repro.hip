@@ -1,6 +1,6 @@
 // mallocasync_repro.hip -- does stream-ordered allocation hand a kernel stale data on this ROCm build?
 // Round 1 saw 1048 of 4000 two-pass box jobs wrong when the intermediate image came from
-// hipMallocAsync/hipFreeAsync (tests/exp/fuzz_box2_gpu.py) and none with hipMalloc. This isolates the
+// hipMallocAsync/hipFreeAsync (tools/fuzz/fuzz_box2_gpu.py) and none with hipMalloc. This isolates the
 // pattern: producer kernel fills a scratch buffer, consumer kernel checks it, the scratch buffer comes
 // from (a) hipMallocAsync on the same stream, freed with hipFreeAsync right after the consumer,
 // (b) the same on one of four streams in rotation (the library's staging lanes), (c) hipMalloc once.
