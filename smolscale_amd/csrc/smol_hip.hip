@@ -88,8 +88,8 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         const uint32_t tw = 64u * rep.tile_cpl / rep.tile_lpc;
         const uint32_t tiles_x = (max_w_out + tw - 1) / tw;
         const uint32_t tiles_y = (max_rows + rep.tile_rows - 1) / rep.tile_rows;
-        /* k_tile deals its tiles out in XCD bands: the count is rounded up to a multiple of 8 */
-        const dim3 grid (k == KC_TILE ? ((tiles_x * tiles_y + 7u) & ~7u) : tiles_x * tiles_y, n_jobs);
+        /* k_tile: (column tiles, row tiles, jobs); k_wtile: (tiles, jobs) */
+        const dim3 grid = (k == KC_TILE) ? dim3 (tiles_x, tiles_y, n_jobs) : dim3 (tiles_x * tiles_y, n_jobs);
         const uint32_t lds = max_lds ? max_lds : tile_lds_bytes (rep);
 
         if (k == KC_WTILE)
@@ -228,6 +228,16 @@ lane_release (Lane &ln)
 }
 
 void
+lane_drain (Lane &ln)
+{
+    if (!ln.ready)
+        return;
+    (void) hipStreamSynchronize (ln.s_in);
+    (void) hipStreamSynchronize (ln.s_k);
+    (void) hipStreamSynchronize (ln.s_out);
+}
+
+void
 device_release_lanes (int device)
 {
     if (hipSetDevice (device) != hipSuccess)
@@ -239,14 +249,26 @@ device_release_lanes (int device)
     }
 }
 
+/* When the last plan on a device goes: give back the slabs that are big (a 65535 x 4096 RGB strip
+ * pins 0.8 GB), keep streams, events and ordinary-sized slabs -- one-shot callers (smol_scale_simple()
+ * creates and destroys a plan per call) would otherwise pay stream + event + hipMalloc set-up on
+ * every image (measured: 5 ms per 1080p call against 0.4 ms). */
+constexpr size_t LANE_KEEP_BYTES = 64u << 20;
+
 void
-lane_drain (Lane &ln)
+device_trim_lanes (int device)
 {
-    if (!ln.ready)
+    if (hipSetDevice (device) != hipSuccess)
         return;
-    (void) hipStreamSynchronize (ln.s_in);
-    (void) hipStreamSynchronize (ln.s_k);
-    (void) hipStreamSynchronize (ln.s_out);
+    for (Lane &ln : g_devices [device].lanes)
+    {
+        std::lock_guard<std::mutex> guard (ln.mtx);
+        if (ln.src_cap > LANE_KEEP_BYTES || ln.dst_cap > LANE_KEEP_BYTES || ln.tmp_cap > LANE_KEEP_BYTES)
+            lane_drain (ln);
+        if (ln.src_cap > LANE_KEEP_BYTES) { (void) hipFree (ln.src_buf); ln.src_buf = nullptr; ln.src_cap = 0; }
+        if (ln.dst_cap > LANE_KEEP_BYTES) { (void) hipFree (ln.dst_buf); ln.dst_buf = nullptr; ln.dst_cap = 0; }
+        if (ln.tmp_cap > LANE_KEEP_BYTES) { (void) hipFree (ln.tmp_buf); ln.tmp_buf = nullptr; ln.tmp_cap = 0; }
+    }
 }
 
 bool
@@ -754,14 +776,14 @@ smol_hip_plan_destroy (SmolHipPlan *plan)
         (void) hipFree (plan->box_scratch);
     delete plan;
 
-    /* the last plan on a device takes the staging lanes with it */
+    /* the last plan on a device gives the big staging slabs back (everything goes in smol_hip_shutdown()) */
     bool last;
     {
         std::lock_guard<std::mutex> g (g_devices [device].ref_mtx);
         last = --g_devices [device].plans == 0;
     }
     if (last)
-        device_release_lanes (device);
+        device_trim_lanes (device);
 }
 
 int

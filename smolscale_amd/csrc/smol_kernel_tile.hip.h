@@ -510,19 +510,13 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     constexpr bool DMA = !STAGE_PREMUL;
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
-    /* Workgroups go round-robin over the 8 XCDs, each with its own L2: give every XCD a
-     * contiguous band of this job's tiles, so that horizontally adjacent tiles (which share the
-     * cache lines at their segment boundaries) meet in one L2 (the copy-only skeleton of
-     * tools/microbench/patternbw.hip gains 1-4 % from it; HBM traffic 1.07x -> ~1.0x) */
-    const uint32_t n_tiles8 = (tiles_x * ((J.n_rows + J.tile_rows - 1) / J.tile_rows) + 7u) & ~7u;
-    if (blockIdx.x >= n_tiles8)
+    /* grid = (column tiles, row tiles, jobs): raster order over the tiles, no integer division at the
+     * head of a workgroup (the XCD-band remap that used to live here served BASELINE config 4, which
+     * k_hspan takes now) */
+    const uint32_t tx = blockIdx.x;
+    const uint32_t ty = blockIdx.y;
+    if (tx * TW >= J.w_out)
         return;
-    /* only for very wide images (tile_band: 64 tiles or more per row, host: tile_setup): narrower
-     * ones lose (ratio 1.5 with 11 tiles per row: 133 -> 238 us) */
-    const uint32_t bid = J.tile_band ? (blockIdx.x & 7u) * (n_tiles8 >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const uint32_t tx = bid % tiles_x;
-    const uint32_t ty = bid / tiles_x;
     const uint32_t yrel0 = ty * J.tile_rows;
 
     if (yrel0 >= J.n_rows)
@@ -965,7 +959,7 @@ k_tile_batch (const JobDev *__restrict__ jobs)
 {
     /* private copy: the descriptor must not be re-read from memory after every
      * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
-    const JobDev J = load_job (jobs, blockIdx.y);
+    const JobDev J = load_job (jobs, blockIdx.z);
     tile_entry<TS, HM, CPL, VCOPY> (J, smol_dyn_lds);
 }
 

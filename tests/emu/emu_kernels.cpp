@@ -14,19 +14,20 @@ uint32_t emu_lane_xchg [64];
 
 /* cooperative kernels: the 64 lanes of a block run as real threads, blocks in turn */
 template <typename F>
-static void run_grid_coop (unsigned gx, unsigned bx, size_t lds_bytes, F body)
+static void run_grid_coop (unsigned gx, unsigned bx, size_t lds_bytes, F body, unsigned gy = 1)
 {
     std::vector<uint8_t> lds (lds_bytes + 64, 0xcd);
     emu_dyn_lds_ptr = (uint8_t *) (((uintptr_t) lds.data () + 15) & ~(uintptr_t) 15);
     pthread_barrier_init (&emu_block_barrier, nullptr, bx);
+    for (unsigned g2 = 0; g2 < gy; g2++)
     for (unsigned b = 0; b < gx; b++)
     {
         std::vector<std::thread> lanes;
         for (unsigned t = 0; t < bx; t++)
             lanes.emplace_back ([=] {
-                gridDim = { gx, 1, 1 };
+                gridDim = { gx, gy, 1 };
                 blockDim = { bx, 1, 1 };
-                blockIdx = { b, 0, 0 };
+                blockIdx = { b, g2, 0 };
                 threadIdx = { t, 0, 0 };
                 body ();
             });
@@ -194,7 +195,7 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
         const uint32_t tw = TILE_COLS * J.tile_cpl / J.tile_lpc;
         const uint32_t tiles_x = (J.w_out + tw - 1) / tw;
         const uint32_t tiles_y = (n_rows + J.tile_rows - 1) / J.tile_rows;
-        run_grid_coop ((tiles_x * tiles_y + 7u) & ~7u, 64, tile_lds_bytes (J), [&] { k_tile_one (J); });
+        run_grid_coop (tiles_x, 64, tile_lds_bytes (J), [&] { k_tile_one (J); }, tiles_y);
         return 0;
     }
 

@@ -1,5 +1,5 @@
 import sys, random
-sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, "tests")
 import numpy as np
 import helpers as H
 KC_HSPAN = 11
