@@ -303,11 +303,10 @@ __device__ __forceinline__ void pow2x_body (const JobDev &J)
         {
             gbyte *dp = drow + (size_t) tc * (C::OPT * 4);
             if (C::OPT == 1)
-                __builtin_nontemporal_store (outw [0], reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (dp));
+                store_out32 (reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (dp), outw [0]);
             else if (C::OPT == 2)
             {
-                const u32x2 v2 = { outw [0], outw [C::OPT - 1] };
-                __builtin_nontemporal_store (v2, reinterpret_cast<SMOL_AS_GLOBAL u32x2 *> (dp));
+                store_out64 (reinterpret_cast<SMOL_AS_GLOBAL uint64_t *> (dp), outw [0], outw [C::OPT - 1]);
             }
             else
             {
@@ -316,7 +315,7 @@ __device__ __forceinline__ void pow2x_body (const JobDev &J)
                 {
                     const u32x4 v4 = { outw [(g * 4 + 0) % C::OPT], outw [(g * 4 + 1) % C::OPT],
                                        outw [(g * 4 + 2) % C::OPT], outw [(g * 4 + 3) % C::OPT] };
-                    __builtin_nontemporal_store (v4, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (dp) + g);
+                    store_out128 (reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (dp) + g, v4);
                 }
             }
         }

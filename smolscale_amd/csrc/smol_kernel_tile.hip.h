@@ -256,7 +256,7 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
          * the same 183 -> 175 us). Strided dword stores (edge tiles of the 4-columns-per-lane
          * variants) must NOT be: partial lines written around the L2 cost ratio 1.5 127 -> 211 us. */
         if (NT)
-            __builtin_nontemporal_store (w, reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4));
+            store_out32 (reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4), w);
         else
             *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4) = w;
     }
@@ -351,7 +351,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c]);
             u32x4 v = { w [0], w [1], w [2], w [3] };
-            __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (rowp) + (size_t) xl * 4));
+            store_out128 (reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (rowp) + (size_t) xl * 4), v);
             return;
         }
     }

@@ -233,6 +233,8 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
             {
                 const u32x4 v = { __builtin_amdgcn_perm (hi [0], lo [0], J.up_perm), __builtin_amdgcn_perm (hi [1], lo [1], J.up_perm),
                                   __builtin_amdgcn_perm (hi [2], lo [2], J.up_perm), __builtin_amdgcn_perm (hi [3], lo [3], J.up_perm) };
+                /* non-temporal, not write-through: this kernel is bound by its stores, and write-through 16-byte
+                 * stores run config 3 at 114 us against 88-93 us (profiles/r02m_store_policy.txt) */
                 __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (out_row) + (size_t) xl * 4));
             }
             else

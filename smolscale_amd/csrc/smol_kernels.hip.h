@@ -93,6 +93,36 @@ __device__ __forceinline__ JobDev load_job (const JobDev *jobs, uint32_t idx)
     return J;
 }
 
+/* Output stores. Output pixels are written once and never read back by the kernel, so they should not
+ * occupy the XCD's L2 on their way out: WRITE-THROUGH stores (the sc1 bit; what an agent-scope relaxed
+ * atomic store compiles to) leave the line out of L2 (MI355X_MICROARCH.md, stores of each flavour) and
+ * the input stream flows better -- the headline kernel at 32 frames: sc1 336 us, plain 346, non-temporal
+ * 351 (tools/microbench/pow2_variants.hip, profiles/r02m_store_policy.txt). 4- and 8-byte forms are
+ * compiler builtins; the 16-byte form has none and is one asm instruction (ending in s_nop 1: the
+ * data registers of a >64-bit store must not be overwritten in the next wait state, cdna_hip_programming.md
+ * 5.7; an uncounted store only ever makes the compiler's vmcnt waits stricter). */
+__device__ __forceinline__ void store_out32 (SMOL_AS_GLOBAL uint32_t *p, uint32_t v)
+{
+#if defined (SMOL_KERNEL_EMU)
+    *p = v;
+#elif defined (SMOL_STORES_NT)
+    __builtin_nontemporal_store (v, p);
+#else
+    __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+__device__ __forceinline__ void store_out64 (SMOL_AS_GLOBAL uint64_t *p, uint32_t lo, uint32_t hi)
+{
+#if defined (SMOL_KERNEL_EMU)
+    *p = (uint64_t) lo | ((uint64_t) hi << 32);
+#elif defined (SMOL_STORES_NT)
+    __builtin_nontemporal_store ((uint64_t) lo | ((uint64_t) hi << 32), p);
+#else
+    __hip_atomic_store (p, (uint64_t) lo | ((uint64_t) hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 /* ------------------------------------------------------------------------- *
  * Per-channel arithmetic                                                    *
  * ------------------------------------------------------------------------- */
@@ -799,6 +829,18 @@ struct Pow2Cfg
 typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
 
+/* 16-byte write-through output store (see store_out32) */
+__device__ __forceinline__ void store_out128 (SMOL_AS_GLOBAL u32x4 *p, u32x4 v)
+{
+#if defined (SMOL_KERNEL_EMU)
+    *p = v;
+#elif defined (SMOL_STORES_NT)
+    __builtin_nontemporal_store (v, p);
+#else
+    asm volatile ("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v" (p), "v" (v) : "memory");
+#endif
+}
+
 template <int HX, int HY>
 __device__ __forceinline__ void pow2_body (const JobDev &J)
 {
@@ -856,14 +898,9 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
 
     gbyte *dp = gptr (J.dst) + (size_t) row * J.dst_stride + (size_t) tc * (C::OPT * 4);
     if (C::OPT == 1)
-    {
-        __builtin_nontemporal_store (outv [0], reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (dp));
-    }
+        store_out32 (reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (dp), outv [0]);
     else
-    {
-        const u32x2 v2 = { outv [0], outv [C::OPT - 1] };
-        __builtin_nontemporal_store (v2, reinterpret_cast<SMOL_AS_GLOBAL u32x2 *> (dp));
-    }
+        store_out64 (reinterpret_cast<SMOL_AS_GLOBAL uint64_t *> (dp), outv [0], outv [C::OPT - 1]);
 }
 
 template <int HX, int HY>

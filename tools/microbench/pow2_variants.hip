@@ -15,6 +15,27 @@ constexpr int W_IN = 4096, H_IN = 4096, W_OUT = 1024, H_OUT = 1024, NF = 8;
 
 template <bool NT> __device__ __forceinline__ u32x4 ld(const u32x4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <bool NT> __device__ __forceinline__ void st(uint32_t* p, uint32_t v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int POL> __device__ __forceinline__ void stp(uint32_t* p, uint32_t v)
+{
+    if (POL == 1) __builtin_nontemporal_store(v, p);
+    else if (POL == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (POL == 3) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+}
+template <int RB, int POL>
+__global__ void __launch_bounds__(64 * RB) k_wrowp(const uint8_t* src, uint8_t* dst)
+{
+    const uint32_t tiles_x = W_OUT / 64;
+    const uint32_t f = blockIdx.y;
+    const uint32_t row = (blockIdx.x / tiles_x) * RB + threadIdx.y;
+    const uint32_t tc = (blockIdx.x % tiles_x) * 64 + threadIdx.x;
+    const uint8_t* s = src + (size_t)f * W_IN * H_IN * 4 + (size_t)row * 4 * (W_IN * 4) + (size_t)tc * 16;
+    u32x4 raw[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) raw[r] = ld<true>((const u32x4*)(s + (size_t)r * (W_IN * 4)));
+    uint32_t* d = (uint32_t*)(dst + (size_t)f * W_OUT * H_OUT * 4 + (size_t)row * (W_OUT * 4)) + tc;
+    stp<POL>(d, avg4(avg4(red4(raw[0]), red4(raw[1])), avg4(red4(raw[2]), red4(raw[3]))));
+}
 
 // V0: thread = 1 output px, RPT output rows per thread; block BLOCK threads along x
 template <int RPT, bool NTL, bool NTS, int BLOCK>
@@ -134,6 +155,8 @@ int main()
         {"wrow 64x4 ntS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<4,true>), dim3(W_OUT/64*H_OUT/4, NF), dim3(64,4), 0, s, a, b); }},
         {"wrow 64x8 ntS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<8,true>), dim3(W_OUT/64*H_OUT/8, NF), dim3(64,8), 0, s, a, b); }},
         {"wrow 64x16 ntS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<16,true>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowp 64x16 sc1 (agent) S", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowp<16,2>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowp 64x16 sc0sc1 (system) S", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowp<16,3>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
         {"wrow 64x16 plainS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<16,false>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
         {"wrow 64x8 plainS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<8,false>), dim3(W_OUT/64*H_OUT/8, NF), dim3(64,8), 0, s, a, b); }},
         {"REF read-only 16B x4 nt", [](const uint8_t* a, uint8_t* b, hipStream_t s){ size_t n = (size_t)NF*W_IN*H_IN*4/16; hipLaunchKernelGGL(k_read, dim3((unsigned)(n/4/256)), dim3(256), 0, s, (const u32x4*)a, (uint32_t*)b, n); }},
