@@ -275,11 +275,14 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
 #ifndef SMOL_KERNEL_EMU
 /* memory -> LDS, 16 bytes per lane, no VGPR destination: LDS address = wave-uniform
  * base + 16 * lane (cdna_hip_programming.md section 5, global_load_lds) */
+/* NON-TEMPORAL (cache policy bits = 2): the staged rows are a once-read stream; with the default policy
+ * the same kernels run 1-6 % slower (BOX 115 -> 113.5 us, ratio 1.5 127 -> 124, photo thumbnails
+ * 142 -> 133; profiles/r02m_dma_policy.txt), as plain loads do in k_pow2 (76 % vs 86 % of the HBM peak) */
 __device__ __forceinline__ void smol_global_load_lds16 (const void *gptr, uint8_t *lds_wave_base, uint32_t)
 {
     __builtin_amdgcn_global_load_lds (
         reinterpret_cast<const __attribute__ ((address_space (1))) void *> (reinterpret_cast<uintptr_t> (gptr)),
-        (__attribute__ ((address_space (3))) void *) lds_wave_base, 16, 0, 0);
+        (__attribute__ ((address_space (3))) void *) lds_wave_base, 16, 0, 2);
 }
 
 __device__ __forceinline__ void smol_wait_vmcnt0 ()

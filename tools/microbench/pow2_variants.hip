@@ -22,6 +22,31 @@ template <int POL> __device__ __forceinline__ void stp(uint32_t* p, uint32_t v)
     else if (POL == 3) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else *p = v;
 }
+// load-policy variants: the four loads as one asm statement (own waitcnt), stores write-through
+#define LD4(POLSTR) asm volatile ( \
+    "global_load_dwordx4 %0, %4, off " POLSTR "\n\tglobal_load_dwordx4 %1, %5, off " POLSTR "\n\t" \
+    "global_load_dwordx4 %2, %6, off " POLSTR "\n\tglobal_load_dwordx4 %3, %7, off " POLSTR "\n\ts_waitcnt vmcnt(0)" \
+    : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory")
+template <int LP>
+__global__ void __launch_bounds__(1024) k_wrowl(const uint8_t* src, uint8_t* dst)
+{
+    const uint32_t tiles_x = W_OUT / 64;
+    const uint32_t f = blockIdx.y;
+    const uint32_t row = (blockIdx.x / tiles_x) * 16 + threadIdx.y;
+    const uint32_t tc = (blockIdx.x % tiles_x) * 64 + threadIdx.x;
+    const uint8_t* s = src + (size_t)f * W_IN * H_IN * 4 + (size_t)row * 4 * (W_IN * 4) + (size_t)tc * 16;
+    const u32x4 *p0 = (const u32x4*)s, *p1 = (const u32x4*)(s + W_IN * 4), *p2 = (const u32x4*)(s + 2 * W_IN * 4), *p3 = (const u32x4*)(s + 3 * W_IN * 4);
+    u32x4 raw[4];
+    if (LP == 0) LD4("nt");
+    else if (LP == 1) LD4("");
+    else if (LP == 2) LD4("sc1");
+    else if (LP == 3) LD4("sc0 sc1");
+    else if (LP == 4) LD4("nt sc1");
+    else if (LP == 5) LD4("nt sc0");
+    else LD4("nt sc0 sc1");
+    uint32_t* d = (uint32_t*)(dst + (size_t)f * W_OUT * H_OUT * 4 + (size_t)row * (W_OUT * 4)) + tc;
+    stp<2>(d, avg4(avg4(red4(raw[0]), red4(raw[1])), avg4(red4(raw[2]), red4(raw[3]))));
+}
 template <int RB, int POL>
 __global__ void __launch_bounds__(64 * RB) k_wrowp(const uint8_t* src, uint8_t* dst)
 {
@@ -157,6 +182,13 @@ int main()
         {"wrow 64x16 ntS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<16,true>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
         {"wrowp 64x16 sc1 (agent) S", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowp<16,2>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
         {"wrowp 64x16 sc0sc1 (system) S", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowp<16,3>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowl loads nt       + sc1 stores", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowl<0>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowl loads plain    + sc1 stores", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowl<1>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowl loads sc1      + sc1 stores", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowl<2>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowl loads sc0 sc1  + sc1 stores", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowl<3>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowl loads nt sc1   + sc1 stores", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowl<4>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowl loads nt sc0   + sc1 stores", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowl<5>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
+        {"wrowl loads nt sc0 sc1+sc1 stores", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrowl<6>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
         {"wrow 64x16 plainS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<16,false>), dim3(W_OUT/64*H_OUT/16, NF), dim3(64,16), 0, s, a, b); }},
         {"wrow 64x8 plainS", [](const uint8_t* a, uint8_t* b, hipStream_t s){ hipLaunchKernelGGL((k_wrow<8,false>), dim3(W_OUT/64*H_OUT/8, NF), dim3(64,8), 0, s, a, b); }},
         {"REF read-only 16B x4 nt", [](const uint8_t* a, uint8_t* b, hipStream_t s){ size_t n = (size_t)NF*W_IN*H_IN*4/16; hipLaunchKernelGGL(k_read, dim3((unsigned)(n/4/256)), dim3(256), 0, s, (const u32x4*)a, (uint32_t*)b, n); }},
