@@ -421,6 +421,8 @@ up_setup (JobDev &d)
      * flavours are bound by arithmetic per tile and keep the tall tiles. */
     if (flavour == 0 && tr > 8)
         tr = 8;
+    if (flavour != 0 && tr > 16)
+        tr = 16;                /* 1080p -> 4320p: sRGB-linear 224 -> 203 us, premul16 70 -> 67.5 (profiles/r02o_up_tile_rows.txt) */
     if (const char *e = tune_env ("SMOL_UP_ROWS"))
         if ((uint64_t) atoi (e) >= 1 && (uint64_t) atoi (e) < tr)
             tr = (uint64_t) atoi (e);
@@ -502,7 +504,9 @@ down_setup (JobDev &d)
         return false;                           /* more than DOWN_NL loads per lane and row */
     d.span_px = (uint32_t) span;
 
-    uint32_t th = 16u >> d.halv_v;              /* <= 128 vertical samples per tile */
+    /* flat tiles again (profiles/r02o_down_tile_rows.txt): 8 rows without vertical halvings, 4 with --
+     * premul16 ratio 1.5 65 -> 60 us, sRGB-linear ratio 1.5 120 -> 111, gamma-correct photo 133 -> 126 */
+    uint32_t th = d.halv_v ? 4u : 8u;           /* <= 128 vertical samples per tile */
     if (const char *e = tune_env ("SMOL_DOWN_ROWS"))
         th = (uint32_t) atoi (e);
     if (th > (128u >> d.halv_v))

@@ -1,0 +1,7 @@
+export SMOLSCALE_AMD_LIB=$PWD/smolscale_amd/libsmolscale_amd_tuning.so
+for rows in default 2 4 8 16 32; do
+  if [ $rows = default ]; then unset SMOL_DOWN_ROWS; else export SMOL_DOWN_ROWS=$rows; fi
+  python tools/bench_configs.py --configs SRGBPHOTO,SRGBHALF,SRGBPNG,P16HALF --iters 20 2>/dev/null | python -c "
+import sys,json
+print('rows=$rows', ' '.join('%s=%.1f(%.3f)' % (d['config'], d['step_us'], d['frac_of_8TBps']) for d in map(json.loads, sys.stdin)))"
+done
