@@ -28,6 +28,8 @@
 
 #pragma once
 
+#include <type_traits>
+
 namespace smolhip {
 
 constexpr int UP_CPL = 4;           /* output columns per lane                   */
@@ -454,6 +456,16 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
  * (smolscale-generic.c:470-752, 912-1164); 4 waves per workgroup share one    *
  * LDS copy of the six tables, each wave works on its own tile.                *
  * ------------------------------------------------------------------------- */
+template <int I, int N, typename F>
+__device__ __forceinline__ void up_static_for (F &&f)
+{
+    if constexpr (I < N)
+    {
+        f (std::integral_constant<int, I> {});
+        up_static_for<I + 1, N> (f);
+    }
+}
+
 template <bool W32>
 __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const uint8_t *lut_lds,
                                           const uint32_t lane, const uint32_t tile)
@@ -582,13 +594,18 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
     uint8_t *out_row = J.dst + (size_t) yrel0 * J.dst_stride;
     uint32_t r = 0;
     uint32_t e = smol_readlane (sched, 0);
+    /* full-width tile of 32-bit pixels on a 16-byte aligned destination (wave-uniform) */
+    const bool vec_ok = (J.bpp_out == 4) && (xn == x0 + TW) && J.out_vec16_ok;
 
-#pragma unroll
-    for (int s = 0; s + 1 < UP_NSRC_W; s++)
+    /* compile-time loop over the source-row pairs: h [] must be indexed by constants (a loop the
+     * optimiser declines to unroll would put it in scratch memory) */
+    up_static_for<0, UP_NSRC_W - 1> ([&] (auto s_const)
     {
+        constexpr int s = decltype (s_const)::value;
         while (r < nrows && (e & 0xffffu) == (uint32_t) s)
         {
             const uint32_t F = e >> 16, G = 256u - F;
+            uint32_t wv [CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++)
             {
@@ -605,15 +622,31 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                     const uint32_t ba = up16_tap (h [s][c][1], h [s + 1][c][1], F, G);
                     v [0] = rg & 0xffffu; v [1] = rg >> 16; v [2] = ba & 0xffffu; v [3] = ba >> 16;
                 }
-                if (xl + c < xn)
+                if (vec_ok)
+                    wv [c] = pack_px_word<true> (J, v, lut);
+                else if (xl + c < xn)
                     store_px<true> (J, out_row, xl + c, v, lut);
+            }
+            if (vec_ok)
+            {
+                /* the lane's adjacent pixels leave as ONE non-temporal store (16 or 8 bytes) */
+                if (CPL == 4)
+                {
+                    const u32x4 v4 = { wv [0], wv [1 % CPL], wv [2 % CPL], wv [3 % CPL] };
+                    __builtin_nontemporal_store (v4, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (out_row) + (size_t) xl * 4));
+                }
+                else
+                {
+                    const u32x2 v2 = { wv [0], wv [1 % CPL] };
+                    __builtin_nontemporal_store (v2, reinterpret_cast<SMOL_AS_GLOBAL u32x2 *> (gptr (out_row) + (size_t) xl * 4));
+                }
             }
             out_row += J.dst_stride;
             r++;
             if (r < nrows)
                 e = smol_readlane (sched, r);
         }
-    }
+    });
 }
 
 template <bool W32>

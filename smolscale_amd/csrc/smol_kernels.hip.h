@@ -354,12 +354,11 @@ __device__ __forceinline__ void fetch_px (const JobDev &J, const uint8_t *rowp, 
  * Pack internal channels into one destination pixel                         *
  *   64bpp-class: smolscale-generic.c:758-906; 128bpp-class: :912-1164       *
  * ------------------------------------------------------------------------- */
+/* internal channels -> the three colour bytes and the alpha byte of the destination pixel */
 template <bool WIDE, typename L>
-__device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32_t x,
-                                          const uint32_t (&v) [4], const L &lut)
+__device__ __forceinline__ void pack_px_channels (const JobDev &J, const uint32_t (&v) [4], const L &lut,
+                                                  uint32_t (&c) [3], uint32_t &a)
 {
-    uint32_t a, c [3];
-
     if (WIDE && J.p16)
         a = (v [3] >> 8) & 0xffu;
     else
@@ -404,6 +403,26 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
                 c [i] = premul8 (lut.to_srgb (u), a);
         }
     }
+
+}
+
+/* the 32-bit destination word of a pixel (bpp_out == 4) */
+template <bool WIDE, typename L>
+__device__ __forceinline__ uint32_t pack_px_word (const JobDev &J, const uint32_t (&v) [4], const L &lut)
+{
+    uint32_t a, c [3];
+    pack_px_channels<WIDE> (J, v, lut, c, a);
+    return (c [0] << (8 * J.pos_out [0])) | (c [1] << (8 * J.pos_out [1]))
+         | (c [2] << (8 * J.pos_out [2])) | (a << (8 * J.pos_out [3]));
+}
+
+template <bool WIDE, typename L>
+__device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32_t x,
+                                          const uint32_t (&v) [4], const L &lut)
+{
+    uint32_t a, c [3];
+
+    pack_px_channels<WIDE> (J, v, lut, c, a);
 
     if (J.bpp_out == 4)
     {
