@@ -1024,7 +1024,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if ((g.k == KC_TILE || g.k == KC_WTILE) && (jobs [j].tile_rows != g.rep.tile_rows || jobs [j].tile_cpl != g.rep.tile_cpl
                                   || (jobs [j].tile_variant >> 2) != (g.rep.tile_variant >> 2)
-                                  || jobs [j].tile_lpc != g.rep.tile_lpc || jobs [j].tile_vcopy != g.rep.tile_vcopy))
+                                  || jobs [j].tile_lpc != g.rep.tile_lpc || jobs [j].tile_vm != g.rep.tile_vm))
                 continue;
             if ((g.k == KC_WAVEPX || g.k == KC_WAVEPX_WIDE) && jobs [j].w_out != g.rep.w_out)
                 continue;

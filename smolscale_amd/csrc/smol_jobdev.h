@@ -24,6 +24,11 @@ inline const char *tune_env (const char *) { return nullptr; }
 
 enum : uint8_t { F_COPY = 0, F_ONE = 1, F_BILINEAR = 2, F_BOX = 3 };
 
+/* k_tile: vertical mode compiled into the entry point (JobDev::tile_vm), and the most vertical
+ * samples a tile may hold (its schedule is one register: lane k = sample k, lane 63 a sentinel) */
+enum : uint8_t { TILE_VM_ANY = 0, TILE_VM_COPY = 1, TILE_VM_PAIR = 2, TILE_VM_BOX = 3 };
+constexpr uint32_t TILE_MAX_VSAMPLES = 63;
+
 /* LDS copy of the parity tables: four inverse tables (4 x 1 KB), from_srgb (512 B), to_srgb (2 KB)
  * and the fused opaque-pixel linearisation (512 B); layout in smol_kernels.hip.h (LutLds) */
 constexpr uint32_t SMOL_LUT_LDS_BYTES = 4 * 1024 + 512 + 2048 + 512;
@@ -57,7 +62,7 @@ struct JobDev
     uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
     uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8)              */
     uint8_t tile_band;             /* k_tile: deal tiles out in XCD bands (very wide images) */
-    uint8_t tile_vcopy;            /* k_tile: vertical copy specialisation (bilinear 0-2H horizontally, 1 column per lane) */
+    uint8_t tile_vm;               /* k_tile: vertical specialisation (TILE_VM_*): 0 decided at run time, 1 copy, 2 bilinear, 3 box */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
@@ -191,8 +196,8 @@ tile_setup (JobDev &d)
         th = (d.filter_v == F_ONE) ? 32 : 16;
     if (const char *e = tune_env ("SMOL_TILE_ROWS"))
         th = (uint32_t) atoi (e);
-    if (th > (128u >> (d.filter_v == F_BILINEAR ? d.halv_v : 0)))
-        th = 128u >> (d.filter_v == F_BILINEAR ? d.halv_v : 0);     /* <= 128 vertical samples per tile */
+    if (th > (TILE_MAX_VSAMPLES >> (d.filter_v == F_BILINEAR ? d.halv_v : 0)))
+        th = TILE_MAX_VSAMPLES >> (d.filter_v == F_BILINEAR ? d.halv_v : 0);    /* the schedule is one register: lane k = sample k, lane 63 stays a sentinel */
     if (th < 1)
         th = 1;
     d.tile_rows = (uint16_t) th;
@@ -228,7 +233,15 @@ tile_setup (JobDev &d)
 
     d.tile_variant = (uint8_t) ((tapsel << 5) | (hm << 2) | out);
     d.tile_band = ((d.w_out + cols - 1) / cols >= 64 && !tune_env ("SMOL_NO_TILE_BAND"));
-    d.tile_vcopy = (d.filter_v == F_COPY && d.tile_cpl == 1 && hm >= 1 && hm <= 3 && !tune_env ("SMOL_NO_TILE_VCOPY"));
+    /* vertical mode compiled in for the combinations that carry the traffic (the rest decide at run time):
+     * bilinear H with copy / bilinear V, box H with box V */
+    d.tile_vm = TILE_VM_ANY;
+    if (d.filter_v == F_COPY && d.tile_cpl == 1 && hm >= 1 && hm <= 3 && !tune_env ("SMOL_NO_TILE_VCOPY"))
+        d.tile_vm = TILE_VM_COPY;
+    else if (d.filter_v == F_BILINEAR && hm >= 1 && hm <= 3 && !tune_env ("SMOL_NO_TILE_VM"))
+        d.tile_vm = TILE_VM_PAIR;
+    else if (d.filter_v == F_BOX && hm >= 4 && !tune_env ("SMOL_NO_TILE_VM"))
+        d.tile_vm = TILE_VM_BOX;
     d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
     d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);
 }
@@ -237,6 +250,8 @@ inline uint32_t
 tile_lds_bytes (const JobDev &d)
 {
     uint32_t bytes = 2 * d.group_rows * d.span_chunks * 16 + 32;
+    if (!d.wide && d.unassoc_out)
+        bytes += 1024;                          /* k_tile: LDS copy of the inverse-alpha table */
     if (d.wide)
         bytes += d.group_rows * d.span_px * ((d.p16 && d.linear) ? 16 : 8) + 16   /* converted rows (k_wtile) */
                  + SMOL_LUT_LDS_BYTES;                                            /* + LDS copy of the tables */

@@ -23,14 +23,15 @@ launch_tile_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
         hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, dim3 (64), lds, s, rep);
 }
 
-template <int TS, int HM>
+/* ... and per compiled-in vertical mode (smol_jobdev.h: TILE_VM_*) */
+template <int TS, int HM, int CPL, int VM>
 void
 launch_tile_kv (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, 1, true>), grid, dim3 (64), lds, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL, VM>), grid, dim3 (64), lds, s, jobs_dev);
     else
-        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, 1, true>), grid, dim3 (64), lds, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL, VM>), grid, dim3 (64), lds, s, rep);
 }
 
 template <int TS>
@@ -39,6 +40,18 @@ launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t l
 {
     const uint32_t hm = (rep.tile_variant >> 2) & 7u;
 
+    using namespace smolhip;
+
+    if (rep.tile_cpl == 4 && rep.tile_vm == TILE_VM_PAIR)
+    {
+        switch (hm)
+        {
+            case 1:  launch_tile_kv<TS, 1, 4, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+            case 2:  launch_tile_kv<TS, 2, 4, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+            default: launch_tile_kv<TS, 3, 4, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+        }
+        return;
+    }
     if (rep.tile_cpl == 4)
     {
         switch (hm)
@@ -50,15 +63,34 @@ launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t l
         }
         return;
     }
-    if (rep.tile_vcopy)
+    if (rep.tile_vm == TILE_VM_COPY)
     {
-        /* horizontal bilinear minification with a vertical copy (e.g. width-only resizes, BASELINE config 4) */
+        /* horizontal bilinear minification with a vertical copy (width-only resizes k_hspan does not take) */
         switch (hm)
         {
-            case 1:  launch_tile_kv<TS, 1> (jobs_dev, rep, grid, lds, s); break;
-            case 2:  launch_tile_kv<TS, 2> (jobs_dev, rep, grid, lds, s); break;
-            default: launch_tile_kv<TS, 3> (jobs_dev, rep, grid, lds, s); break;
+            case 1:  launch_tile_kv<TS, 1, 1, TILE_VM_COPY> (jobs_dev, rep, grid, lds, s); break;
+            case 2:  launch_tile_kv<TS, 2, 1, TILE_VM_COPY> (jobs_dev, rep, grid, lds, s); break;
+            default: launch_tile_kv<TS, 3, 1, TILE_VM_COPY> (jobs_dev, rep, grid, lds, s); break;
         }
+        return;
+    }
+    if (rep.tile_vm == TILE_VM_PAIR)
+    {
+        /* bilinear on both axes: the arbitrary-ratio minification everybody runs */
+        switch (hm)
+        {
+            case 1:  launch_tile_kv<TS, 1, 1, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+            case 2:  launch_tile_kv<TS, 2, 1, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+            default: launch_tile_kv<TS, 3, 1, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+        }
+        return;
+    }
+    if (rep.tile_vm == TILE_VM_BOX)
+    {
+        if (hm == 4)
+            launch_tile_kv<TS, 4, 1, TILE_VM_BOX> (jobs_dev, rep, grid, lds, s);
+        else
+            launch_tile_kv<TS, 5, 1, TILE_VM_BOX> (jobs_dev, rep, grid, lds, s);
         return;
     }
     switch (hm)

@@ -61,11 +61,24 @@ __device__ __forceinline__ Px2 tap2 (Px2 p, Px2 q, uint32_t F)
 }
 
 /* lane-wise a + b and a >> n on both halves (sums of at most 4 taps: <= 1020) */
+__device__ __forceinline__ uint32_t pk_add_u16 (uint32_t a, uint32_t b)
+{
+#ifdef SMOL_KERNEL_EMU
+    return as_u32 (as_u16x2 (a) + as_u16x2 (b));
+#else
+    /* spelled out: left to itself the compiler turns (a + b) >> 1 on packed lanes into a per-lane
+     * average (two 16-bit adds, two shifts and a v_perm instead of v_pk_add + v_pk_lshrrev) */
+    uint32_t r;
+    asm ("v_pk_add_u16 %0, %1, %2" : "=v" (r) : "v" (a), "v" (b));
+    return r;
+#endif
+}
+
 __device__ __forceinline__ Px2 px2_add (Px2 a, Px2 b)
 {
     Px2 r;
-    r.lo = as_u32 (as_u16x2 (a.lo) + as_u16x2 (b.lo));
-    r.hi = as_u32 (as_u16x2 (a.hi) + as_u16x2 (b.hi));
+    r.lo = pk_add_u16 (a.lo, b.lo);
+    r.hi = pk_add_u16 (a.hi, b.hi);
     return r;
 }
 
@@ -221,8 +234,11 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
 }
 
 /* packed pair -> destination pixel word (packers of smolscale-generic.c:758-906) */
+/* inv_tab: the tile's LDS copy of the inverse-alpha table (unassociated output only). A lookup
+ * in global memory would make the compiler drain every outstanding vector-memory operation
+ * (s_waitcnt vmcnt(0): the next group's DMA and all stores in flight) in front of each row. */
 template <int OUT>
-__device__ __forceinline__ uint32_t tile_pack (const JobDev &J, Px2 v)
+__device__ __forceinline__ uint32_t tile_pack (const JobDev &J, Px2 v, const uint32_t *inv_tab = smol_inv_p8_lut)
 {
     uint32_t w = v.lo | (v.hi << 8);             /* bytes in INPUT memory order */
 
@@ -230,7 +246,7 @@ __device__ __forceinline__ uint32_t tile_pack (const JobDev &J, Px2 v)
     {
         const uint32_t ain = (J.bpp_in == 4) ? J.pos_in [3] : 3u;
         const uint32_t a = (w >> (8 * ain)) & 0xffu;
-        const uint32_t inv = smol_inv_p8_lut [a];
+        const uint32_t inv = inv_tab [a];
         uint32_t o = a << (8 * ain);
 #pragma unroll
         for (uint32_t b = 0; b < 4; b++)
@@ -245,9 +261,9 @@ __device__ __forceinline__ uint32_t tile_pack (const JobDev &J, Px2 v)
 }
 
 template <int OUT, bool NT = false>
-__device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint32_t x, Px2 v)
+__device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint32_t x, Px2 v, const uint32_t *inv_tab = smol_inv_p8_lut)
 {
-    const uint32_t w = tile_pack<OUT> (J, v);
+    const uint32_t w = tile_pack<OUT> (J, v, inv_tab);
 
     if (OUT != OUT_ANY)
     {
@@ -295,17 +311,12 @@ __device__ __forceinline__ void smol_wait_vmcnt0 ()
  * "DMA loads, then k stores" this waits for the loads and lets the stores fly. */
 __device__ __forceinline__ void smol_wait_vmcnt_le (uint32_t n)
 {
-    switch (n)
-    {
-        case 0:  asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1:  asm volatile ("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2:  asm volatile ("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3:  asm volatile ("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4:  asm volatile ("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5:  asm volatile ("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6:  asm volatile ("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        default: asm volatile ("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    }
+    /* two cases, not eight: the scalar compare-and-branch ladder of a full switch ran once per row
+     * group in a kernel whose scalar unit is the busiest pipe (profiles/r02p_sq_r3.txt) */
+    if (n >= 2)
+        asm volatile ("s_waitcnt vmcnt(2)" ::: "memory");
+    else
+        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 /* ordering point for a one-wave workgroup: compiler barrier only */
@@ -341,7 +352,8 @@ __device__ __forceinline__ uint32_t smol_shfl_xor (uint32_t v, uint32_t mask)
 
 template <int OUT, int CPL>
 __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp, uint32_t xl, uint32_t xn,
-                                                 bool interior, bool full24, const Px2 (&o) [CPL])
+                                                 bool interior, bool full24, const Px2 (&o) [CPL],
+                                                 const uint32_t *inv_tab = smol_inv_p8_lut)
 {
     if (CPL == 4 && OUT != OUT_ANY)
     {
@@ -352,7 +364,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             uint32_t w [4];
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                w [c] = tile_pack<OUT> (J, o [c]);
+                w [c] = tile_pack<OUT> (J, o [c], inv_tab);
             u32x4 v = { w [0], w [1], w [2], w [3] };
             store_out128 (reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (rowp) + (size_t) xl * 4), v);
             return;
@@ -365,7 +377,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             uint32_t w [4];
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                w [c] = tile_pack<OUT> (J, o [c]) & 0x00ffffffu;
+                w [c] = tile_pack<OUT> (J, o [c], inv_tab) & 0x00ffffffu;
             /* three consecutive dwords (the backend merges them into one dwordx3 store) */
             SMOL_AS_GLOBAL uint32_t *d3 = reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) xl * 3);
             d3 [0] = w [0] | (w [1] << 24);
@@ -376,7 +388,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
         {
             /* dword j of the tile's 192 output bytes starts in pixel a = 4j/3 at byte b = 4j%3 */
             const uint32_t j = threadIdx.x;
-            const uint32_t w = tile_pack<OUT> (J, o [0]) & 0x00ffffffu;
+            const uint32_t w = tile_pack<OUT> (J, o [0], inv_tab) & 0x00ffffffu;
             const uint32_t a = (j * 4u) / 3u;
             const uint32_t b = (j * 4u) - a * 3u;
             const uint32_t wa = smol_shfl_idx (w, a & 63u);
@@ -390,7 +402,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
 #pragma unroll
     for (int c = 0; c < CPL; c++)
         if (xl + c < xn)
-            tile_store<OUT, CPL == 1> (J, rowp, xl + c, o [c]);
+            tile_store<OUT, CPL == 1> (J, rowp, xl + c, o [c], inv_tab);
 }
 
 
@@ -426,27 +438,49 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
 
     if (DMA)
     {
-        /* Row by row with a running row address: everything per row is a handful of
-         * scalar operations (the CU's one scalar unit is shared by all its waves and
-         * was the busiest pipe of this kernel), a lane only adds 16 * its chunk index. */
-        uintptr_t ra = src_base + (size_t) gfirst * src_stride + g0;    /* first needed byte of the row */
-        const uint32_t span_bytes = g1 - g0;
+        /* Row by row with a running, wave-uniform row address: per row a handful of scalar
+         * operations (the CU's one scalar unit is shared by all its waves and is the busiest pipe of
+         * this kernel: profiles/r02p_tile_ablation.txt), the lanes only contribute the constant
+         * 16 * lane as the 32-bit offset of a scalar-base load. */
+        const uintptr_t ra = src_base + (size_t) gfirst * src_stride + g0;
+        const uint8_t *a0 = reinterpret_cast<const uint8_t *> (ra & ~(uintptr_t) 15);  /* aligned start of the row's span */
+        uint32_t mis = (uint32_t) ra & 15u;                                            /* and the span's offset from it  */
+        const uint32_t span15 = g1 - g0 + 15u;
         const uint32_t pitch = J.span_chunks * 16u;
+        const uint32_t lane16 = lane * 16u;
         uint8_t *rowdst = buf;
 
+        if (J.span_chunks <= TILE_COLS)
+        {
+            /* the usual case: a row's span is one DMA instruction */
+            for (uint32_t i = 0; i < nrows; i++)
+            {
+                const uint32_t nbytes = (mis + span15) & ~15u;  /* whole 16-byte chunks from the aligned start */
+
+                if (lane16 < nbytes)
+                    smol_global_load_lds16 (a0 + lane16, rowdst, lane);
+                const uint32_t t = mis + (uint32_t) src_stride;
+                a0 += t & ~15u;
+                mis = t & 15u;
+                rowdst += pitch;
+            }
+            return;
+        }
         for (uint32_t i = 0; i < nrows; i++)
         {
-            const uint32_t nch = (((uint32_t) ra & 15u) + span_bytes + 15u) >> 4;
-            const uintptr_t a0 = ra & ~(uintptr_t) 15;
+            const uint32_t nbytes = (mis + span15) & ~15u;
+            uint32_t k0 = 0;
 
-            for (uint32_t k0 = 0; k0 < nch; k0 += TILE_COLS)
+            do
             {
-                const uint32_t k = k0 + lane;
-                if (k < nch)
-                    smol_global_load_lds16 (reinterpret_cast<const void *> (a0 + (uintptr_t) k * 16),
-                                            rowdst + (size_t) k0 * 16, lane);
+                if (k0 + lane16 < nbytes)
+                    smol_global_load_lds16 (a0 + (k0 + lane16), rowdst + k0, lane);
+                k0 += TILE_COLS * 16u;
             }
-            ra += src_stride;
+            while (k0 < nbytes);
+            const uint32_t t = mis + (uint32_t) src_stride;
+            a0 += t & ~15u;
+            mis = t & 15u;
             rowdst += pitch;
         }
         return;
@@ -499,9 +533,10 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
  * the register path, single LDS buffer). CPL: adjacent output columns per lane
  * (a tile is 64*CPL columns wide) -- amortises the wave's scalar bookkeeping
  * when there is little vector work per column (magnification). */
-template <int TAP, int HM, int OUT, bool STAGE_PREMUL, int CPL, bool VCOPY = false>
+template <int TAP, int HM, int OUT, bool STAGE_PREMUL, int CPL, int VM = TILE_VM_ANY>
 __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 {
+    constexpr bool VCOPY = (VM == TILE_VM_COPY);
     constexpr bool HBOX = (HM >= 4);
     constexpr uint32_t LPC = (HM == 5) ? 8u : 1u;            /* lanes per column (box only) */
     constexpr bool HPAIR = (HM >= 1 && HM <= 3);
@@ -602,23 +637,25 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
      * arithmetic. */
     /* VCOPY: the vertical axis is a copy (source row = output row), known at compile time:
      * no schedule, one output row per staged row */
-    const bool vbox = !VCOPY && (J.filter_v == F_BOX);
-    const bool vpair = !VCOPY && (J.filter_v == F_BILINEAR);
+    /* VM: the vertical mode is a template parameter for the combinations that carry the traffic, so
+     * that the row loop holds one mode's code and state; TILE_VM_ANY decides at run time */
+    const bool vbox = (VM == TILE_VM_BOX) || (VM == TILE_VM_ANY && J.filter_v == F_BOX);
+    const bool vpair = (VM == TILE_VM_PAIR) || (VM == TILE_VM_ANY && J.filter_v == F_BILINEAR);
     const uint32_t hv = vpair ? J.halv_v : 0u;
     const uint32_t nsy = 1u << hv;
     const uint32_t vlag = vpair ? 1u : 0u;
     uint32_t y = J.first_row + yrel0;                   /* absolute output row being built */
     const uint32_t y_end = J.first_row + yrel1;
     const uint32_t jy0 = y << hv;
-    const uint32_t n_samples = (y_end - y) << hv;       /* <= 128 (tile_setup)             */
-    uint32_t sched [2] = { 0, 0 };
-#pragma unroll
-    for (uint32_t q = 0; q < (VCOPY ? 0u : 2u); q++)
+    const uint32_t n_samples = (y_end - y) << hv;       /* <= TILE_MAX_VSAMPLES = 63 (tile_setup) */
+    /* sample k of the tile lives in lane k; the lanes past the last sample hold a row no source row
+     * index reaches (h_in <= 65535), so the row loop needs no "samples left?" test */
+    constexpr uint32_t SCHED_END = 0xffffu;
+    uint32_t sched = SCHED_END;
+    if (!VCOPY)
     {
-        uint32_t k = q * 64u + lane;
-        if (k >= n_samples)
-            k = n_samples - 1;
         uint32_t o, f;
+        const uint32_t k = (lane < n_samples) ? lane : n_samples - 1u;
         if (vbox)
         {
             /* one entry per output row: last source row of its box and that row's weight */
@@ -629,11 +666,12 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         {
             tile_vsample (J, jy0 + k, o, f);
         }
-        sched [q] = o | (f << 16);
+        if (lane < n_samples)
+            sched = o | (f << 16);
     }
     uint32_t ks = 0;                                    /* running sample index in the tile */
     uint32_t s_y = 0;                                   /* sample within the output row     */
-    uint32_t e = VCOPY ? (y | (256u << 16)) : smol_readlane (sched [0], 0);
+    uint32_t e = VCOPY ? (y | (256u << 16)) : smol_readlane (sched, 0);
     uint32_t oy = e & 0xffffu, Fy = e >> 16;
     uint32_t vy0 = 0, vw1 = 0;                          /* vbox: first row of the current box, its weight */
     if (vbox)
@@ -642,7 +680,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         box_span (J.step_y, J.h_in, jy0, vy0, o1, f, vw1);
     }
     const uint32_t row_first = vbox ? vy0 : oy;
-    const uint32_t e_last = VCOPY ? (y_end - 1u) : smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
+    const uint32_t e_last = VCOPY ? (y_end - 1u) : smol_readlane (sched, n_samples - 1u);
     const uint32_t row_last = (e_last & 0xffffu) + vlag;
     const bool interior = (xn == x0 + TW) && J.out_vec16_ok;
     /* 24-bit output, full-width tile, 4-byte aligned rows: dword-granular stores */
@@ -671,6 +709,18 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 #endif
     const bool dbg_notaps = dbg & 1, dbg_nostage = dbg & 2, dbg_nostore = dbg & 4;
     uint32_t stores_since_dma = 0;      /* output rows stored since the last DMA issue (>= 1 store each) */
+
+    /* unassociated output: the 1 KiB inverse-alpha table rides into LDS behind the staging buffers
+     * as one 16-byte-per-lane DMA, retired by the first wait below */
+    const uint32_t *inv_tab = nullptr;
+    if (OUT == OUT_U4 || (OUT == OUT_ANY && J.unassoc_out))
+    {
+        uint8_t *tab = sbuf + 2u * buf_bytes;
+        smol_global_load_lds16 (reinterpret_cast<const uint8_t *> (smol_inv_p8_lut) + lane * 16u, tab, lane);
+        if (!DMA)
+            smol_wait_vmcnt0 ();
+        inv_tab = reinterpret_cast<const uint32_t *> (tab);
+    }
 
     if (DMA && !dbg_nostage)
         tile_stage<true, false> (J, sbuf, lane, gfirst, nrows, g0, g1);
@@ -771,13 +821,13 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 }
                 else
                 {
-                    h [c].lo = 0; h [c].hi = 0;
 #pragma unroll
                     for (uint32_t s = 0; s < NSX; s++)
                     {
                         Px2 pp, qq;
                         tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
-                        h [c] = px2_add (h [c], tap2 (pp, qq, tap_f [c][s]));
+                        const Px2 t = tap2 (pp, qq, tap_f [c][s]);
+                        h [c] = s ? px2_add (h [c], t) : t;
                     }
                     if (HX)
                         h [c] = px2_shr (h [c], HX);
@@ -794,45 +844,43 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     acc [0] = px2_mulw (h [0], vw1);
                 else if (r < oy)
                     acc [0] = px2_add (acc [0], h [0]);
-                if (r == oy && ks < n_samples)
+                if (r == oy)
                 {
                     Px2 o [CPL];
                     o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
                     if (!dbg_nostore)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, full24, o);
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, full24, o, inv_tab);
                     stores_since_dma += dbg_nostore ? 0u : 1u;
                     out_row += J.dst_stride;
                     ks++;
                     vy0 = oy;
                     vw1 = 255u - Fy;
                     acc [0] = px2_mulw (h [0], vw1);
-                    if (ks < n_samples)
-                    {
-                        e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
-                        oy = e & 0xffffu;
-                        Fy = e >> 16;
-                    }
+                    e = smol_readlane (sched, ks);      /* past the last sample: the sentinel */
+                    oy = e & 0xffffu;
+                    Fy = e >> 16;
                 }
             }
             else if (VCOPY)
             {
                 /* vertical copy: this row is an output row */
                 if (!dbg_nostore)
-                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, h);
+                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, h, inv_tab);
                 stores_since_dma += dbg_nostore ? 0u : 1u;
                 out_row += J.dst_stride;
             }
             else
             /* vertical: emit every sample whose last row is r */
-            while (ks < n_samples && oy + vlag == r)
+            while (oy + vlag == r)
             {
+                /* acc is zero at the first sample of an output row */
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
                 {
                     Px2 t = h [c];
                     if (vpair)
                         t = tap2 (hprev [c], h [c], Fy);
-                    acc [c] = (s_y == 0) ? t : px2_add (acc [c], t);
+                    acc [c] = px2_add (acc [c], t);
                 }
                 s_y++;
                 ks++;
@@ -841,19 +889,19 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     Px2 o [CPL];
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
+                    {
                         o [c] = px2_shr (acc [c], hv);
+                        acc [c].lo = acc [c].hi = 0;
+                    }
                     if (!dbg_nostore)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o);
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o, inv_tab);
                     stores_since_dma += dbg_nostore ? 0u : 1u;
                     s_y = 0;
                     out_row += J.dst_stride;
                 }
-                if (ks < n_samples)
-                {
-                    e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
-                    oy = e & 0xffffu;
-                    Fy = e >> 16;
-                }
+                e = smol_readlane (sched, ks);          /* past the last sample: the sentinel */
+                oy = e & 0xffffu;
+                Fy = e >> 16;
             }
             if (!VCOPY)
             {
@@ -871,14 +919,14 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     }
 }
 
-template <int TAP, int HM, bool STAGE_PREMUL, int CPL, bool VCOPY = false>
+template <int TAP, int HM, bool STAGE_PREMUL, int CPL, int VM = TILE_VM_ANY>
 __device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf)
 {
     switch (J.tile_variant & 3u)
     {
-        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL, CPL, VCOPY> (J, sbuf); break;
-        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL, CPL, VCOPY> (J, sbuf); break;
-        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL, CPL, VCOPY> (J, sbuf); break;
+        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL, CPL, VM> (J, sbuf); break;
+        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL, CPL, VM> (J, sbuf); break;
+        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL, CPL, VM> (J, sbuf); break;
     }
 }
 
@@ -887,26 +935,53 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
 {
     const uint32_t hm = (J.tile_variant >> 2) & 7u;
 
+    /* (host emulation only: the GPU build has one entry point per combination) */
     if (J.tile_cpl == 4)
     {
-        switch (hm)
-        {
-            case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL, 4> (J, sbuf); break;
-            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4> (J, sbuf); break;
-            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 4> (J, sbuf); break;
-            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 4> (J, sbuf); break;
-        }
+        if (J.tile_vm == TILE_VM_PAIR)
+            switch (hm)
+            {
+                case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4, TILE_VM_PAIR> (J, sbuf); break;
+                case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 4, TILE_VM_PAIR> (J, sbuf); break;
+                default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 4, TILE_VM_PAIR> (J, sbuf); break;
+            }
+        else
+            switch (hm)
+            {
+                case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL, 4> (J, sbuf); break;
+                case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4> (J, sbuf); break;
+                case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 4> (J, sbuf); break;
+                default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 4> (J, sbuf); break;
+            }
         return;
     }
 
-    if (J.tile_vcopy)
+    if (J.tile_vm == TILE_VM_COPY)
     {
         switch (hm)
         {
-            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1, true> (J, sbuf); break;
-            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1, true> (J, sbuf); break;
-            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1, true> (J, sbuf); break;
+            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1, TILE_VM_COPY> (J, sbuf); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1, TILE_VM_COPY> (J, sbuf); break;
+            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1, TILE_VM_COPY> (J, sbuf); break;
         }
+        return;
+    }
+    if (J.tile_vm == TILE_VM_PAIR)
+    {
+        switch (hm)
+        {
+            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1, TILE_VM_PAIR> (J, sbuf); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1, TILE_VM_PAIR> (J, sbuf); break;
+            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1, TILE_VM_PAIR> (J, sbuf); break;
+        }
+        return;
+    }
+    if (J.tile_vm == TILE_VM_BOX)
+    {
+        if (hm == 4)
+            tile_dispatch_out<TAP, 4, STAGE_PREMUL, 1, TILE_VM_BOX> (J, sbuf);
+        else
+            tile_dispatch_out<TAP, 5, STAGE_PREMUL, 1, TILE_VM_BOX> (J, sbuf);
         return;
     }
 
@@ -942,11 +1017,11 @@ extern __shared__ __attribute__ ((aligned (16))) uint8_t smol_dyn_lds [];
  * gets its own register allocation, so a lean variant (a 1-tap copy) is not held
  * to the occupancy of the heaviest one (4 columns x 4 samples). TS = tapsel of
  * tile_variant: 0 A4, 1 A4 + premultiply while staging, 2 U4, 3 U3. */
-template <int TS, int HM, int CPL, bool VCOPY = false>
+template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
 __device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf)
 {
     constexpr int TAP = (TS <= 1) ? TAP_A4 : (TS == 2 ? TAP_U4 : TAP_U3);
-    tile_dispatch_out<TAP, HM, TS == 1, CPL, VCOPY> (J, sbuf);
+    tile_dispatch_out<TAP, HM, TS == 1, CPL, VM> (J, sbuf);
 }
 
 #ifdef SMOL_KERNEL_EMU
@@ -956,21 +1031,21 @@ __global__ void k_tile_one (const JobDev J)
     tile_dispatch (J, smol_dyn_lds);
 }
 #else
-template <int TS, int HM, int CPL, bool VCOPY = false>
+template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
 __global__ void __launch_bounds__ (64)
 k_tile_batch (const JobDev *__restrict__ jobs)
 {
     /* private copy: the descriptor must not be re-read from memory after every
      * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
     const JobDev J = load_job (jobs, blockIdx.z);
-    tile_entry<TS, HM, CPL, VCOPY> (J, smol_dyn_lds);
+    tile_entry<TS, HM, CPL, VM> (J, smol_dyn_lds);
 }
 
-template <int TS, int HM, int CPL, bool VCOPY = false>
+template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
 __global__ void __launch_bounds__ (64)
 k_tile_one (const JobDev J)
 {
-    tile_entry<TS, HM, CPL, VCOPY> (J, smol_dyn_lds);
+    tile_entry<TS, HM, CPL, VM> (J, smol_dyn_lds);
 }
 #endif
 
