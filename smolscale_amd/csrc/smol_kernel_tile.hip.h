@@ -37,7 +37,7 @@ __device__ __forceinline__ Px2 px2_from_word (uint32_t w)
 {
     Px2 r;
     r.lo = w & PAIR_MASK;
-    r.hi = (w >> 8) & PAIR_MASK;
+    r.hi = __builtin_amdgcn_perm (w, w, 0x0c030c01u);     /* (w >> 8) & PAIR_MASK in one v_perm */
     return r;
 }
 
@@ -304,19 +304,6 @@ __device__ __forceinline__ void smol_global_load_lds16 (const void *gptr, uint8_
 __device__ __forceinline__ void smol_wait_vmcnt0 ()
 {
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-/* Wait until at most n (wave-uniform, clamped to 7) of this wave's vector-memory
- * operations are still outstanding. They retire in issue order, so after
- * "DMA loads, then k stores" this waits for the loads and lets the stores fly. */
-__device__ __forceinline__ void smol_wait_vmcnt_le (uint32_t n)
-{
-    /* two cases, not eight: the scalar compare-and-branch ladder of a full switch ran once per row
-     * group in a kernel whose scalar unit is the busiest pipe (profiles/r02p_sq_r3.txt) */
-    if (n >= 2)
-        asm volatile ("s_waitcnt vmcnt(2)" ::: "memory");
-    else
-        asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 /* ordering point for a one-wave workgroup: compiler barrier only */
@@ -708,7 +695,6 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     constexpr uint32_t dbg = 0;
 #endif
     const bool dbg_notaps = dbg & 1, dbg_nostage = dbg & 2, dbg_nostore = dbg & 4;
-    uint32_t stores_since_dma = 0;      /* output rows stored since the last DMA issue (>= 1 store each) */
 
     /* unassociated output: the 1 KiB inverse-alpha table rides into LDS behind the staging buffers
      * as one 16-byte-per-lane DMA, retired by the first wait below */
@@ -731,19 +717,14 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 
         if (DMA)
         {
-            /* This group's DMA was issued before the previous group's pixel stores, and
-             * vector-memory operations retire in issue order: waiting until no more
-             * than `stores_since_dma' (a lower bound of the stores issued since) are
-             * outstanding retires the DMA without draining the stores. Then start the
-             * next group into the other buffer so it streams in during the consume. */
-            if (dbg & 8)
-                smol_wait_vmcnt0 ();
-            else
-                smol_wait_vmcnt_le (stores_since_dma);
+            /* Retire this group's DMA (issued before the previous group's pixel stores), then start
+             * the next group into the other buffer so that it streams in during the consume.
+             * A counted wait that lets the stores fly (vmcnt(n) for the n stores issued since) measured
+             * the same as draining everything (profiles/r02p_wait_ab.txt) and cost scalar bookkeeping. */
+            smol_wait_vmcnt0 ();
             /* the workgroup is a single wave: no s_barrier needed, and __syncthreads()
              * would make hipcc drain every outstanding store (vmcnt(0)) */
             smol_wave_sync ();
-            stores_since_dma = 0;
             const uint32_t nfirst = gfirst + nrows;
             if (nfirst <= row_last && !dbg_nostage)
             {
@@ -850,7 +831,6 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
                     if (!dbg_nostore)
                         tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, full24, o, inv_tab);
-                    stores_since_dma += dbg_nostore ? 0u : 1u;
                     out_row += J.dst_stride;
                     ks++;
                     vy0 = oy;
@@ -866,13 +846,28 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 /* vertical copy: this row is an output row */
                 if (!dbg_nostore)
                     tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, h, inv_tab);
-                stores_since_dma += dbg_nostore ? 0u : 1u;
                 out_row += J.dst_stride;
             }
             else
             /* vertical: emit every sample whose last row is r */
             while (oy + vlag == r)
             {
+                if (hv == 0)
+                {
+                    /* no vertical halvings: the sample is the output row */
+                    Px2 o [CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; c++)
+                        o [c] = vpair ? tap2 (hprev [c], h [c], Fy) : h [c];
+                    if (!dbg_nostore)
+                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o, inv_tab);
+                    out_row += J.dst_stride;
+                    ks++;
+                    e = smol_readlane (sched, ks);
+                    oy = e & 0xffffu;
+                    Fy = e >> 16;
+                    continue;
+                }
                 /* acc is zero at the first sample of an output row */
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
@@ -895,7 +890,6 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                     }
                     if (!dbg_nostore)
                         tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o, inv_tab);
-                    stores_since_dma += dbg_nostore ? 0u : 1u;
                     s_y = 0;
                     out_row += J.dst_stride;
                 }

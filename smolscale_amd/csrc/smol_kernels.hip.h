@@ -107,6 +107,8 @@ __device__ __forceinline__ void store_out32 (SMOL_AS_GLOBAL uint32_t *p, uint32_
     *p = v;
 #elif defined (SMOL_STORES_NT)
     __builtin_nontemporal_store (v, p);
+#elif defined (SMOL_STORES_PLAIN)
+    *p = v;
 #else
     __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -118,6 +120,8 @@ __device__ __forceinline__ void store_out64 (SMOL_AS_GLOBAL uint64_t *p, uint32_
     *p = (uint64_t) lo | ((uint64_t) hi << 32);
 #elif defined (SMOL_STORES_NT)
     __builtin_nontemporal_store ((uint64_t) lo | ((uint64_t) hi << 32), p);
+#elif defined (SMOL_STORES_PLAIN)
+    *p = (uint64_t) lo | ((uint64_t) hi << 32);
 #else
     __hip_atomic_store (p, (uint64_t) lo | ((uint64_t) hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -855,6 +859,8 @@ __device__ __forceinline__ void store_out128 (SMOL_AS_GLOBAL u32x4 *p, u32x4 v)
     *p = v;
 #elif defined (SMOL_STORES_NT)
     __builtin_nontemporal_store (v, p);
+#elif defined (SMOL_STORES_PLAIN)
+    *p = v;
 #else
     asm volatile ("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v" (p), "v" (v) : "memory");
 #endif

@@ -56,7 +56,6 @@ static inline void smol_global_load_lds16 (const void *gptr, uint8_t *lds_wave_b
     memcpy (lds_wave_base + 16 * lane, gptr, 16);
 }
 static inline void smol_wait_vmcnt0 (void) {}
-static inline void smol_wait_vmcnt_le (uint32_t) {}
 static inline void smol_wave_sync (void) { __syncthreads (); }
 
 /* v_readlane: every lane of the block calls this with the same idx */
