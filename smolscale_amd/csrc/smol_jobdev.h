@@ -138,6 +138,14 @@ tile_setup (JobDev &d)
     if (!d.wide && d.out3_ok && d.w_out >= 256 && d.filter_v != F_BOX
         && d.filter_h == F_BILINEAR && d.halv_h <= 1)
         d.tile_cpl = 4;
+    /* ... but not for a plain 32-bit premultiplied source shrunk by less than ~1.75 on this axis: once the
+     * row loop's scalar work was cut (r02p), one column per lane is faster there (4096^2 -> 2731^2 123 -> 108 us,
+     * -> 3413^2 174 -> 153, H down / V up 113 -> 82; at ratio 1.9, from 24-bit or unassociated sources 4 columns
+     * stay 3-5 % ahead: profiles/r02p_cpl_ab.txt) */
+    if (d.tile_cpl == 4 && d.filter_h == F_BILINEAR && d.halv_h == 0 && d.bpp_in == 4 && !d.unassoc_in
+        && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0 && d.bpp_out == 4
+        && d.step_x >= ((uint64_t) 1 << 32) && d.step_x < ((uint64_t) 7 << 30))
+        d.tile_cpl = 1;
     if (const char *e = tune_env ("SMOL_TILE_CPL"))
         if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX)
             d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
@@ -191,7 +199,22 @@ tile_setup (JobDev &d)
         if (th > 16) th = 16;
     }
     else if (d.filter_v == F_BILINEAR)
-        th = (d.step_y < ((uint64_t) 1 << 32)) ? 32 : (d.halv_v ? (16u >> d.halv_v) : 8u);   /* measured: 8 beats 16 without halvings */
+    {
+        /* minification: 12-13 source rows per tile (profiles/r02p_tile_rows_sweep.txt: ratio 1.5 8-12 output
+         * rows, ratio 2.5 and 3 four, ratio 6 two; below ~1.4 sixteen) */
+        const uint64_t rows_per_out = d.step_y << d.halv_v;                 /* 32.32 source rows per output row */
+        if (d.step_y < ((uint64_t) 1 << 32))
+            th = 32;
+        else if (d.wide)
+            th = d.halv_v ? (16u >> d.halv_v) : 8u;                         /* k_wtile: as measured in round 1 */
+        else if (rows_per_out < ((uint64_t) 14 << 32) / 10)                 /* < 1.4 */
+            th = 16;
+        else
+        {
+            th = (uint32_t) (((uint64_t) 13 << 32) / rows_per_out);
+            if (th < 2) th = 2;
+        }
+    }
     else
         th = (d.filter_v == F_ONE) ? 32 : 16;
     if (const char *e = tune_env ("SMOL_TILE_ROWS"))

@@ -37,6 +37,11 @@ CONFIGS = {
     "BOX": (0, 4096, 4096, None, 0, 448, 448, 8, "4096^2->448^2 RGBA8 premul (BOX/BOX 64bpp), 8 frames per launch"),
     # arbitrary (non power-of-two) ratios through k_tile
     "R1.5": (0, 4096, 4096, None, 0, 2731, 2731, 6, "4096^2->2731^2 RGBA8 premul (0H, ratio 1.5), 6 frames"),
+    "R1.2": (0, 4096, 4096, None, 0, 3413, 3413, 6, "4096^2->3413^2 RGBA8 premul (0H, ratio 1.2), 6 frames"),
+    "R1.9": (0, 4096, 4096, None, 0, 2156, 2156, 6, "4096^2->2156^2 RGBA8 premul (0H, ratio 1.9), 6 frames"),
+    "R1.5RGB": (8, 4096, 4096, None, 0, 2731, 2731, 6, "4096^2 RGB8 ->2731^2 RGBA8 (0H, ratio 1.5), 6 frames"),
+    "R1.5U": (4, 4096, 4096, None, 0, 2731, 2731, 6, "4096^2 RGBA unassociated ->2731^2 RGBA8 premul (0H, ratio 1.5), 6 frames"),
+    "HDOWNVUP": (0, 4096, 2048, None, 0, 2731, 3000, 6, "4096x2048->2731x3000 RGBA8 premul (H ratio 1.5 down, V up), 6 frames"),
     "R3": (0, 4096, 4096, None, 0, 1365, 1365, 8, "4096^2->1365^2 RGBA8 premul (1H, ratio 3), 8 frames"),
     "R6": (0, 4096, 4096, None, 0, 683, 683, 8, "4096^2->683^2 RGBA8 premul (2H, ratio 6), 8 frames"),
     "PHOTO": (8, 4000, 3000, None, 8, 1600, 1200, 12, "4000x3000 RGB8 -> 1600x1200 RGB8 (1H, ratio 2.5), 12 frames"),

@@ -1,7 +1,7 @@
 export SMOLSCALE_AMD_LIB=$PWD/smolscale_amd/libsmolscale_amd_tuning.so
-mkdir -p gpurun_out/r02d
-for cfg in BOX R1.5 R3 R6 PHOTO PNG; do
-  for rows in default 1 2 3 4 6 8 16; do
+mkdir -p gpurun_out/${TAG:-r02d}
+for cfg in ${CFGS:-BOX R1.5 R3 R6 PHOTO PNG}; do
+  for rows in ${ROWS:-default 1 2 3 4 6 8 16}; do
     for band in 1; do
       if [ $rows = default ]; then unset SMOL_TILE_ROWS; else export SMOL_TILE_ROWS=$rows; fi
       python tools/bench_configs.py --configs $cfg --iters 20 2>/dev/null | python -c "
@@ -11,4 +11,4 @@ for l in sys.stdin:
 "
     done
   done
-done | tee gpurun_out/r02d/tile_rows_sweep.txt
+done | tee gpurun_out/${TAG:-r02d}/tile_rows_sweep.txt
