@@ -238,7 +238,7 @@ tile_setup (JobDev &d)
          * double-buffered DMA staging */
         const bool reuse = d.filter_h != F_BILINEAR || d.step_x < ((uint64_t) 1 << 32)
                            || tune_env ("SMOL_TILE_PREMUL_STAGE");
-        tapsel = reuse ? 1 : 2;
+        tapsel = reuse ? 1 : (tune_env ("SMOL_TILE_NO_LDS_PREMUL") ? 2 : 4);   /* 4: DMA, then premultiply the group in LDS */
     }
     else
         tapsel = 0;

@@ -110,7 +110,7 @@ namespace smolhip {
 namespace launch {
 
 /* one translation unit per tap reader (SMOL_TILE_TS = 0 A4, 1 A4 + premultiply while
- * staging, 2 U4, 3 U3): smol_k_tile0.hip ... smol_k_tile3.hip */
+ * staging, 2 U4, 3 U3, 4 A4 after an in-LDS premultiply pass): smol_k_tile0.hip ... smol_k_tile4.hip */
 #define SMOL_TILE_FN2(n) tile_ts##n
 #define SMOL_TILE_FN(n) SMOL_TILE_FN2 (n)
 

@@ -407,6 +407,49 @@ __device__ __forceinline__ void tile_vsample (const JobDev &J, uint32_t jy, uint
     }
 }
 
+/* How source rows reach LDS */
+enum : int
+{
+    TILE_STAGE_DMA = 0,             /* global_load_lds, double buffered                                   */
+    TILE_STAGE_REG_PREMUL = 1,      /* through registers, premultiplying on the way (re-used pixels)      */
+    TILE_STAGE_DMA_PREMUL = 2       /* DMA, then one in-place premultiply pass over the group in LDS      */
+};
+
+/* In-place unassociated -> premultiplied over a staged row group (32-bit pixels on 4-byte
+ * boundaries, so every dword of the 16-byte chunks is one pixel): each source pixel is
+ * premultiplied once instead of once per tap that touches it (1.6 times at ratio 2.5), and the
+ * taps read plain aligned dwords. One wave: LDS operations complete in order, no barrier. */
+__device__ __forceinline__ void tile_premul_lds (const JobDev &J, uint8_t *buf, uint32_t lane, uint32_t nrows)
+{
+    const uint32_t total = nrows * J.span_chunks;
+    const uint32_t ain = J.pos_in [3];
+
+    for (uint32_t c0 = 0; c0 < total; c0 += 2u * TILE_COLS)
+    {
+        u32x4 v [2];
+#pragma unroll
+        for (uint32_t u = 0; u < 2; u++)
+        {
+            const uint32_t c = c0 + u * TILE_COLS + lane;
+            if (c < total)
+                v [u] = *reinterpret_cast<const u32x4 *> (buf + (size_t) c * 16);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 2; u++)
+        {
+            const uint32_t c = c0 + u * TILE_COLS + lane;
+            if (c < total)
+            {
+                v [u].x = premul_word (v [u].x, ain);
+                v [u].y = premul_word (v [u].y, ain);
+                v [u].z = premul_word (v [u].z, ain);
+                v [u].w = premul_word (v [u].w, ain);
+                *reinterpret_cast<u32x4 *> (buf + (size_t) c * 16) = v [u];
+            }
+        }
+    }
+}
+
 constexpr int TILE_STAGE_UNROLL = 8;
 
 /* Bring source rows [gfirst, gfirst + nrows) of the tile's column span into the
@@ -516,11 +559,11 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
 /* TAP: how taps are read. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples
  * per output column, 4 = box with one lane per column, 5 = box with 8 lanes per
  * column (their partial sums meet through wave shuffles; for wide spans, so that
- * 64 lanes still read consecutive LDS words). STAGE_PREMUL: premultiply while staging (TAP_A4 only; uses
+ * 64 lanes still read consecutive LDS words). STAGE (TILE_STAGE_*): DMA; premultiply while staging (TAP_A4 only; uses
  * the register path, single LDS buffer). CPL: adjacent output columns per lane
  * (a tile is 64*CPL columns wide) -- amortises the wave's scalar bookkeeping
  * when there is little vector work per column (magnification). */
-template <int TAP, int HM, int OUT, bool STAGE_PREMUL, int CPL, int VM = TILE_VM_ANY>
+template <int TAP, int HM, int OUT, int STAGE, int CPL, int VM = TILE_VM_ANY>
 __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 {
     constexpr bool VCOPY = (VM == TILE_VM_COPY);
@@ -532,7 +575,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     constexpr uint32_t BPP = (TAP == TAP_U3) ? 3u : 4u;
     constexpr uint32_t TW = TILE_COLS * CPL / LPC;
     static_assert (!HBOX || CPL == 1, "box columns are one per lane group");
-    constexpr bool DMA = !STAGE_PREMUL;
+    constexpr bool DMA = (STAGE != TILE_STAGE_REG_PREMUL);
 
     const uint32_t lane = threadIdx.x;
     /* grid = (column tiles, row tiles, jobs): raster order over the tiles, no integer division at the
@@ -731,12 +774,17 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
                 const uint32_t nn = (row_last - nfirst + 1 < J.group_rows) ? row_last - nfirst + 1 : J.group_rows;
                 tile_stage<true, false> (J, sbuf + (cur ^ 1u) * buf_bytes, lane, nfirst, nn, g0, g1);
             }
+            if (STAGE == TILE_STAGE_DMA_PREMUL && !dbg_notaps)
+            {
+                tile_premul_lds (J, buf, lane, nrows);
+                smol_wave_sync ();      /* (a real barrier only in the host emulation, where lanes are threads) */
+            }
         }
         else
         {
             __syncthreads ();                           /* previous group fully consumed */
             if (!dbg_nostage)
-                tile_stage<false, STAGE_PREMUL> (J, buf, lane, gfirst, nrows, g0, g1);
+                tile_stage<false, STAGE == TILE_STAGE_REG_PREMUL> (J, buf, lane, gfirst, nrows, g0, g1);
             __syncthreads ();
         }
 
@@ -913,18 +961,18 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     }
 }
 
-template <int TAP, int HM, bool STAGE_PREMUL, int CPL, int VM = TILE_VM_ANY>
+template <int TAP, int HM, int STAGE, int CPL, int VM = TILE_VM_ANY>
 __device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf)
 {
     switch (J.tile_variant & 3u)
     {
-        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE_PREMUL, CPL, VM> (J, sbuf); break;
-        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE_PREMUL, CPL, VM> (J, sbuf); break;
-        default:     tile_body<TAP, HM, OUT_ANY, STAGE_PREMUL, CPL, VM> (J, sbuf); break;
+        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE, CPL, VM> (J, sbuf); break;
+        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE, CPL, VM> (J, sbuf); break;
+        default:     tile_body<TAP, HM, OUT_ANY, STAGE, CPL, VM> (J, sbuf); break;
     }
 }
 
-template <int TAP, bool STAGE_PREMUL>
+template <int TAP, int STAGE>
 __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf)
 {
     const uint32_t hm = (J.tile_variant >> 2) & 7u;
@@ -935,17 +983,17 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
         if (J.tile_vm == TILE_VM_PAIR)
             switch (hm)
             {
-                case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4, TILE_VM_PAIR> (J, sbuf); break;
-                case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 4, TILE_VM_PAIR> (J, sbuf); break;
-                default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 4, TILE_VM_PAIR> (J, sbuf); break;
+                case 1:  tile_dispatch_out<TAP, 1, STAGE, 4, TILE_VM_PAIR> (J, sbuf); break;
+                case 2:  tile_dispatch_out<TAP, 2, STAGE, 4, TILE_VM_PAIR> (J, sbuf); break;
+                default: tile_dispatch_out<TAP, 3, STAGE, 4, TILE_VM_PAIR> (J, sbuf); break;
             }
         else
             switch (hm)
             {
-                case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL, 4> (J, sbuf); break;
-                case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 4> (J, sbuf); break;
-                case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 4> (J, sbuf); break;
-                default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 4> (J, sbuf); break;
+                case 0:  tile_dispatch_out<TAP, 0, STAGE, 4> (J, sbuf); break;
+                case 1:  tile_dispatch_out<TAP, 1, STAGE, 4> (J, sbuf); break;
+                case 2:  tile_dispatch_out<TAP, 2, STAGE, 4> (J, sbuf); break;
+                default: tile_dispatch_out<TAP, 3, STAGE, 4> (J, sbuf); break;
             }
         return;
     }
@@ -954,9 +1002,9 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
     {
         switch (hm)
         {
-            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1, TILE_VM_COPY> (J, sbuf); break;
-            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1, TILE_VM_COPY> (J, sbuf); break;
-            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1, TILE_VM_COPY> (J, sbuf); break;
+            case 1:  tile_dispatch_out<TAP, 1, STAGE, 1, TILE_VM_COPY> (J, sbuf); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE, 1, TILE_VM_COPY> (J, sbuf); break;
+            default: tile_dispatch_out<TAP, 3, STAGE, 1, TILE_VM_COPY> (J, sbuf); break;
         }
         return;
     }
@@ -964,42 +1012,43 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
     {
         switch (hm)
         {
-            case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1, TILE_VM_PAIR> (J, sbuf); break;
-            case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1, TILE_VM_PAIR> (J, sbuf); break;
-            default: tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1, TILE_VM_PAIR> (J, sbuf); break;
+            case 1:  tile_dispatch_out<TAP, 1, STAGE, 1, TILE_VM_PAIR> (J, sbuf); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE, 1, TILE_VM_PAIR> (J, sbuf); break;
+            default: tile_dispatch_out<TAP, 3, STAGE, 1, TILE_VM_PAIR> (J, sbuf); break;
         }
         return;
     }
     if (J.tile_vm == TILE_VM_BOX)
     {
         if (hm == 4)
-            tile_dispatch_out<TAP, 4, STAGE_PREMUL, 1, TILE_VM_BOX> (J, sbuf);
+            tile_dispatch_out<TAP, 4, STAGE, 1, TILE_VM_BOX> (J, sbuf);
         else
-            tile_dispatch_out<TAP, 5, STAGE_PREMUL, 1, TILE_VM_BOX> (J, sbuf);
+            tile_dispatch_out<TAP, 5, STAGE, 1, TILE_VM_BOX> (J, sbuf);
         return;
     }
 
     switch (hm)
     {
-        case 0:  tile_dispatch_out<TAP, 0, STAGE_PREMUL, 1> (J, sbuf); break;
-        case 1:  tile_dispatch_out<TAP, 1, STAGE_PREMUL, 1> (J, sbuf); break;
-        case 2:  tile_dispatch_out<TAP, 2, STAGE_PREMUL, 1> (J, sbuf); break;
-        case 3:  tile_dispatch_out<TAP, 3, STAGE_PREMUL, 1> (J, sbuf); break;
-        case 4:  tile_dispatch_out<TAP, 4, STAGE_PREMUL, 1> (J, sbuf); break;
-        default: tile_dispatch_out<TAP, 5, STAGE_PREMUL, 1> (J, sbuf); break;
+        case 0:  tile_dispatch_out<TAP, 0, STAGE, 1> (J, sbuf); break;
+        case 1:  tile_dispatch_out<TAP, 1, STAGE, 1> (J, sbuf); break;
+        case 2:  tile_dispatch_out<TAP, 2, STAGE, 1> (J, sbuf); break;
+        case 3:  tile_dispatch_out<TAP, 3, STAGE, 1> (J, sbuf); break;
+        case 4:  tile_dispatch_out<TAP, 4, STAGE, 1> (J, sbuf); break;
+        default: tile_dispatch_out<TAP, 5, STAGE, 1> (J, sbuf); break;
     }
 }
 
 /* tile_variant = tapsel << 5 | HM << 2 | OUT; tapsel: 0 A4, 1 A4 + premultiply
- * while staging, 2 U4, 3 U3 (smol_jobdev.h: tile_setup) */
+ * while staging, 2 U4, 3 U3, 4 A4 after an in-LDS premultiply pass (smol_jobdev.h: tile_setup) */
 __device__ __forceinline__ void tile_dispatch (const JobDev &J, uint8_t *sbuf)
 {
     switch (J.tile_variant >> 5)
     {
-        case 0:  tile_dispatch_hm<TAP_A4, false> (J, sbuf); break;
-        case 1:  tile_dispatch_hm<TAP_A4, true> (J, sbuf); break;
-        case 2:  tile_dispatch_hm<TAP_U4, false> (J, sbuf); break;
-        default: tile_dispatch_hm<TAP_U3, false> (J, sbuf); break;
+        case 0:  tile_dispatch_hm<TAP_A4, TILE_STAGE_DMA> (J, sbuf); break;
+        case 1:  tile_dispatch_hm<TAP_A4, TILE_STAGE_REG_PREMUL> (J, sbuf); break;
+        case 2:  tile_dispatch_hm<TAP_U4, TILE_STAGE_DMA> (J, sbuf); break;
+        case 3:  tile_dispatch_hm<TAP_U3, TILE_STAGE_DMA> (J, sbuf); break;
+        default: tile_dispatch_hm<TAP_A4, TILE_STAGE_DMA_PREMUL> (J, sbuf); break;
     }
 }
 
@@ -1014,8 +1063,9 @@ extern __shared__ __attribute__ ((aligned (16))) uint8_t smol_dyn_lds [];
 template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
 __device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf)
 {
-    constexpr int TAP = (TS <= 1) ? TAP_A4 : (TS == 2 ? TAP_U4 : TAP_U3);
-    tile_dispatch_out<TAP, HM, TS == 1, CPL, VM> (J, sbuf);
+    constexpr int TAP = (TS <= 1 || TS == 4) ? TAP_A4 : (TS == 2 ? TAP_U4 : TAP_U3);
+    constexpr int STAGE = (TS == 1) ? TILE_STAGE_REG_PREMUL : (TS == 4 ? TILE_STAGE_DMA_PREMUL : TILE_STAGE_DMA);
+    tile_dispatch_out<TAP, HM, STAGE, CPL, VM> (J, sbuf);
 }
 
 #ifdef SMOL_KERNEL_EMU

@@ -22,6 +22,7 @@ void tile_ts0 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
 void tile_ts1 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
 void tile_ts2 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
 void tile_ts3 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
+void tile_ts4 (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
 
 /* k_tile: tapsel of tile_variant picks the translation unit */
 inline void
@@ -32,7 +33,8 @@ tile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStr
         case 0:  tile_ts0 (jobs_dev, rep, grid, lds, s); break;
         case 1:  tile_ts1 (jobs_dev, rep, grid, lds, s); break;
         case 2:  tile_ts2 (jobs_dev, rep, grid, lds, s); break;
-        default: tile_ts3 (jobs_dev, rep, grid, lds, s); break;
+        case 3:  tile_ts3 (jobs_dev, rep, grid, lds, s); break;
+        default: tile_ts4 (jobs_dev, rep, grid, lds, s); break;
     }
 }
 /* two passes through rep.tmp / jobs [i].tmp; h_tiles, v_tiles = waves of each pass (group maxima) */
