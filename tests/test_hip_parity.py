@@ -264,6 +264,47 @@ def test_tile_kernel_wide_images_and_box_shapes():
             assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
 
 
+def test_tile_kernel_vertical_modes_and_staging_variants():
+    """One case per k_tile entry point added in round 2: the vertical mode compiled in (bilinear with one
+    and four columns per lane at 0, 1 and 2 halvings; box with 1 and 8 lanes per column; copy), the
+    run-time fallback (bilinear on one axis, box on the other), unassociated 32-bit sources premultiplied
+    in LDS after the DMA, unassociated output through the LDS inverse table, tiles of 63 vertical samples
+    (the one-register schedule) and the new tile heights (many tile rows, ragged last tile)."""
+    shapes = [
+        # (t_in, w_in, h_in, t_out, w_out, h_out)
+        (0, 1500, 700, 0, 1000, 467),      # bilinear/bilinear 0H, one column per lane (ratio 1.5)
+        (0, 1500, 700, 0, 1200, 600),      # ratio 1.25: 16 rows per tile
+        (0, 1500, 701, 0, 800, 370),       # ratio 1.9: four columns per lane
+        (0, 1800, 900, 0, 600, 301),       # 1H both axes
+        (1, 2600, 1300, 2, 433, 216),      # 2H both axes, channel reorder
+        (8, 2000, 1500, 8, 800, 600),      # 24-bit in and out, four columns per lane
+        (9, 2000, 1500, 0, 1333, 1000),    # 24-bit in, 32-bit out, 0H
+        (4, 2000, 1500, 0, 800, 600),      # unassociated in (premultiplied in LDS), 1H
+        (5, 1500, 700, 1, 1000, 467),      # unassociated in, 0H, four columns per lane
+        (0, 1800, 900, 4, 600, 301),       # unassociated out (LDS inverse table), dword stores
+        (8, 1800, 900, 6, 600, 301),       # 24-bit in, unassociated out
+        (0, 1500, 700, 8, 1000, 467),      # 24-bit out from 32-bit in
+        (0, 2000, 2000, 0, 200, 190),      # box/box, one lane per column
+        (0, 6000, 900, 0, 150, 30),        # box/box, eight lanes per column
+        (0, 2000, 900, 0, 700, 30),        # bilinear H, box V: run-time vertical mode
+        (0, 6000, 300, 0, 150, 120),       # box H, bilinear V
+        (0, 1500, 64, 0, 1000, 200),       # H down, V up (32-row tiles of a magnified axis)
+        (0, 1500, 700, 0, 1000, 700),      # vertical copy
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out) in enumerate(shapes):
+        for sin_pad in (0, 4, 5):
+            sin = w_in * H.bpp(t_in) + sin_pad
+            src = H.make_input(t_in, w_in, h_in, seed=40 + k, valid=False, stride=sin, pad=32)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin_pad)
+        # a strip that starts and ends inside tiles
+        first, n = h_out // 3, h_out // 2
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, None, first, n)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, None, first, n)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "strip")
+
+
 def test_strip_split_determinism():
     """Any partition of the output rows gives the one-shot bytes."""
     rng = random.Random(9)
