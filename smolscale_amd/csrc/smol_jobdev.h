@@ -590,7 +590,10 @@ box_span_host (uint64_t step, uint32_t dim_in, uint32_t k, uint32_t &o0, uint32_
 /* k_boxh + k_boxv: box on both axes in two passes through an intermediate image.
  * Every box/box job of the 128bpp class, and 64bpp-class ones from a vertical ratio
  * of 12 up (below that the single-pass k_tile has enough tiles and wins). */
-constexpr uint32_t BOXH_ROWS_HOST = 8;
+#ifndef SMOL_BOXH_ROWS
+#define SMOL_BOXH_ROWS 4       /* measured: 4000x3000 -> 200x150 thumbnails 129 us with 4 rows per wave, 136 with 8, 145 with 16, 168 with 32 (profiles/r02q_boxh_rows.txt) */
+#endif
+constexpr uint32_t BOXH_ROWS_HOST = SMOL_BOXH_ROWS;
 
 inline bool
 box2_setup (JobDev &d)

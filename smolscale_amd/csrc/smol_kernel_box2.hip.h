@@ -8,7 +8,7 @@
  * waves that each walk 1300 source pixels per row, far too few to fill 256 CUs.
  * Splitting the axes puts the parallelism where the work is:
  *
- *   k_boxh  one wave per 64 output columns x BOXH_ROWS SOURCE rows (h_in / 8 x
+ *   k_boxh  one wave per 64 output columns x BOXH_ROWS SOURCE rows (h_in / 4 x
  *           w_out / 64 waves). Rows arrive in LDS by LDS-DMA (double-buffered, as in
  *           k_tile); a lane sums its column's span (smolscale-generic.c:1427-1556:
  *           left edge weighted, interior in full, right edge weighted, then the
@@ -27,7 +27,7 @@
 
 namespace smolhip {
 
-constexpr uint32_t BOXH_ROWS = 8;       /* source rows per k_boxh wave */
+constexpr uint32_t BOXH_ROWS = dispatch::BOXH_ROWS_HOST;     /* source rows per k_boxh wave */
 
 /* One staged source pixel at byte offset `off' of the LDS row (any alignment). */
 __device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t *rowb, uint32_t off)
@@ -71,6 +71,11 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
     const uint32_t i_begin = (LPC == 1) ? 0u : ((sub * per < n_col) ? sub * per : n_col);
     const uint32_t n_int = (LPC == 1) ? n_col : ((i_begin + per < n_col) ? per : n_col - i_begin);
     const bool edges = (sub == 0);                                  /* the first lane of a group adds both weighted edge pixels */
+    /* 24-bit narrow path: byte masks of the last, partial group of four interior pixels */
+    const uint32_t rem_px = n_int & 3u;
+    const uint32_t rem_mask0 = (rem_px == 0) ? 0u : (rem_px == 1 ? 0x00ffffffu : 0xffffffffu);
+    const uint32_t rem_mask1 = (rem_px <= 1) ? 0u : (rem_px == 2 ? 0x0000ffffu : 0xffffffffu);
+    const uint32_t rem_mask2 = (rem_px == 3) ? 0x000000ffu : 0u;
     const uint32_t g0 = sx0 * bpp, g1 = (sx1 + 1) * bpp;
     const uint32_t row_pitch = J.span_chunks * 16u;
     const uint32_t first_ofs = (o0 - sx0) * bpp;
@@ -159,41 +164,37 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             off = int_ofs + mis;
             if (bpp == 3)
             {
-                /* 24-bit pixels, whole groups of 4 = 12 bytes = 3 dwords (b0 b1 b2 b0 | b1 b2 b0 b1 |
-                 * b2 b0 b1 b2): every dword position is summed in packed 16-bit lanes (at most 64
-                 * groups x 255 per lane) and the twelve partial sums are sorted out once at the end */
+                /* 24-bit pixels in groups of 4 = 12 bytes = 3 dwords (b0 b1 b2 b0 | b1 b2 b0 b1 |
+                 * b2 b0 b1 b2): each channel's four bytes are picked out and summed by three
+                 * v_dot4_u32_u8 with one-hot byte weights -- 9 per group instead of 9 unpacking
+                 * operations + 6 packed adds. The 0-3 pixels left over are one more group with
+                 * the bytes past the span masked off (masks fixed per lane, set up per tile). */
+                constexpr uint32_t W03 = 0x01000001u, W1 = 0x00000100u, W2 = 0x00010000u;
                 const uint32_t ngrp = n_int >> 2;
-                uint32_t s0l = 0, s0h = 0, s1l = 0, s1h = 0, s2l = 0, s2h = 0;
+                uint32_t c0 = 0, c1 = 0, c2 = 0;
                 const uint32_t sh = off & 3u;
                 const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
-                for (uint32_t g = 0; g < J.box_nmax; g += 4, pp += 3)
+                for (uint32_t g = 0; g <= J.box_nmax; g += 4, pp += 3)
                 {
-                    if ((g >> 2) < ngrp)
+                    if ((g >> 2) <= ngrp)
                     {
                         const uint32_t q0 = pp [0], q1 = pp [1], q2 = pp [2], q3 = pp [3];
-                        const uint32_t d0 = __builtin_amdgcn_alignbyte (q1, q0, sh);
-                        const uint32_t d1 = __builtin_amdgcn_alignbyte (q2, q1, sh);
-                        const uint32_t d2 = __builtin_amdgcn_alignbyte (q3, q2, sh);
-                        s0l = as_u32 (as_u16x2 (s0l) + as_u16x2 (d0 & PAIR_MASK));
-                        s0h = as_u32 (as_u16x2 (s0h) + as_u16x2 ((d0 >> 8) & PAIR_MASK));
-                        s1l = as_u32 (as_u16x2 (s1l) + as_u16x2 (d1 & PAIR_MASK));
-                        s1h = as_u32 (as_u16x2 (s1h) + as_u16x2 ((d1 >> 8) & PAIR_MASK));
-                        s2l = as_u32 (as_u16x2 (s2l) + as_u16x2 (d2 & PAIR_MASK));
-                        s2h = as_u32 (as_u16x2 (s2h) + as_u16x2 ((d2 >> 8) & PAIR_MASK));
+                        uint32_t d0 = __builtin_amdgcn_alignbyte (q1, q0, sh);
+                        uint32_t d1 = __builtin_amdgcn_alignbyte (q2, q1, sh);
+                        uint32_t d2 = __builtin_amdgcn_alignbyte (q3, q2, sh);
+                        if ((g >> 2) == ngrp)
+                        {
+                            d0 &= rem_mask0; d1 &= rem_mask1; d2 &= rem_mask2;
+                        }
+                        c0 = smol_udot4 (d0, W03, c0); c0 = smol_udot4 (d1, W2, c0); c0 = smol_udot4 (d2, W1, c0);
+                        c1 = smol_udot4 (d0, W1, c1); c1 = smol_udot4 (d1, W03, c1); c1 = smol_udot4 (d2, W2, c1);
+                        c2 = smol_udot4 (d0, W2, c2); c2 = smol_udot4 (d1, W1, c2); c2 = smol_udot4 (d2, W03, c2);
                     }
                 }
-                /* byte 0 of a pixel: d0.b0 d0.b3 d1.b2 d2.b1; byte 1: d0.b1 d1.b0 d1.b3 d2.b2; byte 2: d0.b2 d1.b1 d2.b0 d2.b3 */
-                const uint32_t b0 = (s0l & 0xffffu) + (s0h >> 16) + (s1l >> 16) + (s2h & 0xffffu);
-                const uint32_t b1 = (s0h & 0xffffu) + (s1l & 0xffffu) + (s1h >> 16) + (s2l >> 16);
-                const uint32_t b2 = (s0l >> 16) + (s1h & 0xffffu) + (s2l & 0xffffu) + (s2h >> 16);
                 Px2 grp;
-                grp.lo = b0 | (b2 << 16);
-                grp.hi = b1 | ((ngrp * 4u * 255u) << 16);                 /* alpha = 0xff per pixel */
+                grp.lo = c0 | (c2 << 16);
+                grp.hi = c1 | ((n_int * 255u) << 16);                     /* alpha = 0xff per pixel */
                 a = px2_add (a, grp);
-                off += ngrp * 12u;
-                /* the 0-3 pixels left over */
-                for (uint32_t k = ngrp * 4u; k < n_int; k++, off += 3u)
-                    a = px2_add (a, px2_from_word (box2_px_word (J, rowb, off)));
             }
             else
             {

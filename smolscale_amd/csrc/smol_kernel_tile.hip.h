@@ -104,10 +104,24 @@ __device__ __forceinline__ Px2 px2_mulw (Px2 v, uint32_t w)
     return r;
 }
 
-/* box normalisation of the four 16-bit sums: scale_64bpp smolscale-generic.c:1231-1245 */
+/* box normalisation of the four 16-bit sums: scale_64bpp smolscale-generic.c:1231-1245. Only bits 24-31 of
+ * c * mul + 2^23 are kept, c is a 16-bit sum and mul = span_mul < 2^21 (a box axis has ratio > 8:
+ * smol_plan.c plan_axis), so the low 32 bits of a 24 x 24 bit multiply are the whole answer. */
 __device__ __forceinline__ uint32_t box_scale16 (uint32_t c, uint32_t mul)
 {
-    return (uint32_t) (((uint64_t) c * mul + (1u << 23)) >> 24) & 0xffu;
+    return ((__umul24 (c, mul) + (1u << 23)) >> 24) & 0xffu;
+}
+
+/* sum of the four byte products a.b[i] * w.b[i], plus acc (v_dot4_u32_u8) */
+__device__ __forceinline__ uint32_t smol_udot4 (uint32_t a, uint32_t w, uint32_t acc)
+{
+#ifdef SMOL_KERNEL_EMU
+    for (int i = 0; i < 4; i++)
+        acc += ((a >> (8 * i)) & 0xffu) * ((w >> (8 * i)) & 0xffu);
+    return acc;
+#else
+    return __builtin_amdgcn_udot4 (a, w, acc, false);
+#endif
 }
 
 __device__ __forceinline__ Px2 px2_box_scale (Px2 a, uint32_t mul)
