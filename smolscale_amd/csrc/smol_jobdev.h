@@ -205,8 +205,9 @@ tile_setup (JobDev &d)
         const uint64_t rows_per_out = d.step_y << d.halv_v;                 /* 32.32 source rows per output row */
         if (d.step_y < ((uint64_t) 1 << 32))
             th = 32;
-        else if (d.wide)
-            th = d.halv_v ? (16u >> d.halv_v) : 8u;                         /* k_wtile: as measured in round 1 */
+        else if (d.wide || (d.unassoc_in && d.bpp_in == 4))
+            th = d.halv_v ? (16u >> d.halv_v) : 8u;                         /* k_wtile, and sources premultiplied group by group in LDS
+                                                                             * (4000x3000 rgbA -> 1600x1200: 8 rows 137 us, 5 rows 146): as in round 1 */
         else if (rows_per_out < ((uint64_t) 14 << 32) / 10)                 /* < 1.4 */
             th = 16;
         else
