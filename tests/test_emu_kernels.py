@@ -215,14 +215,14 @@ def test_emulated_kernels_match_golden_subset():
         assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
 
 
-def _fuzz_tile(rng, dims_fn, n_cases, want_class=3, allow_box=True, max_in=400_000, max_out=8000):
+def _fuzz_tile(rng, dims_fn, n_cases, want_class=3, allow_box=True, max_in=400_000, max_out=8000, dims_h_fn=None):
     import helpers as H
     done = 0
     it = 0
     while done < n_cases:
         it += 1
         w_in, w_out = dims_fn(rng)
-        h_in, h_out = dims_fn(rng)
+        h_in, h_out = (dims_h_fn or dims_fn)(rng)
         if w_in * h_in > max_in or w_out * h_out > max_out:
             continue
         t_in, t_out = rng.randrange(10), rng.randrange(10)
@@ -271,6 +271,28 @@ def test_emulated_tile_kernel_bilinear_family():
         o = rng.randint(65, 200)
         return rng.randint(o + 1, 8 * o), o
     _fuzz_tile(random.Random(2024), dims, 60)
+
+
+def test_emulated_tile_kernel_wide_minification_variants():
+    """Images wide enough (>= 256 output columns) for the entry points with four columns per lane and
+    the vertical mode compiled in: bilinear minification at 0-2 halvings on x, every vertical class on y."""
+    def dims_w(rng):
+        o = rng.randint(256, 330)
+        h = rng.choice([0, 0, 1, 2])
+        return rng.randint((o << h) + 1, min(o << (h + 1), 4 * o + 400)), o
+
+    def dims_h(rng):
+        cls = rng.choice(["copy", "0h", "1h", "2h", "box", "up"])
+        o = rng.randint(1, 14)
+        if cls == "copy":
+            return o, o
+        if cls == "up":
+            return rng.randint(2, 6), rng.randint(7, 20)
+        if cls == "box":
+            return rng.randint(9 * o, 12 * o), o
+        h = {"0h": 0, "1h": 1, "2h": 2}[cls]
+        return rng.randint((o << h) + 1, o << (h + 1)), o
+    _fuzz_tile(random.Random(77), dims_w, 40, max_in=600_000, max_out=8000, dims_h_fn=dims_h)
 
 
 def test_emulated_tile_kernel_box_filters():
