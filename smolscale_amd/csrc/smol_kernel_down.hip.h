@@ -31,6 +31,22 @@ constexpr int DOWN_NL = 3;          /* 16-byte loads per lane per source row, at
 
 typedef uint32_t u32x4a4 __attribute__ ((ext_vector_type (4), aligned (4)));
 
+/* (lo.h * w.lo + hi.h * w.hi) for the 16-bit halves h picked by `sel' (PAIR_LO: the low halves of
+ * `lo' and `hi', PAIR_HI: the high ones), w = packed 16-bit weights: v_perm_b32 + v_dot2_u32_u16.
+ * Exact: halves < 2^16, weights <= 256, the sum of two products fits 32 bits. */
+constexpr uint32_t PAIR_LO = 0x05040100u, PAIR_HI = 0x07060302u;
+
+__device__ __forceinline__ uint32_t pair_dot (uint32_t hi, uint32_t lo, uint32_t sel, uint32_t w)
+{
+    const uint32_t pr = __builtin_amdgcn_perm (hi, lo, sel);
+#ifdef SMOL_KERNEL_EMU
+    return (pr & 0xffffu) * (w & 0xffffu) + (pr >> 16) * (w >> 16);
+#else
+    typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+    return __builtin_amdgcn_udot2 (__builtin_bit_cast (us2, pr), __builtin_bit_cast (us2, w), 0u, false);
+#endif
+}
+
 /* MODE: how a pixel is converted and kept
  *   DOWN_P16   premul16 without sRGB on aligned 32-bit rows: table-free unpack, 16-bit channel pairs
  *   DOWN_GEN16 any other 128bpp-class job whose channels fit 16 bits (sRGB-linear with 8-bit alpha:
@@ -85,6 +101,14 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
 #pragma unroll
         for (uint32_t s = 0; s < NSX; s++)
             tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * PXB;          /* byte offset in the LDS row     */
+    if (MODE == DOWN_P16)
+    {
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (uint32_t s = 0; s < NSX; s++)
+                tap_f [c][s] |= (256u - tap_f [c][s]) << 16;        /* (F, 256 - F) as one packed operand */
+    }
 
     /* ---- vertical schedule (as in k_tile): sample k of the tile in lane k & 63 of sched [k >> 6] */
     const uint32_t hv = J.halv_v;
@@ -274,6 +298,22 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
             for (uint32_t s = 0; s < NSX; s++)
             {
                 const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (buf + tap_ofs [c][s]);
+                if (MODE == DOWN_P16)
+                {
+                    /* p*F + q*(256-F) per channel as ONE v_dot2_u32_u16 on the (p, q) pair a v_perm puts
+                     * side by side, against the packed weights (F, 256 - F). Measured: premul16 ratio 1.5
+                     * 61 -> 57.6 us; the table-driven flavours LOSE 2-8 % with it (profiles/r02u_down_dot2.txt) */
+                    const uint32_t FG = tap_f [c][s];
+                    const uint32_t d0 = pair_dot (pq.z, pq.x, PAIR_LO, FG) >> 8;
+                    const uint32_t d1 = pair_dot (pq.z, pq.x, PAIR_HI, FG) >> 8;
+                    const uint32_t d2 = pair_dot (pq.w, pq.y, PAIR_LO, FG) >> 8;
+                    const uint32_t d3 = pair_dot (pq.w, pq.y, PAIR_HI, FG) >> 8;
+                    hs [0] = s ? hs [0] + d0 : d0;
+                    hs [1] = s ? hs [1] + d1 : d1;
+                    hs [2] = s ? hs [2] + d2 : d2;
+                    hs [3] = s ? hs [3] + d3 : d3;
+                    continue;
+                }
                 const uint32_t F = tap_f [c][s], G = 256u - F;
                 hs [0] += (__umul24 (pq.x & 0xffffu, F) + __umul24 (pq.z & 0xffffu, G)) >> 8;
                 hs [1] += (__umul24 (pq.x >> 16, F) + __umul24 (pq.z >> 16, G)) >> 8;
@@ -301,10 +341,22 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
                     }
                     continue;
                 }
-                const uint32_t t0 = (__umul24 (hp0 [c] & 0xffffu, Fy) + __umul24 (h0 [c] & 0xffffu, G)) >> 8;
-                const uint32_t t1 = (__umul24 (hp0 [c] >> 16, Fy) + __umul24 (h0 [c] >> 16, G)) >> 8;
-                const uint32_t t2 = (__umul24 (hp1 [c] & 0xffffu, Fy) + __umul24 (h1 [c] & 0xffffu, G)) >> 8;
-                const uint32_t t3 = (__umul24 (hp1 [c] >> 16, Fy) + __umul24 (h1 [c] >> 16, G)) >> 8;
+                uint32_t t0, t1, t2, t3;
+                if (MODE == DOWN_P16)
+                {
+                    const uint32_t FGy = Fy | (G << 16);
+                    t0 = pair_dot (h0 [c], hp0 [c], PAIR_LO, FGy) >> 8;
+                    t1 = pair_dot (h0 [c], hp0 [c], PAIR_HI, FGy) >> 8;
+                    t2 = pair_dot (h1 [c], hp1 [c], PAIR_LO, FGy) >> 8;
+                    t3 = pair_dot (h1 [c], hp1 [c], PAIR_HI, FGy) >> 8;
+                }
+                else
+                {
+                    t0 = (__umul24 (hp0 [c] & 0xffffu, Fy) + __umul24 (h0 [c] & 0xffffu, G)) >> 8;
+                    t1 = (__umul24 (hp0 [c] >> 16, Fy) + __umul24 (h0 [c] >> 16, G)) >> 8;
+                    t2 = (__umul24 (hp1 [c] & 0xffffu, Fy) + __umul24 (h1 [c] & 0xffffu, G)) >> 8;
+                    t3 = (__umul24 (hp1 [c] >> 16, Fy) + __umul24 (h1 [c] >> 16, G)) >> 8;
+                }
                 acc [c][0] = s_y ? acc [c][0] + t0 : t0;
                 acc [c][1] = s_y ? acc [c][1] + t1 : t1;
                 acc [c][2] = s_y ? acc [c][2] + t2 : t2;
