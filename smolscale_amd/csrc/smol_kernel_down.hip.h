@@ -31,22 +31,6 @@ constexpr int DOWN_NL = 3;          /* 16-byte loads per lane per source row, at
 
 typedef uint32_t u32x4a4 __attribute__ ((ext_vector_type (4), aligned (4)));
 
-/* (lo.h * w.lo + hi.h * w.hi) for the 16-bit halves h picked by `sel' (PAIR_LO: the low halves of
- * `lo' and `hi', PAIR_HI: the high ones), w = packed 16-bit weights: v_perm_b32 + v_dot2_u32_u16.
- * Exact: halves < 2^16, weights <= 256, the sum of two products fits 32 bits. */
-constexpr uint32_t PAIR_LO = 0x05040100u, PAIR_HI = 0x07060302u;
-
-__device__ __forceinline__ uint32_t pair_dot (uint32_t hi, uint32_t lo, uint32_t sel, uint32_t w)
-{
-    const uint32_t pr = __builtin_amdgcn_perm (hi, lo, sel);
-#ifdef SMOL_KERNEL_EMU
-    return (pr & 0xffffu) * (w & 0xffffu) + (pr >> 16) * (w >> 16);
-#else
-    typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
-    return __builtin_amdgcn_udot2 (__builtin_bit_cast (us2, pr), __builtin_bit_cast (us2, w), 0u, false);
-#endif
-}
-
 /* MODE: how a pixel is converted and kept
  *   DOWN_P16   premul16 without sRGB on aligned 32-bit rows: table-free unpack, 16-bit channel pairs
  *   DOWN_GEN16 any other 128bpp-class job whose channels fit 16 bits (sRGB-linear with 8-bit alpha:

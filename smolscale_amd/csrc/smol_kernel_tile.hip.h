@@ -132,6 +132,22 @@ __device__ __forceinline__ Px2 px2_box_scale (Px2 a, uint32_t mul)
     return r;
 }
 
+/* (lo.h * w.lo + hi.h * w.hi) for the 16-bit halves h picked by `sel' (PAIR_LO: the low halves of
+ * `lo' and `hi', PAIR_HI: the high ones), w = packed 16-bit weights: v_perm_b32 + v_dot2_u32_u16.
+ * Exact: halves < 2^16, weights <= 256, the sum of two products fits 32 bits. */
+constexpr uint32_t PAIR_LO = 0x05040100u, PAIR_HI = 0x07060302u;
+
+__device__ __forceinline__ uint32_t pair_dot (uint32_t hi, uint32_t lo, uint32_t sel, uint32_t w)
+{
+    const uint32_t pr = __builtin_amdgcn_perm (hi, lo, sel);
+#ifdef SMOL_KERNEL_EMU
+    return (pr & 0xffffu) * (w & 0xffffu) + (pr >> 16) * (w >> 16);
+#else
+    typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+    return __builtin_amdgcn_udot2 (__builtin_bit_cast (us2, pr), __builtin_bit_cast (us2, w), 0u, false);
+#endif
+}
+
 /* unassociated -> premultiplied on a whole pixel word; ain = alpha byte index */
 __device__ __forceinline__ uint32_t premul_word (uint32_t w, uint32_t ain)
 {

@@ -271,8 +271,19 @@ constexpr int OUT_W16 = 3;          /* k_up<IN, OUT_W16>: the premul16 flavour *
 constexpr int UP_NSRC_W = 8;        /* source rows per tile (register budget: 2 words per row and column) */
 
 /* (p * F + q * G) >> 8 on both 16-bit halves of packed channel pairs */
+/* DOT: one v_perm + one v_dot2_u32_u16 per half instead of two extractions and two 24-bit multiplies --
+ * premul16 magnification 69 -> 62 us; the table-driven flavours (k_upg) lose 2 % with it, as k_downg does
+ * (profiles/r02u_down_dot2.txt), and keep the multiplies */
+template <bool DOT>
 __device__ __forceinline__ uint32_t up16_tap (uint32_t p, uint32_t q, uint32_t F, uint32_t G)
 {
+    if (DOT)
+    {
+        const uint32_t FG = F | (G << 16);
+        const uint32_t lo = pair_dot (q, p, PAIR_LO, FG) >> 8;
+        const uint32_t hi = pair_dot (q, p, PAIR_HI, FG) >> 8;
+        return lo | (hi << 16);
+    }
     const uint32_t lo = (__umul24 (p & 0xffffu, F) + __umul24 (q & 0xffffu, G)) >> 8;
     const uint32_t hi = (__umul24 (p >> 16, F) + __umul24 (q >> 16, G)) >> 8;
     return lo | (hi << 16);
@@ -379,8 +390,8 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
                 const uint32_t k = (uint32_t) s * span + (tap_ofs [c] - sx0);
                 const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (lds + (size_t) k * 8);
                 const uint32_t F = tap_f [c], G = 256u - F;
-                h_rg [s][c] = up16_tap (pq.x, pq.z, F, G);
-                h_ba [s][c] = up16_tap (pq.y, pq.w, F, G);
+                h_rg [s][c] = up16_tap<true> (pq.x, pq.z, F, G);
+                h_ba [s][c] = up16_tap<true> (pq.y, pq.w, F, G);
             }
         }
     }
@@ -402,8 +413,8 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
 #pragma unroll
             for (int c = 0; c < UP_CPL; c++)
             {
-                const uint32_t rg = up16_tap (h_rg [s][c], h_rg [s + 1][c], F, G);
-                const uint32_t ba = up16_tap (h_ba [s][c], h_ba [s + 1][c], F, G);
+                const uint32_t rg = up16_tap<true> (h_rg [s][c], h_rg [s + 1][c], F, G);
+                const uint32_t ba = up16_tap<true> (h_ba [s][c], h_ba [s + 1][c], F, G);
                 const uint32_t a = ba >> 24;                    /* (alpha lane >> 8) & 0xff */
                 const uint32_t inv = inv_lut [a];
                 /* (s * inv) >> 16 & 0xff (:1036-1100): s < 2^16, inv <= 2^16, the product fits 32 bits */
@@ -583,8 +594,8 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                 else
                 {
                     const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (lds + (size_t) k * 8);
-                    h [s][c][0] = up16_tap (pq.x, pq.z, F, G);
-                    h [s][c][1] = up16_tap (pq.y, pq.w, F, G);
+                    h [s][c][0] = up16_tap<false> (pq.x, pq.z, F, G);
+                    h [s][c][1] = up16_tap<false> (pq.y, pq.w, F, G);
                 }
             }
         }
@@ -618,8 +629,8 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                 }
                 else
                 {
-                    const uint32_t rg = up16_tap (h [s][c][0], h [s + 1][c][0], F, G);
-                    const uint32_t ba = up16_tap (h [s][c][1], h [s + 1][c][1], F, G);
+                    const uint32_t rg = up16_tap<false> (h [s][c][0], h [s + 1][c][0], F, G);
+                    const uint32_t ba = up16_tap<false> (h [s][c][1], h [s + 1][c][1], F, G);
                     v [0] = rg & 0xffffu; v [1] = rg >> 16; v [2] = ba & 0xffffu; v [3] = ba >> 16;
                 }
                 if (vec_ok)
