@@ -409,6 +409,61 @@ def test_batched_images_mixed_types_single_call():
     batch.destroy()
 
 
+def test_ten_thousand_mixed_thumbnails_every_output_checked():
+    """BASELINE config 5 at its full count: 10 000 thumbnails 256^2 -> 64^2, pixel types drawn from the whole
+    10 x 10 table, ONE batch -- and every one of the 10 000 outputs compared with the oracle (each image has
+    its own destination; the sources come from a pool of 8 per input type so that the oracle side is 800
+    scalings, not 10 000)."""
+    rng = random.Random(2025)
+    n_img, pool = 10_000, 8
+    lib = sm.lib()
+    srcs = {(t, k): H.make_input(t, 256, 256, seed=100 * t + k, valid=bool(k & 1), pad=0)
+            for t in range(10) for k in range(pool)}
+    dsrc = {}
+    for key, a in srcs.items():
+        d = sm.DeviceBuffer(a.size)
+        d.upload(a)
+        dsrc[key] = d
+    picks = [(rng.randrange(10), rng.randrange(pool), rng.randrange(10)) for _ in range(n_img)]
+    out_off, total = [], 0
+    for (t_in, k, t_out) in picks:
+        out_off.append(total)
+        total += (64 * 64 * H.bpp(t_out) + 255) & ~255
+    ddst = sm.DeviceBuffer(total)
+    ddst.fill(0x5A)
+    images = []
+    for (t_in, k, t_out), off in zip(picks, out_off):
+        im = sm.SmolHipImage()
+        im.job = H.plan_job(t_in, 256, 256, t_out, 64, 64, 0)
+        im.src, im.dst = dsrc[(t_in, k)].ptr, ddst.ptr + off
+        im.rowstride_in, im.rowstride_out = 256 * H.bpp(t_in), 64 * H.bpp(t_out)
+        im.first_row, im.n_rows = 0, 64
+        images.append(im)
+    batch = sm.HipBatch(images)
+    batch.launch()
+    sm.check(lib.smol_hip_device_synchronize(0))
+    got = ddst.download()
+    want = {}
+    bad = []
+    for i, ((t_in, k, t_out), off) in enumerate(zip(picks, out_off)):
+        key = (t_in, k, t_out)
+        if key not in want:
+            want[key] = H.oracle_scale(srcs[(t_in, k)], t_in, 256, 256, t_out, 64, 64)
+        w = want[key]
+        if not np.array_equal(got[off:off + w.size], w):
+            bad.append((i, key))
+        # the padding between destinations stays untouched
+        pad_end = off + ((w.size + 255) & ~255)
+        if not (got[off + w.size:pad_end] == 0x5A).all():
+            bad.append((i, key, "padding"))
+    assert not bad, bad[:10]
+    assert len(want) > 700
+    batch.destroy()
+    for d in dsrc.values():
+        d.free()
+    ddst.free()
+
+
 def test_post_row_callback_runs_per_row_in_order():
     seen = []
 
