@@ -989,6 +989,39 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
     }
     n_images = (uint32_t) jobs.size ();
 
+    /* Exact 2:1 / 4:1 / 8:1 jobs of several flavours (k_pow2 and the input kinds of k_pow2x) with the same
+     * halvings travel in ONE launch in the caller's order (k_pow2x_mixed_batch) instead of one launch per flavour. */
+    for (uint32_t h = 0; h < 3; h++)
+    {
+        uint32_t seen = 0;                          /* bit per flavour: 0 = k_pow2, 1 + kind = k_pow2x */
+        for (uint32_t i = 0; i < n_images; i++)
+        {
+            if (jobs [i].halv_h != h || jobs [i].halv_v != h)
+                continue;
+            if (cls [i] == KC_POW2)
+                seen |= 1u;
+            else if (cls [i] == KC_POW2X)
+                seen |= 2u << jobs [i].px_kind;
+        }
+        if ((seen & (seen - 1)) == 0 || smolhip::tune_env ("SMOL_BATCH_NO_MIXED_POW2X"))
+            continue;                               /* at most one flavour */
+        for (uint32_t i = 0; i < n_images; i++)
+        {
+            if (jobs [i].halv_h != h || jobs [i].halv_v != h)
+                continue;
+            if (cls [i] == KC_POW2)
+            {
+                JobDev t = jobs [i];
+                if (!pow2x_setup (t))
+                    continue;                       /* stays a k_pow2 job of its own group */
+                jobs [i] = t;
+                cls [i] = KC_POW2X;
+            }
+            if (cls [i] == KC_POW2X)
+                jobs [i].px_mixed = 1;
+        }
+    }
+
     SmolHipBatch *b = new (std::nothrow) SmolHipBatch;
     if (!b)
         return SMOL_HIP_E_INVALID;
@@ -1028,7 +1061,8 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if ((g.k == KC_WAVEPX || g.k == KC_WAVEPX_WIDE) && jobs [j].w_out != g.rep.w_out)
                 continue;
-            if (g.k == KC_POW2X && (jobs [j].halv_h != g.rep.halv_h || jobs [j].px_kind != g.rep.px_kind))
+            if (g.k == KC_POW2X && (jobs [j].halv_h != g.rep.halv_h || jobs [j].px_mixed != g.rep.px_mixed
+                                    || (!g.rep.px_mixed && jobs [j].px_kind != g.rep.px_kind)))
                 continue;
             if (g.k == KC_DOWN && (jobs [j].halv_h != g.rep.halv_h || jobs [j].tile_cpl != g.rep.tile_cpl || jobs [j].down_mode != g.rep.down_mode))
                 continue;

@@ -67,6 +67,7 @@ struct JobDev
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
+    uint8_t px_mixed;              /* k_pow2x: member of a launch that mixes input kinds (batches only): the entry point switches per workgroup */
     uint8_t up_wide;               /* k_up: 0 64bpp class, 1 premul16 fast path, 2 table-driven 16-bit channels, 3 table-driven 32-bit */
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
     uint8_t box2_vlpc;             /* k_boxv: lanes per output pixel (1 or 8)           */

@@ -52,6 +52,11 @@ template <int H>
 void
 launch_pow2x_h (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, hipStream_t s)
 {
+    if (jobs_dev && rep.px_mixed)
+    {
+        hipLaunchKernelGGL ((smolhip::k_pow2x_mixed_batch<H>), grid, dim3 (64, 16), 0, s, jobs_dev);
+        return;
+    }
     switch (rep.px_kind)
     {
         case smolhip::PX_N32: launch_pow2x_k<H, smolhip::PX_N32> (jobs_dev, rep, grid, s); break;

@@ -354,6 +354,26 @@ k_pow2x_batch (const JobDev *__restrict__ jobs)
     pow2x_body<H, IN> (J);
 }
 
+/* A batch that mixes pixel types (BASELINE config 5 as specified: 10 000 thumbnails, types drawn from the
+ * whole table) in ONE launch: workgroups walk the images in the caller's order -- which is address order
+ * for an arena -- and each switches, wave-uniformly, to its job's flavour. Four launches, one per flavour,
+ * each skipping through the arena, lose 8-10 % to their ramps and tails (profiles/r02u_pow2x_types.txt);
+ * running them side by side on forked streams is slower still. */
+template <int H>
+__global__ void __launch_bounds__ (1024)
+k_pow2x_mixed_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = load_job (jobs, blockIdx.z);
+    switch (J.px_kind)
+    {
+        case PX_N32: pow2x_body<H, PX_N32> (J); break;
+        case PX_N24: pow2x_body<H, PX_N24> (J); break;
+        case PX_W32: pow2x_body<H, PX_W32> (J); break;
+        case PX_W16: pow2x_body<H, PX_W16> (J); break;
+        default:     pow2x_body<H, PX_W24> (J); break;
+    }
+}
+
 template <int H, int IN>
 __global__ void __launch_bounds__ (1024)
 k_pow2x_one (const JobDev J)
