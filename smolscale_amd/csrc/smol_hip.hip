@@ -72,9 +72,9 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
     }
     else if (k == KC_BOX2)
     {
-        /* rep.tmp / jobs [i].tmp point at the intermediate images; max_w_out / max_rows
-         * carry the group's largest pass-1 / pass-2 wave counts, max_lds the largest LDS size */
-        L::box2 (jobs_dev, rep, n_jobs, jobs_dev ? max_w_out : box2_h_tiles (rep),
+        /* rep.tmp / jobs [i].tmp point at the intermediate images; max_w_out carries the group's largest
+         * pass-1 grid (box2_h_grid: x | y << 16), max_rows its largest pass-2 wave count, max_lds the largest LDS size */
+        L::box2 (jobs_dev, rep, n_jobs, jobs_dev ? max_w_out : box2_h_grid (rep),
                  jobs_dev ? max_rows : box2_v_tiles (rep), jobs_dev ? max_lds : box2_h_lds_bytes (rep), s);
     }
     else if (k == KC_HSPAN)
@@ -1069,7 +1069,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4 || jobs [j].up_wide != g.rep.up_wide
                                  || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))
                 continue;
-            if (g.k == KC_BOX2 && jobs [j].wide != g.rep.wide)
+            if (g.k == KC_BOX2 && (jobs [j].wide != g.rep.wide || jobs [j].box2_ygroup != g.rep.box2_ygroup))
                 continue;
             if (g.k == KC_HSPAN && (jobs [j].bpp_in != g.rep.bpp_in || jobs [j].halv_h != g.rep.halv_h))
                 continue;
@@ -1081,7 +1081,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if (g.k == KC_BOX2)
             {
                 /* max_w_out / max_rows / max_lds = pass-1 waves / pass-2 waves / pass-1 LDS bytes */
-                if (box2_h_tiles (jobs [j]) > g.max_w_out) g.max_w_out = box2_h_tiles (jobs [j]);
+                g.max_w_out = box2_grid_max (g.max_w_out, box2_h_grid (jobs [j]));
                 if (box2_v_tiles (jobs [j]) > g.max_rows) g.max_rows = box2_v_tiles (jobs [j]);
                 if (box2_h_lds_bytes (jobs [j]) > g.max_lds) g.max_lds = box2_h_lds_bytes (jobs [j]);
                 units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;

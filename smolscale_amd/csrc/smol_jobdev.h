@@ -67,6 +67,7 @@ struct JobDev
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
+    uint8_t box2_ygroup;           /* k_boxh: a workgroup's 4 waves take 4 row groups of one column tile (else 4 column tiles of one row group) */
     uint8_t px_mixed;              /* k_pow2x: member of a launch that mixes input kinds (batches only): the entry point switches per workgroup */
     uint8_t up_wide;               /* k_up: 0 64bpp class, 1 premul16 fast path, 2 table-driven 16-bit channels, 3 table-driven 32-bit */
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
@@ -592,10 +593,18 @@ box_span_host (uint64_t step, uint32_t dim_in, uint32_t k, uint32_t &o0, uint32_
 /* k_boxh + k_boxv: box on both axes in two passes through an intermediate image.
  * Every box/box job of the 128bpp class, and 64bpp-class ones from a vertical ratio
  * of 12 up (below that the single-pass k_tile has enough tiles and wins). */
+/* k_boxh: source rows a wave takes, one after the other through ONE LDS row buffer (no prefetch inside the
+ * wave: the 32 resident waves per CU -- twice what two buffers per wave allow -- cover each other's
+ * latency). 64bpp class: 1 row (4000x3000 -> 200x150: 117-123 us; 4 rows with a second buffer 125-130, 8 rows
+ * 129-137, 32 rows 168); 128bpp class: 4 rows, so that a workgroup's 7 KiB table copy serves 16 rows
+ * (profiles/r02q_boxh_rows.txt). SMOL_BOXH_ROWS / SMOL_BOXH_ROWS_WIDE: build-time overrides for sweeps. */
 #ifndef SMOL_BOXH_ROWS
-#define SMOL_BOXH_ROWS 4       /* measured: 4000x3000 -> 200x150 thumbnails 129 us with 4 rows per wave, 136 with 8, 145 with 16, 168 with 32 (profiles/r02q_boxh_rows.txt) */
+#define SMOL_BOXH_ROWS 1
 #endif
-constexpr uint32_t BOXH_ROWS_HOST = SMOL_BOXH_ROWS;
+#ifndef SMOL_BOXH_ROWS_WIDE
+#define SMOL_BOXH_ROWS_WIDE 4
+#endif
+inline uint32_t boxh_rows (const JobDev &d) { return d.wide ? SMOL_BOXH_ROWS_WIDE : SMOL_BOXH_ROWS; }
 
 inline bool
 box2_setup (JobDev &d)
@@ -625,11 +634,20 @@ box2_setup (JobDev &d)
         span_px = d.w_in;
     const uint32_t bytes = (uint32_t) span_px * d.bpp_in + 15 + 8;
     const uint32_t chunks = (bytes + 15) / 16;
-    if (2u * chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
+    if (chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
         return false;                           /* four waves' row buffers must fit the LDS (nothing of d touched yet) */
 
     d.tile_lpc = (uint8_t) lpc;
     d.box2_vlpc = (d.step_y > (lpc8_min << 16)) ? 8 : 1;
+    {
+        /* pass-1 workgroup shape: 4 column tiles side by side (whole rows, contiguous: 4000x3000 -> 200x150
+         * 122 us against 128) unless that leaves wave slots empty -- 7 column tiles (4096 -> 448): one below the
+         * other 261 us, side by side 300 (profiles/r02q_boxh_rows.txt) */
+        const uint32_t tiles_x = (d.w_out + 64u / lpc - 1u) / (64u / lpc);
+        d.box2_ygroup = (tiles_x % 4u) ? 1 : 0;
+        if (tune_env ("SMOL_BOXH_XGROUP")) d.box2_ygroup = 0;
+        if (tune_env ("SMOL_BOXH_YGROUP")) d.box2_ygroup = 1;
+    }
     d.tmp_row0 = y0;
     d.tmp_row1 = y1;
     d.span_px = (uint32_t) span_px;
@@ -657,7 +675,31 @@ inline uint32_t
 box2_h_tiles (const JobDev &d)
 {
     const uint32_t cols = 64u / d.tile_lpc;
-    return ((d.w_out + cols - 1u) / cols) * ((d.tmp_row1 - d.tmp_row0 + BOXH_ROWS_HOST) / BOXH_ROWS_HOST);
+    return ((d.w_out + cols - 1u) / cols) * ((d.tmp_row1 - d.tmp_row0 + boxh_rows (d)) / boxh_rows (d));
+}
+
+/* pass-1 grid: the 4 waves of a workgroup sit side by side on the same rows (x = groups of 4 column tiles,
+ * y = row groups) when the column tiles come in fours, else one below the other on the same columns
+ * (JobDev::box2_ygroup) -- packed (x | y << 16) so that a batch can carry the per-axis maxima in one word */
+inline uint32_t
+box2_h_grid (const JobDev &d)
+{
+    const uint32_t cols = 64u / d.tile_lpc;
+    uint32_t gx = (d.w_out + cols - 1u) / cols;
+    uint32_t gy = (d.tmp_row1 - d.tmp_row0 + boxh_rows (d)) / boxh_rows (d);
+    if (d.box2_ygroup)
+        gy = (gy + 3u) / 4u;
+    else
+        gx = (gx + 3u) / 4u;
+    return gx | (gy << 16);
+}
+
+inline uint32_t
+box2_grid_max (uint32_t a, uint32_t b)
+{
+    const uint32_t x = (a & 0xffffu) > (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu);
+    const uint32_t y = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+    return x | (y << 16);
 }
 
 inline uint32_t
@@ -670,7 +712,7 @@ box2_v_tiles (const JobDev &d)
 inline uint32_t
 box2_h_lds_bytes (const JobDev &d)
 {
-    return (d.wide ? DOWN_LUT_BYTES_FWD : 0u) + 4u * 2u * d.span_chunks * 16u + 32u;
+    return (d.wide ? DOWN_LUT_BYTES_FWD : 0u) + 4u * d.span_chunks * 16u + 32u;
 }
 
 /* k_hspan (smol_kernel_hspan.hip.h): vertical COPY, horizontal bilinear at (nearly) the power-of-two

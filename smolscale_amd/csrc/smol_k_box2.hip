@@ -15,12 +15,13 @@ using smolhip::JobDev;
 namespace smolhip {
 namespace launch {
 
-/* h_tiles / v_tiles count waves; a workgroup runs 4 of them */
+/* h_grid = pass-1 grid (box2_h_grid: x | y << 16, 4 waves = 4 column tiles per workgroup); v_tiles counts
+ * pass-2 waves, a workgroup runs 4 of them */
 void
-box2 (const JobDev *jobs_dev, const JobDev &rep, uint32_t n_jobs, uint32_t h_tiles, uint32_t v_tiles,
+box2 (const JobDev *jobs_dev, const JobDev &rep, uint32_t n_jobs, uint32_t h_grid, uint32_t v_tiles,
       uint32_t h_lds, hipStream_t s)
 {
-    const dim3 gh ((h_tiles + 3) / 4, n_jobs), gv ((v_tiles + 3) / 4, n_jobs);
+    const dim3 gh (h_grid & 0xffffu, h_grid >> 16, n_jobs), gv ((v_tiles + 3) / 4, n_jobs);
     const uint32_t v_lds = rep.wide ? (uint32_t) ((LUT_LDS_BYTES + 15u) & ~15u) : 0u;
 
     if (rep.wide)

@@ -8,9 +8,12 @@
  * waves that each walk 1300 source pixels per row, far too few to fill 256 CUs.
  * Splitting the axes puts the parallelism where the work is:
  *
- *   k_boxh  one wave per 64 output columns x BOXH_ROWS SOURCE rows (h_in / 4 x
- *           w_out / 64 waves). Rows arrive in LDS by LDS-DMA (double-buffered, as in
- *           k_tile); a lane sums its column's span (smolscale-generic.c:1427-1556:
+ *   k_boxh  one wave per 64 output columns x 1 SOURCE row (4 rows in the 128bpp class, one after the
+ *           other); the 4 waves of a workgroup take 4 neighbouring column tiles of the same row(s),
+ *           grid = (column-tile groups, row groups, jobs). The row arrives in the wave's ONE LDS row
+ *           buffer by LDS-DMA -- no prefetch inside the wave: with a single buffer 32 waves fit a CU and
+ *           cover each other's latency, which measured faster than 20 waves with two buffers each --
+ *           a lane sums its column's span (smolscale-generic.c:1427-1556:
  *           left edge weighted, interior in full, right edge weighted, then the
  *           span_mul normalisation) and writes the horizontal result -- four 16-bit
  *           channels, 8 bytes -- to the intermediate image (coalesced).
@@ -27,7 +30,6 @@
 
 namespace smolhip {
 
-constexpr uint32_t BOXH_ROWS = dispatch::BOXH_ROWS_HOST;     /* source rows per k_boxh wave */
 
 /* One staged source pixel at byte offset `off' of the LDS row (any alignment). */
 __device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t *rowb, uint32_t off)
@@ -41,16 +43,14 @@ __device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t
  * through wave shuffles -- sums of exact integers, so the order does not matter) */
 template <bool WIDE, int LPC>
 __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const uint8_t *lut_lds,
-                                           const uint32_t lane, const uint32_t tile)
+                                           const uint32_t lane, const uint32_t tx, const uint32_t tr)
 {
     constexpr uint32_t COLS = TILE_COLS / LPC;
     const uint32_t sub = lane % LPC;                                /* position in the column's lane group */
-    const uint32_t tiles_x = (J.w_out + COLS - 1) / COLS;
-    const uint32_t tx = tile % tiles_x;
-    const uint32_t tr = tile / tiles_x;
+    constexpr uint32_t BOXH_ROWS = WIDE ? SMOL_BOXH_ROWS_WIDE : SMOL_BOXH_ROWS;     /* source rows per wave (smol_jobdev.h: boxh_rows) */
     const uint32_t r0 = J.tmp_row0 + tr * BOXH_ROWS;                /* first source row of this wave */
 
-    if (r0 > J.tmp_row1)
+    if (r0 > J.tmp_row1 || tx * COLS >= J.w_out)
         return;
 
     const uint32_t r1 = (r0 + BOXH_ROWS - 1 < J.tmp_row1) ? r0 + BOXH_ROWS - 1 : J.tmp_row1;
@@ -61,10 +61,12 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
     const uint32_t bpp = J.bpp_in;
 
     /* the column's span: pixels o0 (weight wl), o0+1 .. o1-1 (in full), o1 (weight fr) */
-    uint32_t o0, o1, fr, wl, sx0, sx1, t0, t1, t2;
+    uint32_t o0, o1, fr, wl;
     box_span (J.step_x, J.w_in, xc, o0, o1, fr, wl);
-    box_span (J.step_x, J.w_in, x0, sx0, t0, t1, t2);
-    box_span (J.step_x, J.w_in, xn - 1, t0, sx1, t1, t2);
+    /* the tile's span: from the first lane's first pixel to the last lane's last (lane 63 sits on column
+     * xn - 1 in full and in partial tiles alike) -- two v_readlane instead of two more 64-bit box_span */
+    const uint32_t sx0 = smol_readlane (o0, 0);
+    const uint32_t sx1 = smol_readlane (o1, 63);
     const uint32_t n_col = o1 - o0 - 1;                             /* interior pixels of the column */
     /* this lane's share of the interior: pixels [i_begin, i_begin + n_int) of it */
     const uint32_t per = (LPC == 1) ? n_col : (n_col + LPC - 1) / LPC;
@@ -77,24 +79,21 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
     const uint32_t rem_mask1 = (rem_px <= 1) ? 0u : (rem_px == 2 ? 0x0000ffffu : 0xffffffffu);
     const uint32_t rem_mask2 = (rem_px == 3) ? 0x000000ffu : 0u;
     const uint32_t g0 = sx0 * bpp, g1 = (sx1 + 1) * bpp;
-    const uint32_t row_pitch = J.span_chunks * 16u;
     const uint32_t first_ofs = (o0 - sx0) * bpp;
     const uint32_t int_ofs = first_ofs + (1u + i_begin) * bpp;      /* first interior pixel of this lane */
     const uint32_t last_ofs = first_ofs + (n_col + 1u) * bpp;       /* the column's last pixel */
     const LutLds lut (lut_lds);
     const uintptr_t src_base = (uintptr_t) J.src;
 
-    tile_stage<true, false> (J, lds, lane, r0, 1, g0, g1);
-
     for (uint32_t r = r0; r <= r1; r++)
     {
-        const uint32_t cur = (r - r0) & 1u;
+        /* one row buffer per wave: request the row, wait for it, sum it (the waves next door fill the gap) */
+        smol_wave_sync ();
+        tile_stage<true, false> (J, lds, lane, r, 1, g0, g1);
         smol_wait_vmcnt0 ();
         smol_wave_sync ();
-        if (r < r1)
-            tile_stage<true, false> (J, lds + (cur ^ 1u) * row_pitch, lane, r + 1, 1, g0, g1);
 
-        const uint8_t *rowb = lds + cur * row_pitch;
+        const uint8_t *rowb = lds;
         const uint32_t mis = (uint32_t) (src_base + (size_t) r * J.src_stride + g0) & 15u;
         uint32_t off = first_ofs + mis;
         u32x2a8 res;
@@ -345,12 +344,17 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     static uint8_t lut_lds [LUT_LDS_BYTES];
     if (WIDE)
         lut_fill_lds (lut_lds, 0, 1);
+    /* host emulation: one wave per block, blocks numbered row group by row group */
+    const uint32_t e_tiles_x = (J.w_out + 64u / J.tile_lpc - 1) / (64u / J.tile_lpc);
     if (J.tile_lpc == 8)
-        boxh_body<WIDE, 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+        boxh_body<WIDE, 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
     else
-        boxh_body<WIDE, 1> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+        boxh_body<WIDE, 1> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
 #else
     const uint32_t wave = threadIdx.x >> 6;
+    /* the workgroup's 4 waves: 4 column tiles of one row group, or 4 row groups of one column tile (box2_setup) */
+    const uint32_t tx = J.box2_ygroup ? blockIdx.x : blockIdx.x * 4u + wave;
+    const uint32_t tr = J.box2_ygroup ? blockIdx.y * 4u + wave : blockIdx.y;
     if (WIDE)
     {
         lut_fill_lds (lds, threadIdx.x, 256);
@@ -358,9 +362,9 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     }
     const uint32_t lut_bytes = WIDE ? ((LUT_LDS_BYTES + 15u) & ~15u) : 0u;
     if (J.tile_lpc == 8)
-        boxh_body<WIDE, 8> (J, lds + lut_bytes + wave * 2u * J.span_chunks * 16u, lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+        boxh_body<WIDE, 8> (J, lds + lut_bytes + wave * J.span_chunks * 16u, lds, threadIdx.x & 63u, tx, tr);
     else
-        boxh_body<WIDE, 1> (J, lds + lut_bytes + wave * 2u * J.span_chunks * 16u, lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+        boxh_body<WIDE, 1> (J, lds + lut_bytes + wave * J.span_chunks * 16u, lds, threadIdx.x & 63u, tx, tr);
 #endif
 }
 
@@ -403,7 +407,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__ (256)
 k_boxh_batch (const JobDev *__restrict__ jobs)
 {
-    const JobDev J = load_job (jobs, blockIdx.y);
+    const JobDev J = load_job (jobs, blockIdx.z);
     boxh_entry<WIDE> (J, smol_dyn_lds);
 }
 

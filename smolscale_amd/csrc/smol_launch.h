@@ -38,7 +38,7 @@ tile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStr
     }
 }
 /* two passes through rep.tmp / jobs [i].tmp; h_tiles, v_tiles = waves of each pass (group maxima) */
-void box2 (const JobDev *jobs_dev, const JobDev &rep, uint32_t n_jobs, uint32_t h_tiles, uint32_t v_tiles,
+void box2 (const JobDev *jobs_dev, const JobDev &rep, uint32_t n_jobs, uint32_t h_grid, uint32_t v_tiles,
            uint32_t h_lds, hipStream_t s);
 void hspan (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
 void wtile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
