@@ -67,6 +67,7 @@ struct JobDev
     uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
+    uint8_t tile_single;           /* k_tile: one staging buffer, no prefetch of the next row group (more resident waves) */
     uint8_t box2_ygroup;           /* k_boxh: a workgroup's 4 waves take 4 row groups of one column tile (else 4 column tiles of one row group) */
     uint8_t px_mixed;              /* k_pow2x: member of a launch that mixes input kinds (batches only): the entry point switches per workgroup */
     uint8_t up_wide;               /* k_up: 0 64bpp class, 1 premul16 fast path, 2 table-driven 16-bit channels, 3 table-driven 32-bit */
@@ -179,6 +180,7 @@ tile_setup (JobDev &d)
     d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / d.span_chunks) + 1;
 
     d.span_px = (uint32_t) span_px;
+    d.tile_single = 0;
     uint32_t budget = TILE_LDS_BUDGET;
     if (const char *e = tune_env ("SMOL_TILE_LDS_BUDGET"))
         budget = (uint32_t) atoi (e);
@@ -270,12 +272,29 @@ tile_setup (JobDev &d)
         d.tile_vm = TILE_VM_BOX;
     d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
     d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);
+
+    /* ONE staging buffer of twice the size and no prefetch of the next row group (the resident waves cover
+     * each other's latency, as in k_boxh) for the entry points where it measured ahead -- compiled in there
+     * (tile_single_variant() in smol_kernel_tile.hip.h states the same condition): unassociated sources
+     * premultiplied in LDS, whose pass likes long groups (4000x3000 rgbA 138 -> 132 us), and 32-bit sources at one
+     * sample and one column per lane under a bilinear vertical filter (4096^2 -> 2731^2 112 -> 106). Elsewhere
+     * equal or behind (box 108 -> 113; profiles/r02w_tile_single.txt). */
+    if (!d.wide && !tune_env ("SMOL_TILE_NO_SINGLE")
+        && (tapsel == 4 || (tapsel == 0 && hm == 1 && d.tile_cpl == 1 && d.tile_vm == TILE_VM_PAIR)))
+    {
+        d.tile_single = 1;
+        uint32_t rows2 = 2 * budget / (d.span_chunks * 16);
+        if (rows2 < 1) rows2 = 1;
+        if (rows2 > 16) rows2 = 16;
+        if (rows2 > d.group_rows)
+            d.group_rows = (uint16_t) rows2;
+    }
 }
 
 inline uint32_t
 tile_lds_bytes (const JobDev &d)
 {
-    uint32_t bytes = 2 * d.group_rows * d.span_chunks * 16 + 32;
+    uint32_t bytes = (d.tile_single ? 1u : 2u) * d.group_rows * d.span_chunks * 16 + 32;
     if (!d.wide && d.unassoc_out)
         bytes += 1024;                          /* k_tile: LDS copy of the inverse-alpha table */
     if (d.wide)

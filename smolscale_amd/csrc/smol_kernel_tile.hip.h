@@ -606,6 +606,10 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     constexpr uint32_t TW = TILE_COLS * CPL / LPC;
     static_assert (!HBOX || CPL == 1, "box columns are one per lane group");
     constexpr bool DMA = (STAGE != TILE_STAGE_REG_PREMUL);
+    /* one staging buffer, no prefetch of the next group: a property of the entry point (smol_jobdev.h sizes the
+     * LDS and the groups for it under the same condition: tile_setup) */
+    constexpr bool single = (STAGE == TILE_STAGE_DMA_PREMUL)
+                            || (STAGE == TILE_STAGE_DMA && TAP == TAP_A4 && HM == 1 && CPL == 1 && VM == TILE_VM_PAIR);
 
     const uint32_t lane = threadIdx.x;
     /* grid = (column tiles, row tiles, jobs): raster order over the tiles, no integer division at the
@@ -774,21 +778,35 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     const uint32_t *inv_tab = nullptr;
     if (OUT == OUT_U4 || (OUT == OUT_ANY && J.unassoc_out))
     {
-        uint8_t *tab = sbuf + 2u * buf_bytes;
+        uint8_t *tab = sbuf + (single ? 1u : 2u) * buf_bytes;
         smol_global_load_lds16 (reinterpret_cast<const uint8_t *> (smol_inv_p8_lut) + lane * 16u, tab, lane);
         if (!DMA)
             smol_wait_vmcnt0 ();
         inv_tab = reinterpret_cast<const uint32_t *> (tab);
     }
 
-    if (DMA && !dbg_nostage)
+    if (DMA && !dbg_nostage && !single)
         tile_stage<true, false> (J, sbuf, lane, gfirst, nrows, g0, g1);
 
     while (true)
     {
         uint8_t *buf = sbuf + cur * buf_bytes;
 
-        if (DMA)
+        if (DMA && single)
+        {
+            /* one buffer: request the group, wait for it (the waves next door fill the gap) */
+            smol_wave_sync ();
+            if (!dbg_nostage)
+                tile_stage<true, false> (J, buf, lane, gfirst, nrows, g0, g1);
+            smol_wait_vmcnt0 ();
+            smol_wave_sync ();
+            if (STAGE == TILE_STAGE_DMA_PREMUL && !dbg_notaps)
+            {
+                tile_premul_lds (J, buf, lane, nrows);
+                smol_wave_sync ();
+            }
+        }
+        else if (DMA)
         {
             /* Retire this group's DMA (issued before the previous group's pixel stores), then start
              * the next group into the other buffer so that it streams in during the consume.
@@ -987,7 +1005,8 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
         if (gfirst > row_last)
             break;
         nrows = (row_last - gfirst + 1 < J.group_rows) ? row_last - gfirst + 1 : J.group_rows;
-        cur ^= 1u;
+        if (!single)
+            cur ^= 1u;
     }
 }
 
