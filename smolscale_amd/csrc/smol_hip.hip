@@ -1179,23 +1179,59 @@ smol_hip_batch_use_graph (SmolHipBatch *batch, int enable)
     HIP_TRY (hipSetDevice (batch->device));
     if (!batch->graph_exec)
     {
-        hipStream_t cs;
+        /* The images are independent: captured on GRAPH_BRANCHES forked streams, so the graph is that many
+         * parallel chains of kernel nodes instead of one chain of n_images (10 000 thumbnails: 28.9 ms as one
+         * chain, 2.9 us per node). */
+        constexpr int GRAPH_BRANCHES = 8;
+        hipStream_t cs, br [GRAPH_BRANCHES] = {};
+        hipEvent_t ev_fork = nullptr, ev_join [GRAPH_BRANCHES] = {};
         HIP_TRY (hipStreamCreateWithFlags (&cs, hipStreamNonBlocking));
-        HIP_TRY (hipStreamBeginCapture (cs, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipSuccess;
-        for (JobDev &jd : batch->jobs_host)
+        hipError_t e = hipEventCreateWithFlags (&ev_fork, hipEventDisableTiming);
+        for (int i = 0; i < GRAPH_BRANCHES && e == hipSuccess; i++)
         {
-            if (jd.n_rows == 0)
-                continue;
-            /* (two-pass jobs keep the intermediate image the batch allocated for them) */
-            uint8_t *tmp_keep = jd.tmp;
-            const KClass kc = classify (jd);
-            jd.tmp = tmp_keep;
-            e = launch_class (kc, nullptr, 1, jd, jd.w_out, jd.n_rows, cs);
-            if (e != hipSuccess)
-                break;
+            e = hipStreamCreateWithFlags (&br [i], hipStreamNonBlocking);
+            if (e == hipSuccess)
+                e = hipEventCreateWithFlags (&ev_join [i], hipEventDisableTiming);
         }
-        hipError_t e2 = hipStreamEndCapture (cs, &batch->graph);
+        hipError_t e2 = hipSuccess;
+        if (e == hipSuccess)
+        {
+            e = hipStreamBeginCapture (cs, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess)
+            {
+                e = hipEventRecord (ev_fork, cs);
+                for (int i = 0; i < GRAPH_BRANCHES && e == hipSuccess; i++)
+                    e = hipStreamWaitEvent (br [i], ev_fork, 0);
+                size_t k = 0;
+                for (JobDev &jd : batch->jobs_host)
+                {
+                    if (e != hipSuccess)
+                        break;
+                    if (jd.n_rows == 0)
+                        continue;
+                    /* (two-pass jobs keep the intermediate image the batch allocated for them) */
+                    uint8_t *tmp_keep = jd.tmp;
+                    const KClass kc = classify (jd);
+                    jd.tmp = tmp_keep;
+                    e = launch_class (kc, nullptr, 1, jd, jd.w_out, jd.n_rows, br [k++ % GRAPH_BRANCHES]);
+                }
+                for (int i = 0; i < GRAPH_BRANCHES; i++)
+                {
+                    hipError_t ej = hipEventRecord (ev_join [i], br [i]);
+                    if (ej == hipSuccess)
+                        ej = hipStreamWaitEvent (cs, ev_join [i], 0);
+                    if (e == hipSuccess)
+                        e = ej;
+                }
+                e2 = hipStreamEndCapture (cs, &batch->graph);
+            }
+        }
+        for (int i = 0; i < GRAPH_BRANCHES; i++)
+        {
+            if (ev_join [i]) (void) hipEventDestroy (ev_join [i]);
+            if (br [i]) (void) hipStreamDestroy (br [i]);
+        }
+        if (ev_fork) (void) hipEventDestroy (ev_fork);
         (void) hipStreamDestroy (cs);
         if (e != hipSuccess)
             return -(int) e;
