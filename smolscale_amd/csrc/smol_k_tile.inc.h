@@ -13,14 +13,45 @@ using smolhip::JobDev;
 namespace {
 
 /* k_tile has one entry point per (tapsel, horizontal mode, columns per lane) */
+/* Workgroup shape. The entry points of the plain 32-bit, one-sample, one-column, bilinear-vertical family
+ * (ratios 1-2: the lightest per-tile work) run 4 (or 3, 2) waves per workgroup on neighbouring column tiles, each in
+ * its own LDS region -- no workgroup barriers in these variants -- when the column tiles divide into such groups
+ * with at most 6 % of the wave slots left empty: neighbouring tiles then share a CU and its L2 instead of landing on
+ * different XCDs (4096^2 -> 2409^2 109 -> 94 us, -> 3413^2 147 -> 131, -> 3034^2 124 -> 116). Everything else keeps
+ * one wave per workgroup: measured mixed elsewhere, from +7 % (ratios 3.5, 6, 7) to -16 % (photographs, rgbA
+ * sources, ratio 5: profiles/r02z_tile_wg.txt). */
+template <int TS, int HM, int CPL, int VM>
+inline uint32_t
+tile_wg_shape (dim3 &grid, dim3 &block, uint32_t &lds_total, uint32_t lds_per_wave)
+{
+    uint32_t nw = 1;
+    const bool family = smolhip::tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM);
+    if (family && !smolhip::tune_env ("SMOL_TILE_WG1"))
+    {
+        for (uint32_t w = 4; w >= 2 && nw == 1; w--)
+        {
+            const uint32_t slots = (grid.x + w - 1) / w * w;
+            if (w * lds_per_wave <= 64u * 1024u && (slots - grid.x) * 100u <= slots * 6u)
+                nw = w;
+        }
+    }
+    block = dim3 (64 * nw);
+    grid.x = (grid.x + nw - 1) / nw;
+    lds_total = nw * lds_per_wave;
+    return nw;
+}
+
 template <int TS, int HM, int CPL>
 void
 launch_tile_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
+    dim3 block;
+    uint32_t lds_total;
+    const uint32_t nw = tile_wg_shape<TS, HM, CPL, smolhip::TILE_VM_ANY> (grid, block, lds_total, lds);
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL>), grid, dim3 (64), lds, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL>), grid, block, lds_total, s, jobs_dev, lds, nw);
     else
-        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, dim3 (64), lds, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, block, lds_total, s, rep, lds, nw);
 }
 
 /* ... and per compiled-in vertical mode (smol_jobdev.h: TILE_VM_*) */
@@ -28,10 +59,13 @@ template <int TS, int HM, int CPL, int VM>
 void
 launch_tile_kv (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
+    dim3 block;
+    uint32_t lds_total;
+    const uint32_t nw = tile_wg_shape<TS, HM, CPL, VM> (grid, block, lds_total, lds);
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL, VM>), grid, dim3 (64), lds, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL, VM>), grid, block, lds_total, s, jobs_dev, lds, nw);
     else
-        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL, VM>), grid, dim3 (64), lds, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL, VM>), grid, block, lds_total, s, rep, lds, nw);
 }
 
 template <int TS>

@@ -336,6 +336,13 @@ __device__ __forceinline__ void smol_wait_vmcnt0 ()
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+/* index of this wave in its workgroup, as a SCALAR (threadIdx.x >> 6 is wave-uniform, but the compiler keeps it
+ * in a vector register, and with it every LDS address and DMA base derived from it) */
+__device__ __forceinline__ uint32_t smol_wave_index ()
+{
+    return (uint32_t) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
+}
+
 /* ordering point for a one-wave workgroup: compiler barrier only */
 __device__ __forceinline__ void smol_wave_sync ()
 {
@@ -404,7 +411,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
         else
         {
             /* dword j of the tile's 192 output bytes starts in pixel a = 4j/3 at byte b = 4j%3 */
-            const uint32_t j = threadIdx.x;
+            const uint32_t j = threadIdx.x & 63u;      /* (a no-op in one-wave workgroups) */
             const uint32_t w = tile_pack<OUT> (J, o [0], inv_tab) & 0x00ffffffu;
             const uint32_t a = (j * 4u) / 3u;
             const uint32_t b = (j * 4u) - a * 3u;
@@ -586,6 +593,13 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
     }
 }
 
+/* entry points that may run several waves per workgroup (smol_k_tile.inc.h: tile_wg_shape): plain 32-bit
+ * source, one sample and one column per lane, bilinear vertical filter, DMA staging */
+__host__ __device__ constexpr bool tile_multiwave_variant (int tap, int hm, int stage, int cpl, int vm)
+{
+    return tap == 0 /* TAP_A4 */ && stage == 0 /* TILE_STAGE_DMA */ && hm == 1 && cpl == 1 && vm == TILE_VM_PAIR;
+}
+
 /* TAP: how taps are read. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples
  * per output column, 4 = box with one lane per column, 5 = box with 8 lanes per
  * column (their partial sums meet through wave shuffles; for wide spans, so that
@@ -594,7 +608,7 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
  * (a tile is 64*CPL columns wide) -- amortises the wave's scalar bookkeeping
  * when there is little vector work per column (magnification). */
 template <int TAP, int HM, int OUT, int STAGE, int CPL, int VM = TILE_VM_ANY>
-__device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
+__device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const uint32_t wg_waves = 1)
 {
     constexpr bool VCOPY = (VM == TILE_VM_COPY);
     constexpr bool HBOX = (HM >= 4);
@@ -611,11 +625,14 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
     constexpr bool single = (STAGE == TILE_STAGE_DMA_PREMUL)
                             || (STAGE == TILE_STAGE_DMA && TAP == TAP_A4 && HM == 1 && CPL == 1 && VM == TILE_VM_PAIR);
 
-    const uint32_t lane = threadIdx.x;
-    /* grid = (column tiles, row tiles, jobs): raster order over the tiles, no integer division at the
-     * head of a workgroup (the XCD-band remap that used to live here served BASELINE config 4, which
-     * k_hspan takes now) */
-    const uint32_t tx = blockIdx.x;
+    /* grid = (groups of column tiles, row tiles, jobs): raster order over the tiles, no integer division at the
+     * head of a workgroup. A workgroup is 1 wave or 4 waves on 4 neighbouring column tiles (smol_k_tile.inc.h);
+     * every wave works alone, in its own LDS region -- the DMA variants have no barriers. */
+    /* (the multi-wave shape exists only for the entry points smol_k_tile.inc.h launches that way; the others keep
+     * their one-wave code to the instruction) */
+    constexpr bool MW = tile_multiwave_variant (TAP, HM, STAGE, CPL, VM);
+    const uint32_t lane = MW ? (threadIdx.x & 63u) : threadIdx.x;
+    const uint32_t tx = MW ? blockIdx.x * wg_waves + smol_wave_index () : blockIdx.x;
     const uint32_t ty = blockIdx.y;
     if (tx * TW >= J.w_out)
         return;
@@ -1011,13 +1028,13 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf)
 }
 
 template <int TAP, int HM, int STAGE, int CPL, int VM = TILE_VM_ANY>
-__device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf)
+__device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf, const uint32_t wg_waves = 1)
 {
     switch (J.tile_variant & 3u)
     {
-        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE, CPL, VM> (J, sbuf); break;
-        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE, CPL, VM> (J, sbuf); break;
-        default:     tile_body<TAP, HM, OUT_ANY, STAGE, CPL, VM> (J, sbuf); break;
+        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE, CPL, VM> (J, sbuf, wg_waves); break;
+        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE, CPL, VM> (J, sbuf, wg_waves); break;
+        default:     tile_body<TAP, HM, OUT_ANY, STAGE, CPL, VM> (J, sbuf, wg_waves); break;
     }
 }
 
@@ -1110,11 +1127,11 @@ extern __shared__ __attribute__ ((aligned (16))) uint8_t smol_dyn_lds [];
  * to the occupancy of the heaviest one (4 columns x 4 samples). TS = tapsel of
  * tile_variant: 0 A4, 1 A4 + premultiply while staging, 2 U4, 3 U3. */
 template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
-__device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf)
+__device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf, const uint32_t wg_waves = 1)
 {
     constexpr int TAP = (TS <= 1 || TS == 4) ? TAP_A4 : (TS == 2 ? TAP_U4 : TAP_U3);
     constexpr int STAGE = (TS == 1) ? TILE_STAGE_REG_PREMUL : (TS == 4 ? TILE_STAGE_DMA_PREMUL : TILE_STAGE_DMA);
-    tile_dispatch_out<TAP, HM, STAGE, CPL, VM> (J, sbuf);
+    tile_dispatch_out<TAP, HM, STAGE, CPL, VM> (J, sbuf, wg_waves);
 }
 
 #ifdef SMOL_KERNEL_EMU
@@ -1125,20 +1142,22 @@ __global__ void k_tile_one (const JobDev J)
 }
 #else
 template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
-__global__ void __launch_bounds__ (64)
-k_tile_batch (const JobDev *__restrict__ jobs)
+__global__ void __launch_bounds__ (tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM) ? 256 : 64)
+k_tile_batch (const JobDev *__restrict__ jobs, const uint32_t lds_per_wave, const uint32_t wg_waves)
 {
     /* private copy: the descriptor must not be re-read from memory after every
      * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
     const JobDev J = load_job (jobs, blockIdx.z);
-    tile_entry<TS, HM, CPL, VM> (J, smol_dyn_lds);
+    constexpr bool MW = tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM);
+    tile_entry<TS, HM, CPL, VM> (J, MW ? smol_dyn_lds + smol_wave_index () * lds_per_wave : smol_dyn_lds, wg_waves);
 }
 
 template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
-__global__ void __launch_bounds__ (64)
-k_tile_one (const JobDev J)
+__global__ void __launch_bounds__ (tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM) ? 256 : 64)
+k_tile_one (const JobDev J, const uint32_t lds_per_wave, const uint32_t wg_waves)
 {
-    tile_entry<TS, HM, CPL, VM> (J, smol_dyn_lds);
+    constexpr bool MW = tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM);
+    tile_entry<TS, HM, CPL, VM> (J, MW ? smol_dyn_lds + smol_wave_index () * lds_per_wave : smol_dyn_lds, wg_waves);
 }
 #endif
 

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #define __device__
+#define __host__
 #define __global__
 #define __forceinline__ inline
 #define __constant__ const
@@ -57,6 +58,7 @@ static inline void smol_global_load_lds16 (const void *gptr, uint8_t *lds_wave_b
 }
 static inline void smol_wait_vmcnt0 (void) {}
 static inline void smol_wave_sync (void) { __syncthreads (); }
+static inline uint32_t smol_wave_index (void) { return 0; }       /* emulated blocks are one wave */
 
 /* v_readlane: every lane of the block calls this with the same idx */
 extern uint32_t emu_lane_xchg [64];

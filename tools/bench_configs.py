@@ -43,6 +43,12 @@ CONFIGS = {
     "R1.5U": (4, 4096, 4096, None, 0, 2731, 2731, 6, "4096^2 RGBA unassociated ->2731^2 RGBA8 premul (0H, ratio 1.5), 6 frames"),
     "HDOWNVUP": (0, 4096, 2048, None, 0, 2731, 3000, 6, "4096x2048->2731x3000 RGBA8 premul (H ratio 1.5 down, V up), 6 frames"),
     "R3": (0, 4096, 4096, None, 0, 1365, 1365, 8, "4096^2->1365^2 RGBA8 premul (1H, ratio 3), 8 frames"),
+    "R1.35": (0, 4096, 4096, None, 0, 3034, 3034, 6, "4096^2->3034^2 RGBA8 premul (0H, ratio 1.35), 6 frames"),
+    "R1.7": (0, 4096, 4096, None, 0, 2409, 2409, 6, "4096^2->2409^2 RGBA8 premul (0H, ratio 1.7), 6 frames"),
+    "R2.5": (0, 4096, 4096, None, 0, 1638, 1638, 8, "4096^2->1638^2 RGBA8 premul (1H, ratio 2.5), 8 frames"),
+    "R3.5": (0, 4096, 4096, None, 0, 1170, 1170, 8, "4096^2->1170^2 RGBA8 premul (1H, ratio 3.5), 8 frames"),
+    "R5": (0, 4096, 4096, None, 0, 819, 819, 8, "4096^2->819^2 RGBA8 premul (2H, ratio 5), 8 frames"),
+    "R7": (0, 4096, 4096, None, 0, 585, 585, 8, "4096^2->585^2 RGBA8 premul (2H, ratio 7), 8 frames"),
     "R6": (0, 4096, 4096, None, 0, 683, 683, 8, "4096^2->683^2 RGBA8 premul (2H, ratio 6), 8 frames"),
     "PHOTO": (8, 4000, 3000, None, 8, 1600, 1200, 12, "4000x3000 RGB8 -> 1600x1200 RGB8 (1H, ratio 2.5), 12 frames"),
     "PNG": (4, 4000, 3000, None, 0, 1600, 1200, 10, "4000x3000 RGBA unassociated -> 1600x1200 RGBA premul (1H), 10 frames"),
