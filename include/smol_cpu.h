@@ -22,6 +22,19 @@ int smol_cpu_scale_rows (const SmolHipJob *job,
                          void *dest, uint32_t rowstride_out,
                          uint32_t first_row, uint32_t n_rows);
 
+/* The same with the per-column tap tables built once: a context that hands out its rows in many small
+ * batches (the reference's row loop, smolscale.c:507-546) pays the O(width_out << halvings) set-up at
+ * creation, not per call. The plan is immutable after creation: any number of threads may scale rows
+ * through one plan at the same time. create returns SMOL_HIP_E_INVALID for a job that smol_hip_plan_job()
+ * could not have produced (filter / halving / pixel type out of range, a bilinear axis of one pixel). */
+typedef struct SmolCpuPlan SmolCpuPlan;
+int smol_cpu_plan_create (const SmolHipJob *job, SmolCpuPlan **plan_out);
+int smol_cpu_plan_scale_rows (const SmolCpuPlan *plan,
+                              const void *pixels_in, uint32_t rowstride_in,
+                              void *dest, uint32_t rowstride_out,
+                              uint32_t first_row, uint32_t n_rows);
+void smol_cpu_plan_destroy (SmolCpuPlan *plan);
+
 #ifdef __cplusplus
 }
 #endif

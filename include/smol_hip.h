@@ -131,7 +131,9 @@ int smol_hip_scale_rows_host (SmolHipPlan *plan,
  * strips in flight together. Rows are independent, so nothing is exchanged between
  * devices. plans [i] may name the same device more than once. With page-locked host
  * memory one host thread drives all devices asynchronously; with pageable memory the
- * strips are handed to the library's persistent worker threads (created once). */
+ * strips are handed to the library's persistent worker threads (created once).
+ * Every plan must have been created for the SAME job (one image, one geometry): a plan
+ * whose job differs from plans [0]'s makes the call return SMOL_HIP_E_INVALID. */
 int smol_hip_scale_rows_host_multi (SmolHipPlan *const *plans, uint32_t n_plans,
                                     const void *pixels_in_host, uint32_t rowstride_in,
                                     void *dest_host, uint32_t rowstride_out,
@@ -154,7 +156,13 @@ int smol_hip_host_unregister (void *host_ptr);
 /* Device-pointer entry: input image and output strip already live in device
  * memory. Asynchronous on `hip_stream' (a hipStream_t, NULL = default stream): no
  * allocation and no synchronisation once the plan is prepared. Concurrent calls on one
- * plan are fine for disjoint row ranges of the same source image. */
+ * plan -- from any threads, on any streams -- are fine: for disjoint row ranges of one source
+ * image and for different source images alike. (The two-pass box filter keeps its intermediate
+ * image in a ring of four buffers owned by the plan, one per image in flight; a fifth
+ * concurrent image queues behind the oldest with hipStreamWaitEvent, and the second to
+ * fourth buffers are allocated on first use. A captured call -- hipStreamBeginCapture --
+ * always uses the first buffer and orders nothing: replays of such a graph must not overlap
+ * other work on the same plan.) */
 int smol_hip_scale_rows_device (SmolHipPlan *plan,
                                 const void *pixels_in_dev, uint32_t rowstride_in,
                                 void *dest_dev, uint32_t rowstride_out,

@@ -547,7 +547,71 @@ free_tables (Ctx *c)
     free (c->h_ofs); free (c->h_f); free (c->h_last); free (c->h_wl); free (c->h_fr);
 }
 
-/* ---- entry point ------------------------------------------------------------------------------------- */
+/* ---- entry points ------------------------------------------------------------------------------------ */
+
+/* A hand-built job (the ABI is reachable through ctypes) must not index outside the tables or the image */
+static int
+job_valid (const SmolHipJob *j)
+{
+    if (j->pixel_type_in >= 10 || j->pixel_type_out >= 10)
+        return 0;
+    if (!j->width_in || !j->height_in || !j->width_out || !j->height_out)
+        return 0;
+    if (j->filter_h > F_BOX || j->filter_v > F_BOX || j->halvings_h > 2 || j->halvings_v > 2)
+        return 0;
+    if ((j->filter_h == F_BILINEAR && j->width_in < 2) || (j->filter_v == F_BILINEAR && j->height_in < 2))
+        return 0;                       /* bilin_tap clamps to dim_in - 2 */
+    if ((j->filter_h == F_COPY && j->width_in != j->width_out) || (j->filter_v == F_COPY && j->height_in != j->height_out))
+        return 0;
+    if ((j->filter_h == F_BOX && (j->step_x >> 16) > j->width_in) || (j->filter_v == F_BOX && (j->step_y >> 16) > j->height_in))
+        return 0;
+    if ((j->filter_h == F_BOX && j->step_x < 0x10000u) || (j->filter_v == F_BOX && j->step_y < 0x10000u))
+        return 0;
+    return 1;
+}
+
+struct SmolCpuPlan
+{
+    SmolHipJob job;
+    Ctx c;
+};
+
+int
+smol_cpu_plan_create (const SmolHipJob *job, SmolCpuPlan **plan_out)
+{
+    SmolCpuPlan *p;
+    int rc;
+
+    if (!job || !plan_out || !job_valid (job))
+        return SMOL_HIP_E_INVALID;
+    p = calloc (1, sizeof (*p));
+    if (!p)
+        return SMOL_HIP_E_INVALID;
+    p->job = *job;
+    p->c.job = &p->job;
+    p->c.ti = &k_types [job->pixel_type_in];
+    p->c.to = &k_types [job->pixel_type_out];
+    p->c.wide = job->wide; p->c.p16 = job->premul16; p->c.linear = job->linear; p->c.quirk24 = job->quirk24;
+    p->c.mask = p->c.wide ? 0x00ffffffu : 0xffu;
+    rc = build_tables (&p->c);
+    if (rc)
+    {
+        free_tables (&p->c);
+        free (p);
+        return rc;
+    }
+    *plan_out = p;
+    return 0;
+}
+
+void
+smol_cpu_plan_destroy (SmolCpuPlan *plan)
+{
+    if (!plan)
+        return;
+    free_tables (&plan->c);
+    free (plan);
+}
 
 int
 smol_cpu_scale_rows (const SmolHipJob *job,
@@ -555,52 +619,55 @@ smol_cpu_scale_rows (const SmolHipJob *job,
                      void *dest, uint32_t rowstride_out,
                      uint32_t first_row, uint32_t n_rows)
 {
-    Ctx c;
+    SmolCpuPlan *plan;
+    int rc;
+
+    if (!job || !pixels_in || !dest)
+        return SMOL_HIP_E_INVALID;
+    if (n_rows == 0)
+        return job_valid (job) ? 0 : SMOL_HIP_E_INVALID;
+    rc = smol_cpu_plan_create (job, &plan);
+    if (rc)
+        return rc;
+    rc = smol_cpu_plan_scale_rows (plan, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
+    smol_cpu_plan_destroy (plan);
+    return rc;
+}
+
+int
+smol_cpu_plan_scale_rows (const SmolCpuPlan *plan,
+                          const void *pixels_in, uint32_t rowstride_in,
+                          void *dest, uint32_t rowstride_out,
+                          uint32_t first_row, uint32_t n_rows)
+{
+    const Ctx *cp;
+    const SmolHipJob *job;
     RowSource rs;
     uint32_t *mem, *vout, *acc;
     uint32_t y, k, x;
     size_t row_lanes_in, row_lanes_out;
-    int rc;
     uint8_t *drow = dest;
 
-    if (!job || !pixels_in || !dest || job->pixel_type_in >= 10 || job->pixel_type_out >= 10)
+    if (!plan || !pixels_in || !dest)
         return SMOL_HIP_E_INVALID;
+    cp = &plan->c;
+    job = &plan->job;
     if (n_rows == 0)
         return 0;
     if (first_row >= job->height_out || n_rows > job->height_out - first_row)
         return SMOL_HIP_E_INVALID;
 
-    memset (&c, 0, sizeof (c));
-    c.job = job;
-    c.ti = &k_types [job->pixel_type_in];
-    c.to = &k_types [job->pixel_type_out];
-    c.wide = job->wide; c.p16 = job->premul16; c.linear = job->linear; c.quirk24 = job->quirk24;
-    c.mask = c.wide ? 0x00ffffffu : 0xffu;
-    rc = build_tables (&c);
-    if (rc)
-    {
-        free_tables (&c);
-        return rc;
-    }
-
 #ifdef SMOL_CPU_X86
-    if (fast_class_ok (&c))
-    {
-        rc = fast_scale_rows (&c, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
-        free_tables (&c);
-        return rc;
-    }
+    if (fast_class_ok (cp))
+        return fast_scale_rows (cp, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
 #endif
 
     row_lanes_in = (size_t) job->width_in * 4;
     row_lanes_out = (size_t) job->width_out * 4;
     mem = malloc ((row_lanes_in + row_lanes_out * 5) * sizeof (uint32_t));
     if (!mem)
-    {
-        free_tables (&c);
         return SMOL_HIP_E_INVALID;
-    }
-    rs.c = &c; rs.src = pixels_in; rs.stride = rowstride_in; rs.next = 0;
+    rs.c = cp; rs.src = pixels_in; rs.stride = rowstride_in; rs.next = 0;
     rs.urow = mem;
     for (k = 0; k < 3; k++)
     {
@@ -612,7 +679,7 @@ smol_cpu_scale_rows (const SmolHipJob *job,
 
     for (y = first_row; y < first_row + n_rows; y++, drow += rowstride_out)
     {
-        const uint32_t mask = c.mask;
+        const uint32_t mask = cp->mask;
 
         if (job->filter_v == F_BILINEAR)
         {
@@ -644,8 +711,8 @@ smol_cpu_scale_rows (const SmolHipJob *job,
             box_span (job->step_y, job->height_in, y, &y0, &y1, &w2, &w1);
             /* 128bpp-class rows weight the last row by w2 - 1 and skip it when w2 == 0
              * (smolscale-generic.c:2236-2253); 64bpp-class rows use w2 as is (:2042-2069) */
-            last_w = c.wide ? (w2 ? w2 - 1 : 0) : w2;
-            y_end = (c.wide && w2 == 0) ? y1 - 1 : y1;
+            last_w = cp->wide ? (w2 ? w2 - 1 : 0) : w2;
+            y_end = (cp->wide && w2 == 0) ? y1 - 1 : y1;
             memset (acc, 0, row_lanes_out * sizeof (uint32_t));
             for (r = y0; r <= y_end; r++)
             {
@@ -658,17 +725,16 @@ smol_cpu_scale_rows (const SmolHipJob *job,
                     for (x = 0; x < row_lanes_out; x++) acc [x] += h [x];
             }
             for (x = 0; x < row_lanes_out; x++)
-                vout [x] = box_scale (&c, acc [x], job->span_mul_y);
+                vout [x] = box_scale (cp, acc [x], job->span_mul_y);
         }
         else
         {
             const uint32_t *h = hrow_get (&rs, job->filter_v == F_ONE ? 0u : y, NULL);
             memcpy (vout, h, row_lanes_out * sizeof (uint32_t));
         }
-        pack_row (&c, vout, job->width_out, drow);
+        pack_row (cp, vout, job->width_out, drow);
     }
 
     free (mem);
-    free_tables (&c);
     return 0;
 }

@@ -144,9 +144,49 @@ constexpr int MAX_DEVICES = 16;
 constexpr uint32_t MAX_CHUNKS = 32;
 constexpr size_t CHUNK_BYTES = 8u << 20;        /* host<->device bytes per pipeline chunk, about */
 
+/* Ownership of a lane: a binary semaphore, not a mutex -- a lane is taken in strip_issue() and given back in
+ * strip_finish(), possibly with other strips of the same thread issued in between (a device listed twice, more
+ * strips than lanes), and try_lock() on a std::mutex the calling thread already owns is undefined behaviour. */
+class LaneGate
+{
+    std::mutex m;
+    std::condition_variable cv;
+    bool busy = false;
+public:
+    bool try_acquire ()
+    {
+        std::lock_guard<std::mutex> g (m);
+        if (busy)
+            return false;
+        busy = true;
+        return true;
+    }
+    void acquire ()
+    {
+        std::unique_lock<std::mutex> lk (m);
+        cv.wait (lk, [this] { return !busy; });
+        busy = true;
+    }
+    void release ()
+    {
+        {
+            std::lock_guard<std::mutex> g (m);
+            busy = false;
+        }
+        cv.notify_one ();
+    }
+};
+
+struct LaneHold
+{
+    LaneGate &g;
+    explicit LaneHold (LaneGate &gate) : g (gate) { g.acquire (); }
+    ~LaneHold () { g.release (); }
+};
+
 struct Lane
 {
-    std::mutex mtx;
+    LaneGate gate;
     bool ready = false;
     hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
     hipEvent_t ev_in [MAX_CHUNKS] = {}, ev_k [MAX_CHUNKS] = {};
@@ -199,7 +239,7 @@ lane_prepare (Lane &ln, size_t src_need, size_t dst_need, size_t tmp_need)
     return rc;
 }
 
-/* caller holds ln.mtx (or nobody can: shutdown) and the device is current */
+/* caller holds the lane (ln.gate) or nobody can (shutdown), and the device is current */
 void
 lane_release (Lane &ln)
 {
@@ -244,7 +284,7 @@ device_release_lanes (int device)
         return;
     for (Lane &ln : g_devices [device].lanes)
     {
-        std::lock_guard<std::mutex> guard (ln.mtx);
+        LaneHold hold (ln.gate);
         lane_release (ln);
     }
 }
@@ -262,7 +302,7 @@ device_trim_lanes (int device)
         return;
     for (Lane &ln : g_devices [device].lanes)
     {
-        std::lock_guard<std::mutex> guard (ln.mtx);
+        LaneHold hold (ln.gate);
         if (ln.src_cap > LANE_KEEP_BYTES || ln.dst_cap > LANE_KEEP_BYTES || ln.tmp_cap > LANE_KEEP_BYTES)
             lane_drain (ln);
         if (ln.src_cap > LANE_KEEP_BYTES) { (void) hipFree (ln.src_buf); ln.src_buf = nullptr; ln.src_cap = 0; }
@@ -285,33 +325,151 @@ host_ptr_is_pinned (const void *p)
 
 } /* namespace */
 
+/* Intermediate image of the two-pass box filter for the device-pointer entry. A plan keeps a small ring of them:
+ * calls for the SAME source image (disjoint strips, any streams) share a slot -- a boundary row two strips both
+ * need gets the same bytes from both -- and calls for DIFFERENT images never meet in one: a new image takes, in
+ * this order, a slot that is idle or was only used by its own stream (stream order protects it), a fresh slot, or
+ * the least recently used one behind hipStreamWaitEvent on every call still using it. */
+constexpr int BOX_SLOTS = 4;
+constexpr int BOX_USERS = 4;
+
+struct BoxUse
+{
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;          /* recorded behind the last call this stream made on the slot */
+    bool pending = false;
+};
+
+struct BoxSlot
+{
+    void *buf = nullptr;
+    const void *src = nullptr;          /* image the slot serves (address of its row 0) */
+    BoxUse use [BOX_USERS];
+    uint64_t tick = 0;
+};
+
 struct SmolHipPlan
 {
     SmolHipJob job;
     int device;
     std::mutex mtx;
-    void *box_scratch = nullptr;        /* device-pointer entry: whole-image intermediate of the two-pass box filter */
-    size_t box_cap = 0;
+    BoxSlot box [BOX_SLOTS];
+    uint64_t box_tick = 0;
 };
 
 namespace {
 
-/* Whole-image intermediate for the device-pointer entry, indexed by absolute source row so
- * that concurrent calls for disjoint strips of one image share it safely (a boundary row
- * two strips both need gets the same bytes from both). */
-int
-plan_box_scratch (SmolHipPlan *plan, void **out)
+size_t
+plan_box_bytes (const SmolHipPlan *plan)
 {
-    const SmolHipJob &j = plan->job;
-    const size_t need = (size_t) j.height_in * j.width_out * 8 + 64;
-    std::lock_guard<std::mutex> guard (plan->mtx);
+    return (size_t) plan->job.height_in * plan->job.width_out * 8 + 64;
+}
 
-    if (!plan->box_scratch)
+int
+box_slot_alloc (SmolHipPlan *plan, BoxSlot &sl)
+{
+    if (!sl.buf)
+        HIP_TRY (hipMalloc (&sl.buf, plan_box_bytes (plan)));
+    for (BoxUse &u : sl.use)
+        if (!u.done)
+            HIP_TRY (hipEventCreateWithFlags (&u.done, hipEventDisableTiming));
+    return 0;
+}
+
+/* no call of another stream is still using the slot */
+bool
+box_slot_free_for (BoxSlot &sl, hipStream_t stream)
+{
+    bool ok = true;
+    for (BoxUse &u : sl.use)
     {
-        HIP_TRY (hipMalloc (&plan->box_scratch, need));
-        plan->box_cap = need;
+        if (u.pending && u.stream != stream && hipEventQuery (u.done) == hipSuccess)
+            u.pending = false;
+        if (u.pending && u.stream != stream)
+            ok = false;
     }
-    *out = plan->box_scratch;
+    (void) hipGetLastError ();          /* hipErrorNotReady from the queries is not an error */
+    return ok;
+}
+
+/* Picks the intermediate image for a call on `stream' reading image `src', makes the stream wait where it has to,
+ * and returns the use entry the caller records behind its kernels. Under stream capture slot 0 is used as it
+ * stands (no events: replays of a captured call must not overlap other work on the same plan -- smol_hip.h).
+ * Called with the plan's mutex held. */
+int
+plan_box_acquire (SmolHipPlan *plan, const void *src, hipStream_t stream, bool capturing,
+                  BoxSlot **slot_out, BoxUse **use_out)
+{
+    BoxSlot *pick = nullptr;
+
+    *use_out = nullptr;
+    if (capturing)
+    {
+        int rc = box_slot_alloc (plan, plan->box [0]);
+        if (rc)
+            return rc;
+        *slot_out = &plan->box [0];
+        return 0;
+    }
+    for (BoxSlot &sl : plan->box)
+        if (sl.buf && sl.src == src)
+            pick = &sl;
+    if (!pick)
+        for (BoxSlot &sl : plan->box)
+            if (sl.buf && box_slot_free_for (sl, stream))
+            {
+                pick = &sl;
+                break;
+            }
+    if (!pick)
+        for (BoxSlot &sl : plan->box)
+            if (!sl.buf)
+            {
+                if (box_slot_alloc (plan, sl) == 0)
+                    pick = &sl;
+                else
+                    (void) hipGetLastError ();   /* out of memory: wait for a slot in use instead */
+                break;
+            }
+    if (!pick)
+    {
+        for (BoxSlot &sl : plan->box)
+            if (sl.buf && (!pick || sl.tick < pick->tick))
+                pick = &sl;
+        if (!pick)
+            return -(int) hipErrorOutOfMemory;
+        for (BoxUse &u : pick->use)
+            if (u.pending && u.stream != stream)
+            {
+                HIP_TRY (hipStreamWaitEvent (stream, u.done, 0));
+                u.pending = false;      /* everything later on `stream' is behind it now */
+            }
+    }
+    int rc = box_slot_alloc (plan, *pick);
+    if (rc)
+        return rc;
+    pick->src = src;
+
+    /* the entry this call's event goes to: the stream's own, else an idle one, else the first -- whose call the
+     * stream then waits for, so that the event recorded behind this call stands for both */
+    BoxUse *use = nullptr;
+    for (BoxUse &u : pick->use)
+        if (u.pending && u.stream == stream)
+            use = &u;
+    if (!use)
+        for (BoxUse &u : pick->use)
+            if (!u.pending)
+            {
+                use = &u;
+                break;
+            }
+    if (!use)
+    {
+        use = &pick->use [0];
+        HIP_TRY (hipStreamWaitEvent (stream, use->done, 0));
+    }
+    *slot_out = pick;
+    *use_out = use;
     return 0;
 }
 
@@ -459,7 +617,7 @@ strip_issue (Strip &st, bool may_block)
     for (int i = 0; i < N_LANES && !ln; i++)
     {
         Lane &cand = ds.lanes [(start + i) % N_LANES];
-        if (cand.mtx.try_lock ())
+        if (cand.gate.try_acquire ())
             ln = &cand;
     }
     if (!ln)
@@ -467,13 +625,13 @@ strip_issue (Strip &st, bool may_block)
         if (!may_block)
             return 1;
         ln = &ds.lanes [start % N_LANES];
-        ln->mtx.lock ();
+        ln->gate.acquire ();
     }
 
     st.rc = strip_issue_locked (st, *ln);
     if (st.rc)
     {
-        ln->mtx.unlock ();
+        ln->gate.release ();
         return st.rc;
     }
     st.lane = ln;
@@ -492,7 +650,7 @@ strip_finish (Strip &st)
     if (e != hipSuccess)
         lane_drain (ln);
     st.lane = nullptr;
-    ln.mtx.unlock ();
+    ln.gate.release ();
     if (e != hipSuccess)
         st.rc = -(int) e;
     return st.rc;
@@ -772,8 +930,19 @@ smol_hip_plan_destroy (SmolHipPlan *plan)
     if (!plan)
         return;
     const int device = plan->device;
-    if (plan->box_scratch && hipSetDevice (device) == hipSuccess)
-        (void) hipFree (plan->box_scratch);
+    if (hipSetDevice (device) == hipSuccess)
+        for (BoxSlot &sl : plan->box)
+        {
+            for (BoxUse &u : sl.use)
+                if (u.done)
+                {
+                    if (u.pending)
+                        (void) hipEventSynchronize (u.done);
+                    (void) hipEventDestroy (u.done);
+                }
+            if (sl.buf)
+                (void) hipFree (sl.buf);
+        }
     delete plan;
 
     /* the last plan on a device gives the big staging slabs back (everything goes in smol_hip_shutdown()) */
@@ -795,8 +964,8 @@ smol_hip_plan_prepare (SmolHipPlan *plan)
     if (j.filter_h != SMOL_HIP_FILTER_BOX || j.filter_v != SMOL_HIP_FILTER_BOX)
         return 0;
     HIP_TRY (hipSetDevice (plan->device));
-    void *p;
-    return plan_box_scratch (plan, &p);
+    std::lock_guard<std::mutex> guard (plan->mtx);
+    return box_slot_alloc (plan, plan->box [0]);
 }
 
 int
@@ -817,22 +986,55 @@ smol_hip_scale_rows_device (SmolHipPlan *plan,
 
     JobDev jd;
     fill_jobdev (jd, plan->job, pixels_in_dev, rowstride_in, dest_dev, rowstride_out, first_row, n_rows);
-    void *scratch = nullptr;
+    JobDev probe = jd;
+    if (classify (probe) != KC_BOX2)
     {
-        JobDev probe = jd;
-        if (classify (probe) == KC_BOX2)
-        {
-            int rc = plan_box_scratch (plan, &scratch);
-            if (rc)
-                return rc;
-            /* the kernels index the intermediate image from the job's first source row:
-             * shift the base so that row r of the image always lands at r * w_out * 8 */
-            scratch = static_cast<uint8_t *> (scratch) + (size_t) probe.tmp_row0 * probe.w_out * 8;
-        }
+        HIP_TRY (launch_single (jd, static_cast<hipStream_t> (hip_stream), nullptr));
+        return 0;
     }
-    HIP_TRY (launch_single (jd, static_cast<hipStream_t> (hip_stream), scratch));
+
+    /* two passes through an intermediate image that belongs to the plan: picked, launched and marked under the
+     * plan's mutex so that two calls cannot choose the same slot for different images */
+    hipStream_t stream = static_cast<hipStream_t> (hip_stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream)
+        HIP_TRY (hipStreamIsCapturing (stream, &cap));
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> guard (plan->mtx);
+    BoxSlot *sl = nullptr;
+    BoxUse *use = nullptr;
+    int rc = plan_box_acquire (plan, pixels_in_dev, stream, capturing, &sl, &use);
+    if (rc)
+        return rc;
+    /* the kernels index the intermediate image from the job's first source row:
+     * shift the base so that row r of the image always lands at r * w_out * 8 */
+    void *scratch = static_cast<uint8_t *> (sl->buf) + (size_t) probe.tmp_row0 * probe.w_out * 8;
+    HIP_TRY (launch_single (jd, stream, scratch));
+    if (use)
+    {
+        HIP_TRY (hipEventRecord (use->done, stream));
+        use->pending = true;
+        use->stream = stream;
+        sl->tick = ++plan->box_tick;
+    }
     return 0;
 }
+
+namespace {
+
+/* field by field: padding and the reserved bytes of a caller-built job carry no meaning */
+bool
+same_job (const SmolHipJob &a, const SmolHipJob &b)
+{
+    return a.width_in == b.width_in && a.height_in == b.height_in && a.width_out == b.width_out
+           && a.height_out == b.height_out && a.pixel_type_in == b.pixel_type_in && a.pixel_type_out == b.pixel_type_out
+           && a.filter_h == b.filter_h && a.filter_v == b.filter_v && a.halvings_h == b.halvings_h
+           && a.halvings_v == b.halvings_v && a.wide == b.wide && a.premul16 == b.premul16 && a.linear == b.linear
+           && a.quirk24 == b.quirk24 && a.span_mul_x == b.span_mul_x && a.span_mul_y == b.span_mul_y
+           && a.frac0_x == b.frac0_x && a.step_x == b.step_x && a.frac0_y == b.frac0_y && a.step_y == b.step_y;
+}
+
+} /* namespace */
 
 int
 smol_hip_scale_rows_host (SmolHipPlan *plan,
@@ -853,8 +1055,8 @@ smol_hip_scale_rows_host_multi (SmolHipPlan *const *plans, uint32_t n_plans,
     if (!plans || !n_plans || n_plans > (uint32_t) MAX_DEVICES || !pixels_in_host || !dest_host)
         return SMOL_HIP_E_INVALID;
     for (uint32_t i = 0; i < n_plans; i++)
-        if (!plans [i])
-            return SMOL_HIP_E_INVALID;
+        if (!plans [i] || !same_job (plans [i]->job, plans [0]->job))
+            return SMOL_HIP_E_INVALID;  /* every strip must belong to the same job (smol_hip.h) */
     if (n_rows == 0)
         return 0;
     if (!rows_ok (first_row, n_rows, plans [0]->job.height_out))

@@ -29,6 +29,15 @@
 namespace smolhip {
 
 constexpr uint32_t TILE_COLS = 64;
+
+/* build-time A/B switches (tools/build_tuning.sh): bit 0 / bit 1 of SMOL_TILE_PREFETCH = software-pipelined tap
+ * reads for the one-column / four-column entry points, SMOL_TILE_BOXBATCH = batched box interior */
+#ifndef SMOL_TILE_PREFETCH
+#define SMOL_TILE_PREFETCH 0    /* measured (profiles/r03a_tile_ab.txt): 2-8 % SLOWER -- the kernel is bound by vector issue, not by LDS latency */
+#endif
+#ifndef SMOL_TILE_BOXBATCH
+#define SMOL_TILE_BOXBATCH 1
+#endif
 constexpr uint32_t PAIR_MASK = 0x00ff00ffu;
 
 struct Px2 { uint32_t lo, hi; };     /* bytes 0,2 and bytes 1,3 of a pixel, 16-bit lanes */
@@ -207,29 +216,52 @@ enum : int
     OUT_ANY = 2     /* 24-bit, or byte-aligned 32-bit (either alpha)    */
 };
 
-/* Pixel pair (p, q) for one tap. rowb: LDS row base (already offset by the row's
- * misalignment), off: byte offset of p inside the span, PAIR: q is the next pixel
- * (bilinear) or p itself (COPY / ONE). */
+/* The raw LDS words of one tap: issued early (the next row's, or a batch of box pixels) so that several
+ * reads are in flight, unpacked when the arithmetic wants them. */
+struct TapRaw { uint32_t d0, d1, d2; };
+
+/* rowb: LDS row base (already offset by the row's misalignment), off: byte offset of p inside the span,
+ * PAIR: q is the next pixel (bilinear) or p itself (COPY / ONE / box). */
 template <int TAP, bool PAIR>
-__device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *rowb, uint32_t off,
-                                                Px2 &p, Px2 &q)
+__device__ __forceinline__ TapRaw tile_tap_load (const uint8_t *rowb, uint32_t off)
+{
+    TapRaw r;
+
+    if (TAP == TAP_A4)
+    {
+        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + off);
+        r.d0 = pp [0];
+        r.d1 = PAIR ? pp [1] : 0u;
+        r.d2 = 0u;
+    }
+    else
+    {
+        /* 4-byte aligned reads around the pixel(s); v_alignbyte does the rest in tile_tap_unpack */
+        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
+        r.d0 = pp [0];
+        r.d1 = pp [1];
+        r.d2 = PAIR ? pp [2] : 0u;
+    }
+    return r;
+}
+
+/* off: the byte offset the words were loaded for (only its low two bits matter here) */
+template <int TAP, bool PAIR>
+__device__ __forceinline__ void tile_tap_unpack (const JobDev &J, const TapRaw &r, uint32_t off, Px2 &p, Px2 &q)
 {
     uint32_t wp, wq;
 
     if (TAP == TAP_A4)
     {
-        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + off);
-        wp = pp [0];
-        wq = PAIR ? pp [1] : wp;
+        wp = r.d0;
+        wq = PAIR ? r.d1 : wp;
     }
     else if (TAP == TAP_U4)
     {
         /* v_alignbyte shifts by the low two bits of its third operand: `off' goes in as is */
-        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
-        const uint32_t d0 = pp [0], d1 = pp [1];
-        wp = __builtin_amdgcn_alignbyte (d1, d0, off);
+        wp = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);
         if (PAIR)
-            wq = __builtin_amdgcn_alignbyte (pp [2], d1, off);
+            wq = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
         else
             wq = wp;
         if (J.unassoc_in)
@@ -241,14 +273,12 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
     }
     else
     {
-        const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
-        const uint32_t d0 = pp [0], d1 = pp [1];
-        const uint32_t b0 = __builtin_amdgcn_alignbyte (d1, d0, off);     /* bytes 0..3 from p */
+        const uint32_t b0 = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);     /* bytes 0..3 from p */
         if (PAIR)
         {
             /* bytes 0..7 from p hold both pixels (p = bytes 0-2, q = bytes 3-5): four v_perm pick
              * the packed halves directly -- selector 0x0c = 0x00, 0x0d = 0xff (the alpha lane) */
-            const uint32_t b1 = __builtin_amdgcn_alignbyte (pp [2], d1, off);
+            const uint32_t b1 = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
             p.lo = __builtin_amdgcn_perm (b1, b0, 0x0c020c00u);
             p.hi = __builtin_amdgcn_perm (b1, b0, 0x0c0d0c01u);
             q.lo = __builtin_amdgcn_perm (b1, b0, 0x0c050c03u);
@@ -261,6 +291,15 @@ __device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *
 
     p = px2_from_word (wp);
     q = PAIR ? px2_from_word (wq) : p;
+}
+
+/* Pixel pair (p, q) for one tap, read and unpacked in one go */
+template <int TAP, bool PAIR>
+__device__ __forceinline__ void tile_read_pair (const JobDev &J, const uint8_t *rowb, uint32_t off,
+                                                Px2 &p, Px2 &q)
+{
+    const TapRaw r = tile_tap_load<TAP, PAIR> (rowb, off);
+    tile_tap_unpack<TAP, PAIR> (J, r, off, p, q);
 }
 
 /* packed pair -> destination pixel word (packers of smolscale-generic.c:758-906) */
@@ -624,6 +663,8 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
      * LDS and the groups for it under the same condition: tile_setup) */
     constexpr bool single = (STAGE == TILE_STAGE_DMA_PREMUL)
                             || (STAGE == TILE_STAGE_DMA && TAP == TAP_A4 && HM == 1 && CPL == 1 && VM == TILE_VM_PAIR);
+    /* software-pipelined tap reads (the next row's LDS words are in flight during this row's arithmetic) */
+    constexpr bool PF = !HBOX && (CPL == 1 ? (SMOL_TILE_PREFETCH & 1) : (SMOL_TILE_PREFETCH & 2)) != 0;
 
     /* grid = (groups of column tiles, row tiles, jobs): raster order over the tiles, no integer division at the
      * head of a workgroup. A workgroup is 1 wave or 4 waves on 4 neighbouring column tiles (smol_k_tile.inc.h);
@@ -709,6 +750,16 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
         for (uint32_t s = 0; s < NSX; s++)
             tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * BPP;   /* byte offset inside the span */
     box_last = (box_last - sx0) * BPP;
+    /* batched box interior: pixels that need no test, and the per-lane masks of the two that do */
+    const uint32_t box_fs = (uint32_t) (J.step_x >> 16);
+    const uint32_t box_nfree = (HBOX && box_fs >= 2u) ? box_fs - 2u : 0u;
+    /* (as values in vector registers, applied with v_and: a v_cndmask on a lane mask held in scalar registers
+     * costs six times a plain vector instruction -- tools/microbench/valu_rate.hip) */
+    uint32_t box_m0 = (box_nfree < box_n) ? 0xffffffffu : 0u;
+    uint32_t box_m1 = (box_nfree + 1u < box_n) ? 0xffffffffu : 0u;
+#ifndef SMOL_KERNEL_EMU
+    asm volatile ("" : "+v" (box_m0), "+v" (box_m1));
+#endif
 
     /* ---- vertical schedule ------------------------------------------------------
      * (source row of the top tap, weight) for every vertical sample of the tile,
@@ -856,6 +907,21 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
         /* ---- consume the staged rows in order ------------------------------------- */
         uint32_t ra_lo = (uint32_t) (src_base + (size_t) gfirst * J.src_stride + g0);   /* low bits of the row's first byte */
         const uint8_t *rowbase = buf;
+        /* PF: the LDS words of row i + 1's taps are requested before row i's arithmetic, so that a row
+         * costs the wave one LDS round trip less (the chain read -> wait -> 26 vector instructions was
+         * 40 % round trip at 5 waves per SIMD) */
+        TapRaw nraw [CPL][NSX];
+        if (PF)
+        {
+            const uint32_t mis0 = ra_lo & 15u;
+            const uint8_t *rowb0 = rowbase + ((TAP == TAP_A4) ? mis0 : 0u);
+            const uint32_t tmis0 = (TAP == TAP_A4) ? 0u : mis0;
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+#pragma unroll
+                for (uint32_t s = 0; s < NSX; s++)
+                    nraw [c][s] = tile_tap_load<TAP, HPAIR> (rowb0, tap_ofs [c][s] + tmis0);
+        }
         for (uint32_t i = 0; i < nrows; i++, ra_lo += J.src_stride, rowbase += row_pitch)
         {
             const uint32_t r = gfirst + i;
@@ -866,6 +932,25 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
             const uint8_t *rowb = rowbase + ((TAP == TAP_A4) ? mis : 0u);
             const uint32_t tmis = (TAP == TAP_A4) ? 0u : mis;
 
+            TapRaw raw [CPL][NSX];
+            if (PF)
+            {
+                /* the last row of a group asks for itself again (wave-uniform select, no branch) */
+                const bool more = i + 1u < nrows;
+                const uint32_t nmis = (ra_lo + (more ? J.src_stride : 0u)) & 15u;
+                const uint8_t *nbase = rowbase + (more ? row_pitch : 0u);
+                const uint8_t *nrowb = nbase + ((TAP == TAP_A4) ? nmis : 0u);
+                const uint32_t ntmis = (TAP == TAP_A4) ? 0u : nmis;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+#pragma unroll
+                    for (uint32_t s = 0; s < NSX; s++)
+                    {
+                        raw [c][s] = nraw [c][s];
+                        nraw [c][s] = tile_tap_load<TAP, HPAIR> (nrowb, tap_ofs [c][s] + ntmis);
+                    }
+            }
+
             Px2 h [CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++)
@@ -873,6 +958,66 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
                 if (dbg_notaps)
                 {
                     h [c].lo = tap_ofs [c][0] + r; h [c].hi = tap_f [c][0];
+                }
+                else if (HBOX && LPC == 1 && SMOL_TILE_BOXBATCH)
+                {
+                    /* One lane per column: both edges and the interior in batches of four independent LDS
+                     * reads. Every column of an axis has fs - 2, fs - 1 or fs interior pixels (fs = floor of
+                     * the ratio; fs - 2 only where the last box is clipped at the image edge): the first
+                     * fs - 2 need no test, the last two are masked per lane (box_m0 / box_m1, set up once per
+                     * tile). The old loop read one pixel, waited, added: eleven LDS round trips per row. */
+                    Px2 pp, qq;
+                    const uint32_t off0 = tap_ofs [0][0] + tmis;
+                    const TapRaw e0 = tile_tap_load<TAP, false> (rowb, off0);
+                    const TapRaw e1 = tile_tap_load<TAP, false> (rowb, box_last + tmis);
+                    uint32_t off = off0 + BPP;
+                    uint32_t left = box_nfree;
+                    Px2 a = { 0, 0 };
+                    while (left >= 4u)
+                    {
+                        TapRaw q4 [4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++)
+                            q4 [k] = tile_tap_load<TAP, false> (rowb, off + k * BPP);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++)
+                        {
+                            tile_tap_unpack<TAP, false> (J, q4 [k], off + k * BPP, pp, qq);
+                            a = px2_add (a, pp);
+                        }
+                        off += 4u * BPP;
+                        left -= 4u;
+                    }
+                    {
+                        /* 0-3 untested pixels, then the two masked ones: one batch of up to five reads */
+                        TapRaw q5 [5];
+#pragma unroll
+                        for (uint32_t k = 0; k < 3; k++)
+                            if (k < left)
+                                q5 [k] = tile_tap_load<TAP, false> (rowb, off + k * BPP);
+                        const uint32_t offm = off + left * BPP;
+                        q5 [3] = tile_tap_load<TAP, false> (rowb, offm);
+                        q5 [4] = tile_tap_load<TAP, false> (rowb, offm + BPP);
+#pragma unroll
+                        for (uint32_t k = 0; k < 3; k++)
+                            if (k < left)
+                            {
+                                tile_tap_unpack<TAP, false> (J, q5 [k], off + k * BPP, pp, qq);
+                                a = px2_add (a, pp);
+                            }
+                        tile_tap_unpack<TAP, false> (J, q5 [3], offm, pp, qq);
+                        pp.lo &= box_m0; pp.hi &= box_m0;
+                        a = px2_add (a, pp);
+                        tile_tap_unpack<TAP, false> (J, q5 [4], offm + BPP, pp, qq);
+                        pp.lo &= box_m1; pp.hi &= box_m1;
+                        a = px2_add (a, pp);
+                    }
+                    /* the edges were requested first and are consumed last */
+                    tile_tap_unpack<TAP, false> (J, e0, off0, pp, qq);
+                    a = px2_add (a, px2_mulw (pp, box_wl));
+                    tile_tap_unpack<TAP, false> (J, e1, box_last + tmis, pp, qq);
+                    a = px2_add (a, px2_mulw (pp, box_fr));
+                    h [c] = px2_box_scale (a, J.span_mul_x);
                 }
                 else if (HBOX)
                 {
@@ -910,7 +1055,10 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
                 else if (HM == 0)
                 {
                     Px2 pp, qq;
-                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, pp, qq);
+                    if (PF)
+                        tile_tap_unpack<TAP, false> (J, raw [c][0], tap_ofs [c][0] + tmis, pp, qq);
+                    else
+                        tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, pp, qq);
                     h [c] = pp;
                 }
                 else
@@ -919,7 +1067,10 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
                     for (uint32_t s = 0; s < NSX; s++)
                     {
                         Px2 pp, qq;
-                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
+                        if (PF)
+                            tile_tap_unpack<TAP, true> (J, raw [c][s], tap_ofs [c][s] + tmis, pp, qq);
+                        else
+                            tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
                         const Px2 t = tap2 (pp, qq, tap_f [c][s]);
                         h [c] = s ? px2_add (h [c], t) : t;
                     }

@@ -49,6 +49,7 @@ struct SmolScaleCtx
     SmolHipPlan *plans [SMOL_MAX_DEVICES];  /* one per device (row sharding)      */
     int n_plans;
     SmolHipJob job;                 /* CPU backend: the planned job                */
+    SmolCpuPlan *cpu_plan;          /* ... and its tap tables, built once          */
 };
 
 /* The seam. init() plans the job and acquires backend resources; batch() must
@@ -185,22 +186,26 @@ static const SmolBackend hip_backend =
 static int
 cpu_backend_init (SmolScaleCtx *ctx)
 {
-    return smol_hip_plan_job (ctx->pixel_type_in, ctx->width_in, ctx->height_in,
-                              ctx->pixel_type_out, ctx->width_out, ctx->height_out,
-                              ctx->with_srgb, &ctx->job);
+    int rc = smol_hip_plan_job (ctx->pixel_type_in, ctx->width_in, ctx->height_in,
+                                ctx->pixel_type_out, ctx->width_out, ctx->height_out,
+                                ctx->with_srgb, &ctx->job);
+    if (rc)
+        return rc;
+    return smol_cpu_plan_create (&ctx->job, &ctx->cpu_plan);
 }
 
 static int
 cpu_backend_batch (const SmolScaleCtx *ctx, void *dest, uint32_t first, uint32_t n)
 {
-    return smol_cpu_scale_rows (&ctx->job, ctx->pixels_in, ctx->rowstride_in,
-                                dest, ctx->rowstride_out, first, n);
+    return smol_cpu_plan_scale_rows (ctx->cpu_plan, ctx->pixels_in, ctx->rowstride_in,
+                                     dest, ctx->rowstride_out, first, n);
 }
 
 static void
 cpu_backend_fini (SmolScaleCtx *ctx)
 {
-    (void) ctx;
+    smol_cpu_plan_destroy (ctx->cpu_plan);
+    ctx->cpu_plan = NULL;
 }
 
 static const SmolBackend cpu_backend =

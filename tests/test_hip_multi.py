@@ -191,6 +191,69 @@ def test_device_pointer_box_path_is_asynchronous_and_capturable():
     plan.destroy()
 
 
+def test_one_box_plan_many_images_on_alternating_streams():
+    """The normal pipelining pattern: ONE per-geometry plan, frame N on stream A while frame N+1 runs on
+    stream B (and more frames than the plan has intermediate buffers, from several threads). The two-pass
+    box filter's intermediate image is per image in flight (ring in the plan), so nothing may leak from one
+    frame into another."""
+    import torch
+    t_in, w_in, h_in, t_out, w_out, h_out = 0, 2600, 1900, 1, 130, 100      # ratio 20 / 19: k_boxh + k_boxv
+    n_frames, rounds = 6, 4
+    dev = torch.device("cuda", 0)
+    frames, wants, dsrcs, ddsts = [], [], [], []
+    for f in range(n_frames):
+        src = H.make_input(t_in, w_in, h_in, seed=100 + f, pad=16)
+        frames.append(src)
+        wants.append(H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out))
+        dsrcs.append(torch.from_numpy(src).to(dev))
+        ddsts.append(torch.zeros(h_out * w_out * 4, dtype=torch.uint8, device=dev))
+    plan = sm.HipPlan(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0), 0)
+    plan.prepare()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_frames)]
+    torch.cuda.synchronize()
+    for rnd in range(rounds):
+        for d in ddsts:
+            d.zero_()
+        torch.cuda.synchronize()
+        # every frame on its own stream, as two strips; nobody waits until all are queued
+        for f in range(n_frames):
+            st = streams[(f + rnd) % n_frames].cuda_stream
+            half = h_out // 2 + (f & 1)
+            plan.scale_rows_device(dsrcs[f].data_ptr(), w_in * 4, ddsts[f].data_ptr(), w_out * 4, 0, half, stream=st)
+            plan.scale_rows_device(dsrcs[f].data_ptr(), w_in * 4, ddsts[f].data_ptr() + half * w_out * 4, w_out * 4,
+                                   half, h_out - half, stream=st)
+        torch.cuda.synchronize()
+        for f in range(n_frames):
+            assert np.array_equal(ddsts[f].cpu().numpy(), wants[f]), (rnd, f)
+    # the same from threads, two strips of one frame on two different streams
+    errs = []
+
+    def worker(f):
+        try:
+            sa, sb = streams[f].cuda_stream, streams[(f + 1) % n_frames].cuda_stream
+            half = h_out // 3
+            for _ in range(5):
+                plan.scale_rows_device(dsrcs[f].data_ptr(), w_in * 4, ddsts[f].data_ptr(), w_out * 4, 0, half, stream=sa)
+                plan.scale_rows_device(dsrcs[f].data_ptr(), w_in * 4, ddsts[f].data_ptr() + half * w_out * 4,
+                                       w_out * 4, half, h_out - half, stream=sb)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    for d in ddsts:
+        d.zero_()
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=worker, args=(f,)) for f in range(n_frames)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for f in range(n_frames):
+        assert np.array_equal(ddsts[f].cpu().numpy(), wants[f]), f
+    plan.destroy()
+
+
 def test_concurrent_callers_share_lanes_and_shutdown_releases_them():
     """8 threads x multi-entry calls on one GPU (lanes are borrowed per call), then
     smol_hip_shutdown() and a further call (lanes and workers come back on demand)."""
