@@ -41,6 +41,27 @@ tile_wg_shape (dim3 &grid, dim3 &block, uint32_t &lds_total, uint32_t lds_per_wa
     return nw;
 }
 
+/* XCD-aware order (smol_kernel_tile.hip.h: TileSwz): a 1-D launch of all workgroups, each XCD taking a contiguous eighth */
+inline smolhip::TileSwz
+tile_swizzle (dim3 &grid)
+{
+    smolhip::TileSwz z = { 0, 0, 0, 0, 0, 0, 0 };
+    const uint64_t gxgy = (uint64_t) grid.x * grid.y;
+    const uint64_t n = gxgy * grid.z;
+
+    if (n < 64 || n * gxgy >= ((uint64_t) 1 << 32) || smolhip::tune_env ("SMOL_TILE_NO_SWZ"))
+        return z;
+    z.on = 1;
+    z.gx = grid.x;
+    z.gxgy = (uint32_t) gxgy;
+    z.inv_gx = (uint32_t) (((uint64_t) 1 << 32) / grid.x) + 1u;
+    z.inv_gxgy = (uint32_t) (((uint64_t) 1 << 32) / gxgy) + 1u;
+    z.q = (uint32_t) (n / 8);
+    z.r = (uint32_t) (n % 8);
+    grid = dim3 ((uint32_t) n);
+    return z;
+}
+
 template <int TS, int HM, int CPL>
 void
 launch_tile_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
@@ -48,10 +69,11 @@ launch_tile_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
     dim3 block;
     uint32_t lds_total;
     const uint32_t nw = tile_wg_shape<TS, HM, CPL, smolhip::TILE_VM_ANY> (grid, block, lds_total, lds);
+    const smolhip::TileSwz swz = tile_swizzle (grid);
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL>), grid, block, lds_total, s, jobs_dev, lds, nw);
+        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL>), grid, block, lds_total, s, jobs_dev, lds, nw, swz);
     else
-        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, block, lds_total, s, rep, lds, nw);
+        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL>), grid, block, lds_total, s, rep, lds, nw, swz);
 }
 
 /* ... and per compiled-in vertical mode (smol_jobdev.h: TILE_VM_*) */
@@ -62,10 +84,11 @@ launch_tile_kv (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t l
     dim3 block;
     uint32_t lds_total;
     const uint32_t nw = tile_wg_shape<TS, HM, CPL, VM> (grid, block, lds_total, lds);
+    const smolhip::TileSwz swz = tile_swizzle (grid);
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL, VM>), grid, block, lds_total, s, jobs_dev, lds, nw);
+        hipLaunchKernelGGL ((smolhip::k_tile_batch<TS, HM, CPL, VM>), grid, block, lds_total, s, jobs_dev, lds, nw, swz);
     else
-        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL, VM>), grid, block, lds_total, s, rep, lds, nw);
+        hipLaunchKernelGGL ((smolhip::k_tile_one<TS, HM, CPL, VM>), grid, block, lds_total, s, rep, lds, nw, swz);
 }
 
 template <int TS>

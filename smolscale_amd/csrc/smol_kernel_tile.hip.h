@@ -38,6 +38,7 @@ constexpr uint32_t TILE_COLS = 64;
 #ifndef SMOL_TILE_BOXBATCH
 #define SMOL_TILE_BOXBATCH 1
 #endif
+
 constexpr uint32_t PAIR_MASK = 0x00ff00ffu;
 
 struct Px2 { uint32_t lo, hi; };     /* bytes 0,2 and bytes 1,3 of a pixel, 16-bit lanes */
@@ -488,8 +489,38 @@ enum : int
 {
     TILE_STAGE_DMA = 0,             /* global_load_lds, double buffered                                   */
     TILE_STAGE_REG_PREMUL = 1,      /* through registers, premultiplying on the way (re-used pixels)      */
-    TILE_STAGE_DMA_PREMUL = 2       /* DMA, then one in-place premultiply pass over the group in LDS      */
+    TILE_STAGE_DMA_PREMUL = 2,      /* DMA, then one in-place premultiply pass over the group in LDS      */
+    TILE_STAGE_RPF = 3,             /* registers hold the NEXT group in flight while LDS holds the one being consumed */
+    TILE_STAGE_RPF_PREMUL = 4       /* ... premultiplying between register and LDS                        */
 };
+
+/* Register-prefetch staging (TILE_STAGE_RPF*). What bounds the DMA variants is the number of bytes the chip has in
+ * flight, and with LDS-DMA that is capped by the LDS itself: every byte in flight needs its landing place there, and
+ * half of a wave's LDS is the group being consumed (profiles/r03a_tile_budget_sweep.txt: 2 to 6 KiB per buffer, 13 to
+ * 32 waves per CU, all within 2 % -- the product is what counts, and it is fixed). Here the landing place is the
+ * register file: a wave keeps TILE_RQ 16-byte chunks per lane (RQ KiB per wave) requested for the whole time it
+ * filters the previous group, then moves them to its ONE LDS buffer (ds_write_b128, lanes contiguous) and asks for
+ * the next group at once. Chunk slot c = u * 64 + lane of a group is (row c / span_chunks, chunk c % span_chunks):
+ * all 64 lanes load whatever the span's width, and a slot's byte offset from the group's first byte is the same for
+ * every group of the tile (e [u], computed once). LDS layout and the row loop are those of the DMA variants. */
+template <int HM, int CPL>
+__host__ __device__ constexpr uint32_t tile_rq ()
+{
+    return (HM == 4 || CPL == 4) ? 6u : 4u;
+}
+
+/* unassociated -> premultiplied on a whole pixel word in packed 16-bit lanes: (c + 1) * (a + 1) - 1 == c * (a + 1) + a
+ * <= 65535, one v_pk_mad_u16 per pair of channels; asel = v_perm selector that splats the alpha byte into both lanes,
+ * amask = 0xff at the alpha byte (smolscale-generic.c:238-244) */
+__device__ __forceinline__ uint32_t premul_word_pk (uint32_t w, uint32_t asel, uint32_t amask)
+{
+    const uint32_t a2 = __builtin_amdgcn_perm (w, w, asel);              /* a | a << 16 */
+    const u16x2 A2 = as_u16x2 (a2), M2 = as_u16x2 (a2 + 0x00010001u);
+    const uint32_t lo = as_u32 ((as_u16x2 (w & PAIR_MASK) * M2 + A2) >> 8);
+    const uint32_t hi = as_u32 ((as_u16x2 (__builtin_amdgcn_perm (w, w, 0x0c030c01u)) * M2 + A2) >> 8);
+    const uint32_t r = lo | (hi << 8);
+    return (r & ~amask) | (w & amask);
+}
 
 /* In-place unassociated -> premultiplied over a staged row group (32-bit pixels on 4-byte
  * boundaries, so every dword of the 16-byte chunks is one pixel): each source pixel is
@@ -498,7 +529,8 @@ enum : int
 __device__ __forceinline__ void tile_premul_lds (const JobDev &J, uint8_t *buf, uint32_t lane, uint32_t nrows)
 {
     const uint32_t total = nrows * J.span_chunks;
-    const uint32_t ain = J.pos_in [3];
+    const uint32_t apos = J.pos_in [3] & 3u;
+    const uint32_t asel = 0x0c000c00u | apos | (apos << 16), amask = 0xffu << (8u * apos);
 
     for (uint32_t c0 = 0; c0 < total; c0 += 2u * TILE_COLS)
     {
@@ -516,10 +548,10 @@ __device__ __forceinline__ void tile_premul_lds (const JobDev &J, uint8_t *buf, 
             const uint32_t c = c0 + u * TILE_COLS + lane;
             if (c < total)
             {
-                v [u].x = premul_word (v [u].x, ain);
-                v [u].y = premul_word (v [u].y, ain);
-                v [u].z = premul_word (v [u].z, ain);
-                v [u].w = premul_word (v [u].w, ain);
+                v [u].x = premul_word_pk (v [u].x, asel, amask);
+                v [u].y = premul_word_pk (v [u].y, asel, amask);
+                v [u].z = premul_word_pk (v [u].z, asel, amask);
+                v [u].w = premul_word_pk (v [u].w, asel, amask);
                 *reinterpret_cast<u32x4 *> (buf + (size_t) c * 16) = v [u];
             }
         }
@@ -632,11 +664,53 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
     }
 }
 
+#ifdef SMOL_KERNEL_EMU
+__device__ __forceinline__ u32x4 tile_load_chunk (uintptr_t a) { return *reinterpret_cast<const u32x4 *> (a); }
+#else
+__device__ __forceinline__ u32x4 tile_load_chunk (uintptr_t a)
+{
+    return __builtin_nontemporal_load (reinterpret_cast<const SMOL_AS_GLOBAL u32x4 *> (a));
+}
+#endif
+
+/* Request the group of source rows [gfirst, gfirst + nrows) into the register ring. e [u]: byte offset of slot
+ * u * 64 + lane from the group's first byte (0 for the slots past the group). A slot's address is the 16-byte
+ * frame that holds that byte: (G + e) & ~15. `edge': the group is short or holds the image's last row -- slots are
+ * then checked one by one, so that no frame without a byte of the image is touched (a frame with one cannot
+ * fault: it lies in that byte's page). */
+template <uint32_t RQ>
+__device__ __forceinline__ void tile_rpf_issue (const JobDev &J, u32x4 (&ring) [RQ], const uint32_t (&e) [RQ], uint32_t lane,
+                                                uint32_t gfirst, uint32_t nrows, uint32_t g0, uint32_t g1, bool edge)
+{
+    const uintptr_t G = (uintptr_t) J.src + (size_t) gfirst * J.src_stride + g0;
+    const uintptr_t Gb = G & ~(uintptr_t) 15;
+    const uint32_t m0 = (uint32_t) G & 15u;
+
+    if (!edge)
+    {
+#pragma unroll
+        for (uint32_t u = 0; u < RQ; u++)
+            ring [u] = tile_load_chunk (Gb + ((m0 + e [u]) & ~15u));
+        return;
+    }
+    const uint32_t span15 = g1 - g0 + 15u;
+#pragma unroll
+    for (uint32_t u = 0; u < RQ; u++)
+    {
+        const uint32_t c = u * TILE_COLS + lane;
+        const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
+        const uint32_t k = c - i * J.span_chunks;
+        const uint32_t mis = (m0 + e [u]) & 15u;
+        const bool ok = (i < nrows) && (k * 16u < ((mis + span15) & ~15u));
+        ring [u] = tile_load_chunk (Gb + (ok ? ((m0 + e [u]) & ~15u) : 0u));
+    }
+}
+
 /* entry points that may run several waves per workgroup (smol_k_tile.inc.h: tile_wg_shape): plain 32-bit
  * source, one sample and one column per lane, bilinear vertical filter, DMA staging */
 __host__ __device__ constexpr bool tile_multiwave_variant (int tap, int hm, int stage, int cpl, int vm)
 {
-    return tap == 0 /* TAP_A4 */ && stage == 0 /* TILE_STAGE_DMA */ && hm == 1 && cpl == 1 && vm == TILE_VM_PAIR;
+    return tap == 0 /* TAP_A4 */ && (stage == 0 /* TILE_STAGE_DMA */ || stage == 3 /* TILE_STAGE_RPF */) && hm == 1 && cpl == 1 && vm == TILE_VM_PAIR;
 }
 
 /* TAP: how taps are read. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples
@@ -647,7 +721,7 @@ __host__ __device__ constexpr bool tile_multiwave_variant (int tap, int hm, int 
  * (a tile is 64*CPL columns wide) -- amortises the wave's scalar bookkeeping
  * when there is little vector work per column (magnification). */
 template <int TAP, int HM, int OUT, int STAGE, int CPL, int VM = TILE_VM_ANY>
-__device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const uint32_t wg_waves = 1)
+__device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const uint32_t bx, const uint32_t by, const uint32_t wg_waves = 1)
 {
     constexpr bool VCOPY = (VM == TILE_VM_COPY);
     constexpr bool HBOX = (HM >= 4);
@@ -658,10 +732,12 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     constexpr uint32_t BPP = (TAP == TAP_U3) ? 3u : 4u;
     constexpr uint32_t TW = TILE_COLS * CPL / LPC;
     static_assert (!HBOX || CPL == 1, "box columns are one per lane group");
-    constexpr bool DMA = (STAGE != TILE_STAGE_REG_PREMUL);
+    constexpr bool RPF = (STAGE == TILE_STAGE_RPF || STAGE == TILE_STAGE_RPF_PREMUL);
+    constexpr uint32_t RQ = tile_rq<HM, CPL> ();
+    constexpr bool DMA = (STAGE != TILE_STAGE_REG_PREMUL) && !RPF;
     /* one staging buffer, no prefetch of the next group: a property of the entry point (smol_jobdev.h sizes the
      * LDS and the groups for it under the same condition: tile_setup) */
-    constexpr bool single = (STAGE == TILE_STAGE_DMA_PREMUL)
+    constexpr bool single = (STAGE == TILE_STAGE_DMA_PREMUL) || RPF
                             || (STAGE == TILE_STAGE_DMA && TAP == TAP_A4 && HM == 1 && CPL == 1 && VM == TILE_VM_PAIR);
     /* software-pipelined tap reads (the next row's LDS words are in flight during this row's arithmetic) */
     constexpr bool PF = !HBOX && (CPL == 1 ? (SMOL_TILE_PREFETCH & 1) : (SMOL_TILE_PREFETCH & 2)) != 0;
@@ -673,8 +749,8 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
      * their one-wave code to the instruction) */
     constexpr bool MW = tile_multiwave_variant (TAP, HM, STAGE, CPL, VM);
     const uint32_t lane = MW ? (threadIdx.x & 63u) : threadIdx.x;
-    const uint32_t tx = MW ? blockIdx.x * wg_waves + smol_wave_index () : blockIdx.x;
-    const uint32_t ty = blockIdx.y;
+    const uint32_t tx = MW ? bx * wg_waves + smol_wave_index () : bx;
+    const uint32_t ty = by;
     if (tx * TW >= J.w_out)
         return;
     const uint32_t yrel0 = ty * J.tile_rows;
@@ -846,7 +922,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     const uint32_t *inv_tab = nullptr;
     if (OUT == OUT_U4 || (OUT == OUT_ANY && J.unassoc_out))
     {
-        uint8_t *tab = sbuf + (single ? 1u : 2u) * buf_bytes;
+        uint8_t *tab = sbuf + (RPF ? RQ * 1024u : (single ? 1u : 2u) * buf_bytes);
         smol_global_load_lds16 (reinterpret_cast<const uint8_t *> (smol_inv_p8_lut) + lane * 16u, tab, lane);
         if (!DMA)
             smol_wait_vmcnt0 ();
@@ -856,11 +932,60 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     if (DMA && !dbg_nostage && !single)
         tile_stage<true, false> (J, sbuf, lane, gfirst, nrows, g0, g1);
 
+    /* register prefetch: slot offsets (the same for every group of the tile), first group requested */
+    u32x4 ring [RQ];
+    uint32_t ring_e [RQ];
+    const uint32_t rpf_apos = J.pos_in [3] & 3u;          /* (0xff for 24-bit sources, which are never premultiplied) */
+    const uint32_t rpf_asel = 0x0c000c00u | rpf_apos | (rpf_apos << 16);
+    const uint32_t rpf_amask = 0xffu << (8u * rpf_apos);
+    if (RPF)
+    {
+#pragma unroll
+        for (uint32_t u = 0; u < RQ; u++)
+        {
+            const uint32_t c = u * TILE_COLS + lane;
+            const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
+            const uint32_t k = c - i * J.span_chunks;
+            ring_e [u] = (i < J.group_rows) ? i * J.src_stride + k * 16u : 0u;
+            ring [u] = u32x4 { 0, 0, 0, 0 };
+        }
+        if (!dbg_nostage)
+            tile_rpf_issue<RQ> (J, ring, ring_e, lane, gfirst, nrows, g0, g1,
+                                nrows < J.group_rows || gfirst + nrows >= J.h_in);
+    }
+
     while (true)
     {
         uint8_t *buf = sbuf + cur * buf_bytes;
 
-        if (DMA && single)
+        if (RPF)
+        {
+            /* the previous group has been consumed (LDS operations of a wave complete in order): park this one in
+             * LDS -- the compiler's own s_waitcnt guards the ring registers -- and request the next */
+            smol_wave_sync ();
+#pragma unroll
+            for (uint32_t u = 0; u < RQ; u++)
+            {
+                u32x4 v = ring [u];
+                if (STAGE == TILE_STAGE_RPF_PREMUL && !dbg_notaps)
+                {
+                    v.x = premul_word_pk (v.x, rpf_asel, rpf_amask);
+                    v.y = premul_word_pk (v.y, rpf_asel, rpf_amask);
+                    v.z = premul_word_pk (v.z, rpf_asel, rpf_amask);
+                    v.w = premul_word_pk (v.w, rpf_asel, rpf_amask);
+                }
+                *reinterpret_cast<u32x4 *> (buf + (u * TILE_COLS + lane) * 16u) = v;
+            }
+            smol_wave_sync ();
+            const uint32_t nfirst = gfirst + nrows;
+            if (nfirst <= row_last && !dbg_nostage)
+            {
+                const uint32_t nn = (row_last - nfirst + 1 < J.group_rows) ? row_last - nfirst + 1 : J.group_rows;
+                tile_rpf_issue<RQ> (J, ring, ring_e, lane, nfirst, nn, g0, g1,
+                                    nn < J.group_rows || nfirst + nn >= J.h_in);
+            }
+        }
+        else if (DMA && single)
         {
             /* one buffer: request the group, wait for it (the waves next door fill the gap) */
             smol_wave_sync ();
@@ -1179,13 +1304,13 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
 }
 
 template <int TAP, int HM, int STAGE, int CPL, int VM = TILE_VM_ANY>
-__device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf, const uint32_t wg_waves = 1)
+__device__ __forceinline__ void tile_dispatch_out (const JobDev &J, uint8_t *sbuf, const uint32_t bx, const uint32_t by, const uint32_t wg_waves = 1)
 {
     switch (J.tile_variant & 3u)
     {
-        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE, CPL, VM> (J, sbuf, wg_waves); break;
-        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE, CPL, VM> (J, sbuf, wg_waves); break;
-        default:     tile_body<TAP, HM, OUT_ANY, STAGE, CPL, VM> (J, sbuf, wg_waves); break;
+        case OUT_P4: tile_body<TAP, HM, OUT_P4, STAGE, CPL, VM> (J, sbuf, bx, by, wg_waves); break;
+        case OUT_U4: tile_body<TAP, HM, OUT_U4, STAGE, CPL, VM> (J, sbuf, bx, by, wg_waves); break;
+        default:     tile_body<TAP, HM, OUT_ANY, STAGE, CPL, VM> (J, sbuf, bx, by, wg_waves); break;
     }
 }
 
@@ -1200,17 +1325,17 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
         if (J.tile_vm == TILE_VM_PAIR)
             switch (hm)
             {
-                case 1:  tile_dispatch_out<TAP, 1, STAGE, 4, TILE_VM_PAIR> (J, sbuf); break;
-                case 2:  tile_dispatch_out<TAP, 2, STAGE, 4, TILE_VM_PAIR> (J, sbuf); break;
-                default: tile_dispatch_out<TAP, 3, STAGE, 4, TILE_VM_PAIR> (J, sbuf); break;
+                case 1:  tile_dispatch_out<TAP, 1, STAGE, 4, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
+                case 2:  tile_dispatch_out<TAP, 2, STAGE, 4, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
+                default: tile_dispatch_out<TAP, 3, STAGE, 4, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
             }
         else
             switch (hm)
             {
-                case 0:  tile_dispatch_out<TAP, 0, STAGE, 4> (J, sbuf); break;
-                case 1:  tile_dispatch_out<TAP, 1, STAGE, 4> (J, sbuf); break;
-                case 2:  tile_dispatch_out<TAP, 2, STAGE, 4> (J, sbuf); break;
-                default: tile_dispatch_out<TAP, 3, STAGE, 4> (J, sbuf); break;
+                case 0:  tile_dispatch_out<TAP, 0, STAGE, 4> (J, sbuf, blockIdx.x, blockIdx.y); break;
+                case 1:  tile_dispatch_out<TAP, 1, STAGE, 4> (J, sbuf, blockIdx.x, blockIdx.y); break;
+                case 2:  tile_dispatch_out<TAP, 2, STAGE, 4> (J, sbuf, blockIdx.x, blockIdx.y); break;
+                default: tile_dispatch_out<TAP, 3, STAGE, 4> (J, sbuf, blockIdx.x, blockIdx.y); break;
             }
         return;
     }
@@ -1219,9 +1344,9 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
     {
         switch (hm)
         {
-            case 1:  tile_dispatch_out<TAP, 1, STAGE, 1, TILE_VM_COPY> (J, sbuf); break;
-            case 2:  tile_dispatch_out<TAP, 2, STAGE, 1, TILE_VM_COPY> (J, sbuf); break;
-            default: tile_dispatch_out<TAP, 3, STAGE, 1, TILE_VM_COPY> (J, sbuf); break;
+            case 1:  tile_dispatch_out<TAP, 1, STAGE, 1, TILE_VM_COPY> (J, sbuf, blockIdx.x, blockIdx.y); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE, 1, TILE_VM_COPY> (J, sbuf, blockIdx.x, blockIdx.y); break;
+            default: tile_dispatch_out<TAP, 3, STAGE, 1, TILE_VM_COPY> (J, sbuf, blockIdx.x, blockIdx.y); break;
         }
         return;
     }
@@ -1229,29 +1354,29 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
     {
         switch (hm)
         {
-            case 1:  tile_dispatch_out<TAP, 1, STAGE, 1, TILE_VM_PAIR> (J, sbuf); break;
-            case 2:  tile_dispatch_out<TAP, 2, STAGE, 1, TILE_VM_PAIR> (J, sbuf); break;
-            default: tile_dispatch_out<TAP, 3, STAGE, 1, TILE_VM_PAIR> (J, sbuf); break;
+            case 1:  tile_dispatch_out<TAP, 1, STAGE, 1, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE, 1, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
+            default: tile_dispatch_out<TAP, 3, STAGE, 1, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
         }
         return;
     }
     if (J.tile_vm == TILE_VM_BOX)
     {
         if (hm == 4)
-            tile_dispatch_out<TAP, 4, STAGE, 1, TILE_VM_BOX> (J, sbuf);
+            tile_dispatch_out<TAP, 4, STAGE, 1, TILE_VM_BOX> (J, sbuf, blockIdx.x, blockIdx.y);
         else
-            tile_dispatch_out<TAP, 5, STAGE, 1, TILE_VM_BOX> (J, sbuf);
+            tile_dispatch_out<TAP, 5, STAGE, 1, TILE_VM_BOX> (J, sbuf, blockIdx.x, blockIdx.y);
         return;
     }
 
     switch (hm)
     {
-        case 0:  tile_dispatch_out<TAP, 0, STAGE, 1> (J, sbuf); break;
-        case 1:  tile_dispatch_out<TAP, 1, STAGE, 1> (J, sbuf); break;
-        case 2:  tile_dispatch_out<TAP, 2, STAGE, 1> (J, sbuf); break;
-        case 3:  tile_dispatch_out<TAP, 3, STAGE, 1> (J, sbuf); break;
-        case 4:  tile_dispatch_out<TAP, 4, STAGE, 1> (J, sbuf); break;
-        default: tile_dispatch_out<TAP, 5, STAGE, 1> (J, sbuf); break;
+        case 0:  tile_dispatch_out<TAP, 0, STAGE, 1> (J, sbuf, blockIdx.x, blockIdx.y); break;
+        case 1:  tile_dispatch_out<TAP, 1, STAGE, 1> (J, sbuf, blockIdx.x, blockIdx.y); break;
+        case 2:  tile_dispatch_out<TAP, 2, STAGE, 1> (J, sbuf, blockIdx.x, blockIdx.y); break;
+        case 3:  tile_dispatch_out<TAP, 3, STAGE, 1> (J, sbuf, blockIdx.x, blockIdx.y); break;
+        case 4:  tile_dispatch_out<TAP, 4, STAGE, 1> (J, sbuf, blockIdx.x, blockIdx.y); break;
+        default: tile_dispatch_out<TAP, 5, STAGE, 1> (J, sbuf, blockIdx.x, blockIdx.y); break;
     }
 }
 
@@ -1259,6 +1384,19 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
  * while staging, 2 U4, 3 U3, 4 A4 after an in-LDS premultiply pass (smol_jobdev.h: tile_setup) */
 __device__ __forceinline__ void tile_dispatch (const JobDev &J, uint8_t *sbuf)
 {
+#if SMOL_TILE_RPF
+    if (J.tile_rpf)
+    {
+        switch (J.tile_variant >> 5)
+        {
+            case 0:  tile_dispatch_hm<TAP_A4, TILE_STAGE_RPF> (J, sbuf); return;
+            case 2:  tile_dispatch_hm<TAP_U4, TILE_STAGE_RPF> (J, sbuf); return;
+            case 3:  tile_dispatch_hm<TAP_U3, TILE_STAGE_RPF> (J, sbuf); return;
+            case 4:  tile_dispatch_hm<TAP_A4, TILE_STAGE_RPF_PREMUL> (J, sbuf); return;
+            default: break;
+        }
+    }
+#endif
     switch (J.tile_variant >> 5)
     {
         case 0:  tile_dispatch_hm<TAP_A4, TILE_STAGE_DMA> (J, sbuf); break;
@@ -1278,11 +1416,20 @@ extern __shared__ __attribute__ ((aligned (16))) uint8_t smol_dyn_lds [];
  * to the occupancy of the heaviest one (4 columns x 4 samples). TS = tapsel of
  * tile_variant: 0 A4, 1 A4 + premultiply while staging, 2 U4, 3 U3. */
 template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
-__device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf, const uint32_t wg_waves = 1)
+__device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf, const uint32_t bx, const uint32_t by, const uint32_t wg_waves = 1)
 {
     constexpr int TAP = (TS <= 1 || TS == 4) ? TAP_A4 : (TS == 2 ? TAP_U4 : TAP_U3);
     constexpr int STAGE = (TS == 1) ? TILE_STAGE_REG_PREMUL : (TS == 4 ? TILE_STAGE_DMA_PREMUL : TILE_STAGE_DMA);
-    tile_dispatch_out<TAP, HM, STAGE, CPL, VM> (J, sbuf, wg_waves);
+#if SMOL_TILE_RPF
+    /* register-prefetch staging where the host found the span to fit the ring (JobDev::tile_rpf) */
+    constexpr int STAGE_R = (TS == 4) ? TILE_STAGE_RPF_PREMUL : TILE_STAGE_RPF;
+    if (TS != 1 && HM != 5 && J.tile_rpf)
+    {
+        tile_dispatch_out<TAP, HM, STAGE_R, CPL, VM> (J, sbuf, bx, by, wg_waves);
+        return;
+    }
+#endif
+    tile_dispatch_out<TAP, HM, STAGE, CPL, VM> (J, sbuf, bx, by, wg_waves);
 }
 
 #ifdef SMOL_KERNEL_EMU
@@ -1292,23 +1439,53 @@ __global__ void k_tile_one (const JobDev J)
     tile_dispatch (J, smol_dyn_lds);
 }
 #else
-template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
-__global__ void __launch_bounds__ (tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM) ? 256 : 64)
-k_tile_batch (const JobDev *__restrict__ jobs, const uint32_t lds_per_wave, const uint32_t wg_waves)
+/* XCD-aware tile order (cdna_hip_programming.md T1). Workgroups are dealt round-robin to the chip's 8 XCDs, each
+ * with its own L2: in raster order the 8 neighbours of a tile row run on 8 different L2s, and every 128-byte line
+ * that two neighbouring spans share -- one per boundary and source row, 1/6 of a 768-byte span -- crosses the fabric
+ * twice. With the swizzle each XCD takes a contiguous eighth of the tiles (of all jobs of the launch), in raster
+ * order. 1-D launch of n workgroups; w -> (x, y, job) through host-made reciprocals (exact: the host only sets
+ * `on' when n * gxgy < 2^32). */
+struct TileSwz
 {
-    /* private copy: the descriptor must not be re-read from memory after every
-     * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
-    const JobDev J = load_job (jobs, blockIdx.z);
-    constexpr bool MW = tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM);
-    tile_entry<TS, HM, CPL, VM> (J, MW ? smol_dyn_lds + smol_wave_index () * lds_per_wave : smol_dyn_lds, wg_waves);
+    uint32_t on, gx, gxgy, inv_gx, inv_gxgy, q, r;
+};
+
+__device__ __forceinline__ void tile_coords (const TileSwz &S, uint32_t &bx, uint32_t &by, uint32_t &bz)
+{
+    if (!S.on)
+    {
+        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+        return;
+    }
+    const uint32_t o = blockIdx.x, xcd = o & 7u, slot = o >> 3;
+    const uint32_t w = (xcd < S.r ? xcd * (S.q + 1u) : S.r * (S.q + 1u) + (xcd - S.r) * S.q) + slot;
+    bz = (uint32_t) (((uint64_t) w * S.inv_gxgy) >> 32);
+    const uint32_t rem = w - bz * S.gxgy;
+    by = (uint32_t) (((uint64_t) rem * S.inv_gx) >> 32);
+    bx = rem - by * S.gx;
 }
 
 template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
 __global__ void __launch_bounds__ (tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM) ? 256 : 64)
-k_tile_one (const JobDev J, const uint32_t lds_per_wave, const uint32_t wg_waves)
+k_tile_batch (const JobDev *__restrict__ jobs, const uint32_t lds_per_wave, const uint32_t wg_waves, const TileSwz swz)
 {
+    uint32_t bx, by, bz;
+    tile_coords (swz, bx, by, bz);
+    /* private copy: the descriptor must not be re-read from memory after every
+     * pixel store (byte-typed stores may alias anything as far as the compiler knows) */
+    const JobDev J = load_job (jobs, bz);
     constexpr bool MW = tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM);
-    tile_entry<TS, HM, CPL, VM> (J, MW ? smol_dyn_lds + smol_wave_index () * lds_per_wave : smol_dyn_lds, wg_waves);
+    tile_entry<TS, HM, CPL, VM> (J, MW ? smol_dyn_lds + smol_wave_index () * lds_per_wave : smol_dyn_lds, bx, by, wg_waves);
+}
+
+template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
+__global__ void __launch_bounds__ (tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM) ? 256 : 64)
+k_tile_one (const JobDev J, const uint32_t lds_per_wave, const uint32_t wg_waves, const TileSwz swz)
+{
+    uint32_t bx, by, bz;
+    tile_coords (swz, bx, by, bz);
+    constexpr bool MW = tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM);
+    tile_entry<TS, HM, CPL, VM> (J, MW ? smol_dyn_lds + smol_wave_index () * lds_per_wave : smol_dyn_lds, bx, by, wg_waves);
 }
 #endif
 
