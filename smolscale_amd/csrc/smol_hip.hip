@@ -50,7 +50,7 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
         const uint32_t rx = 2u << rep.halv_h;
         const uint32_t opt = rx >= 4 ? 1 : 4 / rx;
         const uint32_t tcols = max_w_out / opt;
-        const uint32_t by = pow2_block_rows ();
+        const uint32_t by = pow2_block_rows (rep);
         L::pow2 (jobs_dev, rep, dim3 ((tcols + 63) / 64, (max_rows + by - 1) / by, n_jobs), by, s);
     }
     else if (k == KC_POW2X)

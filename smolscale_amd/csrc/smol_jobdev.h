@@ -91,6 +91,40 @@ struct JobDev
     uint32_t span_px;              /* k_wtile: most source pixels a tile's span can hold  */
 };
 
+/* XCD-aware tile order (cdna_hip_programming.md T1). Workgroups are dealt round-robin to the chip's 8 XCDs, each
+ * with its own L2: in raster order the 8 neighbours of a tile row run on 8 different L2s, and every 128-byte line
+ * that two neighbouring spans share -- one per boundary and source row, 1/6 of a 768-byte span -- crosses the fabric
+ * twice. With the swizzle each XCD takes a contiguous eighth of the tiles (of all jobs of the launch), in raster
+ * order. 1-D launch of n workgroups; w -> (x, y, job) through host-made reciprocals (exact: the host only sets
+ * `on' when n * gxgy < 2^32). */
+struct TileSwz
+{
+    uint32_t on, gx, gxgy, inv_gx, inv_gxgy, q, r;
+};
+
+/* host: the swizzle for a (gx, gy, gz) grid, which then launches as n = gx * gy * gz workgroups in one dimension
+ * (*n_out; 0 = keep the 3-D grid) */
+inline TileSwz
+swizzle_make (uint32_t gx, uint32_t gy, uint32_t gz, bool enable, uint32_t *n_out)
+{
+    TileSwz z = { 0, 0, 0, 0, 0, 0, 0 };
+    const uint64_t gxgy = (uint64_t) gx * gy;
+    const uint64_t n = gxgy * gz;
+
+    *n_out = 0;
+    if (!enable || n < 64 || n * gxgy >= ((uint64_t) 1 << 32))
+        return z;
+    z.on = 1;
+    z.gx = gx;
+    z.gxgy = (uint32_t) gxgy;
+    z.inv_gx = (uint32_t) (((uint64_t) 1 << 32) / gx) + 1u;
+    z.inv_gxgy = (uint32_t) (((uint64_t) 1 << 32) / gxgy) + 1u;
+    z.q = (uint32_t) (n / 8);
+    z.r = (uint32_t) (n % 8);
+    *n_out = (uint32_t) n;
+    return z;
+}
+
 namespace dispatch {
 
 /* byte position of R,G,B,A per SmolPixelType (smolscale.h:16-36 names the
@@ -394,7 +428,10 @@ pow2_ok (const JobDev &d)
 
     if (d.w_out % opt)
         return false;
-    if ((((uintptr_t) d.src) | d.src_stride) & 15)
+    /* 4-byte aligned rows suffice: global_load_dwordx4 only needs dword alignment, and a sub-rectangle of a
+     * larger image (pixels_in + 4 * x, the parent's stride: smolscale.h:56-60) keeps the streaming kernel.
+     * SMOL_POW2_ALIGN16 (tuning builds): the old 16-byte requirement, for A/B */
+    if ((((uintptr_t) d.src) | d.src_stride) & (tune_env ("SMOL_POW2_ALIGN16") ? 15 : 3))
         return false;
     if ((((uintptr_t) d.dst) | d.dst_stride) & (opt * 4 - 1))
         return false;
@@ -402,10 +439,19 @@ pow2_ok (const JobDev &d)
 }
 
 /* k_pow2 workgroup height: output rows (= waves) per workgroup */
-inline uint32_t
-pow2_block_rows ()
+/* (rows that share 128-byte lines with the neighbouring column tiles -- crops, odd widths: smol_k_stream.hip -- run
+ * 8 rows per workgroup under the XCD-aware order: 4096^2 -> 1024^2 at base + 4 B / parent stride 97 -> 91 us, aligned
+ * rows 85 -> 88: profiles/r03a_pow2_crop.txt) */
+inline bool
+pow2_shared_lines (const JobDev &d)
 {
-    uint32_t by = 16;
+    return ((((uintptr_t) d.src) | d.src_stride) & 255u) != 0;
+}
+
+inline uint32_t
+pow2_block_rows (const JobDev &d)
+{
+    uint32_t by = pow2_shared_lines (d) ? 8 : 16;
     if (const char *e = tune_env ("SMOL_POW2_BY"))
         if (atoi (e) >= 1 && atoi (e) <= 16)
             by = (uint32_t) atoi (e);
@@ -437,7 +483,7 @@ pow2x_setup (JobDev &d)
 
     if (d.w_out % opt)
         return false;
-    if ((((uintptr_t) d.src) | d.src_stride) & (d.bpp_in == 3 ? 3 : 15))
+    if ((((uintptr_t) d.src) | d.src_stride) & ((d.bpp_in == 3 || !tune_env ("SMOL_POW2_ALIGN16")) ? 3 : 15))
         return false;
     if (!d.wide)
     {

@@ -19,10 +19,20 @@ template <int HX, int HY>
 void
 launch_pow2_one (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t by, hipStream_t s)
 {
+    /* Source rows that do not start on 256-byte boundaries (a crop of a larger image, an odd width): the 1 KiB a
+     * wave instruction reads then shares its first and last 128-byte line with the neighbouring column tiles --
+     * deal the workgroups out so that neighbours run on the same XCD and meet in its L2 (smol_jobdev.h: TileSwz).
+     * Aligned rows share nothing and keep the plain 3-D grid. */
+    const bool shared_lines = smolhip::dispatch::pow2_shared_lines (rep);
+    uint32_t n;
+    const smolhip::TileSwz swz = smolhip::swizzle_make (grid.x, grid.y, grid.z,
+                                                        shared_lines && !smolhip::tune_env ("SMOL_POW2_NO_SWZ"), &n);
+    if (n)
+        grid = dim3 (n);
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (64, by), 0, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_pow2_batch<HX, HY>), grid, dim3 (64, by), 0, s, jobs_dev, swz);
     else
-        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (64, by), 0, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_pow2_one<HX, HY>), grid, dim3 (64, by), 0, s, rep, swz);
 }
 
 template <int HX>

@@ -41,24 +41,14 @@ tile_wg_shape (dim3 &grid, dim3 &block, uint32_t &lds_total, uint32_t lds_per_wa
     return nw;
 }
 
-/* XCD-aware order (smol_kernel_tile.hip.h: TileSwz): a 1-D launch of all workgroups, each XCD taking a contiguous eighth */
+/* XCD-aware order (smol_jobdev.h: TileSwz): a 1-D launch of all workgroups, each XCD taking a contiguous eighth */
 inline smolhip::TileSwz
 tile_swizzle (dim3 &grid)
 {
-    smolhip::TileSwz z = { 0, 0, 0, 0, 0, 0, 0 };
-    const uint64_t gxgy = (uint64_t) grid.x * grid.y;
-    const uint64_t n = gxgy * grid.z;
-
-    if (n < 64 || n * gxgy >= ((uint64_t) 1 << 32) || smolhip::tune_env ("SMOL_TILE_NO_SWZ"))
-        return z;
-    z.on = 1;
-    z.gx = grid.x;
-    z.gxgy = (uint32_t) gxgy;
-    z.inv_gx = (uint32_t) (((uint64_t) 1 << 32) / grid.x) + 1u;
-    z.inv_gxgy = (uint32_t) (((uint64_t) 1 << 32) / gxgy) + 1u;
-    z.q = (uint32_t) (n / 8);
-    z.r = (uint32_t) (n % 8);
-    grid = dim3 ((uint32_t) n);
+    uint32_t n;
+    const smolhip::TileSwz z = smolhip::swizzle_make (grid.x, grid.y, grid.z, !smolhip::tune_env ("SMOL_TILE_NO_SWZ"), &n);
+    if (n)
+        grid = dim3 (n);
     return z;
 }
 

@@ -52,7 +52,9 @@ struct Pow2xCfg
 typedef uint32_t u32x3_native __attribute__ ((ext_vector_type (3)));
 typedef u32x3_native u32x3a __attribute__ ((aligned (4)));
 
-template <bool BPP3> struct Pow2xRaw { typedef u32x4 T; };
+/* (4-byte alignment is all global_load_dwordx4 / dwordx3 need: rows of a cropped image keep these kernels) */
+typedef u32x4 u32x4a __attribute__ ((aligned (4)));
+template <bool BPP3> struct Pow2xRaw { typedef u32x4a T; };
 template <> struct Pow2xRaw<true> { typedef u32x3a T; };
 
 template <bool BPP3>

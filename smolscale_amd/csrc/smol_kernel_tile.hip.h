@@ -1439,32 +1439,6 @@ __global__ void k_tile_one (const JobDev J)
     tile_dispatch (J, smol_dyn_lds);
 }
 #else
-/* XCD-aware tile order (cdna_hip_programming.md T1). Workgroups are dealt round-robin to the chip's 8 XCDs, each
- * with its own L2: in raster order the 8 neighbours of a tile row run on 8 different L2s, and every 128-byte line
- * that two neighbouring spans share -- one per boundary and source row, 1/6 of a 768-byte span -- crosses the fabric
- * twice. With the swizzle each XCD takes a contiguous eighth of the tiles (of all jobs of the launch), in raster
- * order. 1-D launch of n workgroups; w -> (x, y, job) through host-made reciprocals (exact: the host only sets
- * `on' when n * gxgy < 2^32). */
-struct TileSwz
-{
-    uint32_t on, gx, gxgy, inv_gx, inv_gxgy, q, r;
-};
-
-__device__ __forceinline__ void tile_coords (const TileSwz &S, uint32_t &bx, uint32_t &by, uint32_t &bz)
-{
-    if (!S.on)
-    {
-        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
-        return;
-    }
-    const uint32_t o = blockIdx.x, xcd = o & 7u, slot = o >> 3;
-    const uint32_t w = (xcd < S.r ? xcd * (S.q + 1u) : S.r * (S.q + 1u) + (xcd - S.r) * S.q) + slot;
-    bz = (uint32_t) (((uint64_t) w * S.inv_gxgy) >> 32);
-    const uint32_t rem = w - bz * S.gxgy;
-    by = (uint32_t) (((uint64_t) rem * S.inv_gx) >> 32);
-    bx = rem - by * S.gx;
-}
-
 template <int TS, int HM, int CPL, int VM = TILE_VM_ANY>
 __global__ void __launch_bounds__ (tile_multiwave_variant (TS == 0 ? 0 : 1, HM, TS == 0 ? 0 : 1, CPL, VM) ? 256 : 64)
 k_tile_batch (const JobDev *__restrict__ jobs, const uint32_t lds_per_wave, const uint32_t wg_waves, const TileSwz swz)

@@ -850,6 +850,7 @@ struct Pow2Cfg
 };
 
 typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+typedef u32x4 u32x4a4 __attribute__ ((aligned (4)));       /* a 16-byte load unit on a 4-byte boundary (cropped images) */
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
 
 /* 16-byte write-through output store (see store_out32) */
@@ -866,8 +867,24 @@ __device__ __forceinline__ void store_out128 (SMOL_AS_GLOBAL u32x4 *p, u32x4 v)
 #endif
 }
 
+/* workgroup -> (x, y, job) under the XCD-aware order (smol_jobdev.h: TileSwz) */
+__device__ __forceinline__ void tile_coords (const TileSwz &S, uint32_t &bx, uint32_t &by, uint32_t &bz)
+{
+    if (!S.on)
+    {
+        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+        return;
+    }
+    const uint32_t o = blockIdx.x, xcd = o & 7u, slot = o >> 3;
+    const uint32_t w = (xcd < S.r ? xcd * (S.q + 1u) : S.r * (S.q + 1u) + (xcd - S.r) * S.q) + slot;
+    bz = (uint32_t) (((uint64_t) w * S.inv_gxgy) >> 32);
+    const uint32_t rem = w - bz * S.gxgy;
+    by = (uint32_t) (((uint64_t) rem * S.inv_gx) >> 32);
+    bx = rem - by * S.gx;
+}
+
 template <int HX, int HY>
-__device__ __forceinline__ void pow2_body (const JobDev &J)
+__device__ __forceinline__ void pow2_body (const JobDev &J, const uint32_t bx, const uint32_t by)
 {
     using C = Pow2Cfg<HX, HY>;
 
@@ -876,8 +893,8 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
      * 8 TB/s against 79.5 % for 256 x 1), with non-temporal loads AND stores. */
     /* grid = (column tiles, row tiles, jobs): no division at the head of a workgroup */
     const uint32_t tcols = J.w_out / C::OPT;
-    const uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
-    const uint32_t tc = blockIdx.x * C::BLOCK_X + threadIdx.x;
+    const uint32_t row = by * blockDim.y + threadIdx.y;
+    const uint32_t tc = bx * C::BLOCK_X + threadIdx.x;
 
     if (row >= J.n_rows || tc >= tcols)
         return;
@@ -893,7 +910,7 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
 #pragma unroll
         for (int l = 0; l < C::NLOAD; l++)
             raw [r][l] = __builtin_nontemporal_load (
-                reinterpret_cast<const SMOL_AS_GLOBAL u32x4 *> (sp + (size_t) r * J.src_stride) + l);
+                reinterpret_cast<const SMOL_AS_GLOBAL u32x4a4 *> (sp + (size_t) r * J.src_stride) + l);
 
     uint32_t hres [C::OPT][C::RY];
 #pragma unroll
@@ -930,16 +947,20 @@ __device__ __forceinline__ void pow2_body (const JobDev &J)
 
 template <int HX, int HY>
 __global__ void __launch_bounds__ (1024)
-k_pow2_batch (const JobDev *jobs)
+k_pow2_batch (const JobDev *jobs, const TileSwz swz)
 {
-    pow2_body<HX, HY> (load_job (jobs, blockIdx.z));
+    uint32_t bx, by, bz;
+    tile_coords (swz, bx, by, bz);
+    pow2_body<HX, HY> (load_job (jobs, bz), bx, by);
 }
 
 template <int HX, int HY>
 __global__ void __launch_bounds__ (1024)
-k_pow2_one (const JobDev J)
+k_pow2_one (const JobDev J, const TileSwz swz)
 {
-    pow2_body<HX, HY> (J);
+    uint32_t bx, by, bz;
+    tile_coords (swz, bx, by, bz);
+    pow2_body<HX, HY> (J, bx, by);
 }
 
 

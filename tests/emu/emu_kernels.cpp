@@ -76,9 +76,9 @@ static void run_pow2_hy (const JobDev &J, unsigned gx, unsigned gy)
 {
     switch (J.halv_v)
     {
-        case 0: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 0> (J); }, gy); break;
-        case 1: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 1> (J); }, gy); break;
-        default: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 2> (J); }, gy); break;
+        case 0: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 0> (J, smolhip::TileSwz { 0, 0, 0, 0, 0, 0, 0 }); }, gy); break;
+        case 1: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 1> (J, smolhip::TileSwz { 0, 0, 0, 0, 0, 0, 0 }); }, gy); break;
+        default: run_grid_2d (gx, 64, 16, [&] { k_pow2_one<HX, 2> (J, smolhip::TileSwz { 0, 0, 0, 0, 0, 0, 0 }); }, gy); break;
     }
 }
 

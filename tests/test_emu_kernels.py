@@ -43,13 +43,20 @@ def test_emulated_pow2_kernel_matches_oracle():
         t_in, t_out = rng.randrange(4), rng.randrange(4)
         sin = w_in * 4 + rng.choice([0, 16, 32])
         sout = w_out * 4 + rng.choice([0, 8, 16])
-        src = H.aligned_copy(H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=16))
+        # 16-byte aligned rows, and (every third case) a base 4 / 8 / 12 bytes past a 16-byte boundary with a stride
+        # of any multiple of 4: a crop of a larger image -- the streaming kernel takes both
+        mis = rng.choice([4, 8, 12]) if it % 3 == 2 else 0
+        if mis:
+            sin += rng.choice([0, 4, 8, 12])
+        raw = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=16)
+        buf = H.aligned_copy(np.concatenate([np.zeros(mis, np.uint8), raw]))
+        src = buf[mis:]
         first = rng.randint(0, h_out - 1)
         n = rng.randint(1, h_out - first)
         want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
         got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
         hits += (k == 2)
-        assert np.array_equal(got, want), (hx, hy, w_out, h_out, t_in, t_out, k)
+        assert np.array_equal(got, want), (hx, hy, w_out, h_out, t_in, t_out, k, mis, sin)
     assert hits >= 40
 
 

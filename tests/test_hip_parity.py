@@ -85,6 +85,31 @@ def test_pow2_fast_path_vs_oracle():
         assert np.array_equal(got, want), (hx, hy, w_out, h_out, t_in, t_out)
 
 
+def test_pow2_streaming_kernels_on_cropped_and_odd_stride_sources():
+    """Exact 2:1 / 4:1 / 8:1 from a sub-rectangle of a larger image (pixels_in + 4 * x, the parent's stride:
+    smolscale.h:56-60) and from rows whose stride is not a multiple of 16: the streaming kernels take any
+    4-byte aligned source (smolscale-generic.c:1623-1634 tolerates any alignment)."""
+    rng = random.Random(3131)
+    for it in range(80):
+        h = rng.randrange(3)
+        w_out = rng.choice([4, 8, 64, 72, 136, 256, 300, 1024])
+        h_out = rng.randint(1, 40)
+        w_in, h_in = w_out << (h + 1), h_out << (h + 1)
+        t_in, t_out = rng.randrange(8), rng.randrange(10)
+        x0 = rng.choice([1, 2, 3, 5, 7])                            # crop origin in the parent, pixels
+        parent_w = w_in + x0 + rng.choice([0, 1, 2, 3, 4, 11])
+        sin = parent_w * 4
+        parent = H.make_input(t_in, parent_w, h_in, seed=it, valid=bool(it & 1), pad=32)
+        src = parent[x0 * 4:]
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, None, first, n)
+        # the device copy keeps the parent's 16-byte phase: base = aligned + 4 * x0
+        got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, None, first, n,
+                                 src_misalign=(4 * x0) % 16)
+        assert np.array_equal(got, want), (h, w_out, h_out, t_in, t_out, x0, parent_w, first, n)
+
+
 def test_pow2x_every_type_pair_and_storage_class():
     """k_pow2x (exact 2:1/4:1/8:1, any pixel types, 64bpp and 128bpp classes) through
     the host-pointer API and from caller-owned device buffers."""

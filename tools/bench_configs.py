@@ -32,6 +32,12 @@ CONFIGS = {
     "C2": (0, 4096, 4096, None, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul (1H/1H), 8 frames per launch"),
     "C3": (4, 1920, 1080, None, 0, 7680, 4320, 4, "1920x1080 RGBA unassociated -> 7680x4320 RGBA premul (0H/0H magnify), 4 frames"),
     "C4": (8, 65535, 4096, 65535 * 3, 0, 8192, 4096, 1, "65535x4096 RGB8 (odd stride 196605) -> 8192x4096 RGBA8 (2H/COPY), 1 frame"),
+    # a sub-rectangle of a larger image (pixels_in + 4 * x with the parent's stride) and rows whose stride is not a
+    # multiple of 16: the alignment the streaming kernels used to demand (11th field: byte offset of the source base)
+    "C2CROP4": (0, 4096, 4096, 4112 * 4, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul, crop of a 4112-wide parent at x=1 (base + 4 B), 8 frames", 0, 4),
+    "C2CROP12": (0, 4096, 4096, 4112 * 4, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul, crop of a 4112-wide parent at x=3 (base + 12 B), 8 frames", 0, 12),
+    "C2CROP0": (0, 4096, 4096, 4112 * 4, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul, crop of a 4112-wide parent at x=0 (aligned; control), 8 frames", 0, 0),
+    "C2ODD": (0, 4096, 4096, 4097 * 4, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul, stride 16388 (every row another 16-byte phase), 8 frames", 0, 0),
     "C5": (0, 256, 256, None, 0, 64, 64, 10000, "10000 thumbnails 256^2->64^2 RGBA8 premul (1H/1H), one batch"),
     "C5mix": (-1, 256, 256, None, -1, 64, 64, 10000, "10000 thumbnails 256^2->64^2, pixel types drawn uniformly from the 10x10 table"),
     "BOX": (0, 4096, 4096, None, 0, 448, 448, 8, "4096^2->448^2 RGBA8 premul (BOX/BOX 64bpp), 8 frames per launch"),
@@ -78,6 +84,7 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
     srgb = cfg[9] if len(cfg) > 9 else 0
+    src_off = cfg[10] if len(cfg) > 10 else 0
     if tin is not None:
         t_in0, stride_in = tin, None
     if tout is not None:
@@ -124,7 +131,7 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
             off_in += slot_in
             off_out += slot_out
         else:
-            dsrc = sm.DeviceBuffer(n_in + 64)
+            dsrc = sm.DeviceBuffer(n_in + 64 + src_off)
             ddst = sm.DeviceBuffer(n_out + 64)
         if i < 16 or n_in > (1 << 24):
             host = rng.integers(0, 256, n_in, dtype=np.uint8)
@@ -134,12 +141,12 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
         if opaque and bpp(t_in) == 4 and (i < 16 or n_in > (1 << 24)):
             # photographs with an alpha channel are opaque: alpha byte 3 (RGBA/BGRA) or 0 (ARGB/ABGR)
             host[(3 if (t_in & 3) < 2 else 0)::4] = 255
-        dsrc.upload(host[:n_in])
+        dsrc.upload(host[:n_in], offset=src_off) if src_off else dsrc.upload(host[:n_in])
         if i == 0:
             host_src_kept = host[:n_in].copy()
         im = sm.SmolHipImage()
         im.job = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
-        im.src, im.dst = dsrc.ptr, ddst.ptr
+        im.src, im.dst = dsrc.ptr + src_off, ddst.ptr
         im.rowstride_in, im.rowstride_out = s_in, s_out
         im.first_row, im.n_rows = 0, h_out
         images.append(im)
