@@ -294,6 +294,8 @@ OTHER_CONFIGS = {
     "C5 256x256->64x64 RGBA8 premul x10000": (0, 256, 256, None, 0, 64, 64, 10000),
     "C5mix 256x256->64x64 x10000, pixel types drawn from the 10x10 table": (-1, 256, 256, None, -1, 64, 64, 10000),
     "BOX 4096x4096->448x448 RGBA8 premul x8": (0, 4096, 4096, None, 0, 448, 448, 8),
+    # the headline geometry as a crop of a wider image: base + 4 bytes, the parent's stride (ordinary use of rowstride_in)
+    "C2CROP 4096x4096 (x=1 of a 4112-wide parent)->1024x1024 RGBA8 premul x8": (0, 4096, 4096, 4112 * 4, 0, 1024, 1024, 8, 4),
 }
 
 
@@ -306,7 +308,10 @@ def other_configs(dev, local_rank):
     """Time the other configs with synthetic device-resident data (hipEvents on the launch stream, after
     0.2 s of warm-up load each). Any failure is reported in place of the numbers."""
     out = {}
-    for name, (t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_img) in OTHER_CONFIGS.items():
+    traffic_all = recorded_traffic_table()
+    for name, spec in OTHER_CONFIGS.items():
+        t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_img = spec[:8]
+        src_off = spec[8] if len(spec) > 8 else 0
         try:
             rng = np.random.default_rng(20260202)
             slot_in = (h_in * (stride_in or w_in * 4) + 64 + 255) // 256 * 256      # 256-byte aligned images
@@ -320,7 +325,7 @@ def other_configs(dev, local_rank):
                 if (t_in, t_out) not in jobs:
                     jobs[(t_in, t_out)] = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
                 bi, bo = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
-                images.append(_image(jobs[(t_in, t_out)], src[i].data_ptr(), dst[i].data_ptr(),
+                images.append(_image(jobs[(t_in, t_out)], src[i].data_ptr() + src_off, dst[i].data_ptr(),
                                      stride_in or w_in * bi, w_out * bo, 0, h_out))
                 algo += w_in * h_in * bi + w_out * h_out * bo
             torch.cuda.synchronize()
@@ -334,7 +339,13 @@ def other_configs(dev, local_rank):
                          "step_us_min": st["min"], "step_us_median": st["median"],
                          "GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                          "frac_of_peak_best": round(algo / (st["min"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                         "Mpix_out_per_s": round(n_img * w_out * h_out / (st["mean"] * 1e-6) / 1e6, 1)}
+                         "Mpix_out_per_s": round(n_img * w_out * h_out / (st["mean"] * 1e-6) / 1e6, 1),
+                         "algorithmic_bytes_per_step": algo}
+            tr = traffic_all.get(name.split(" ", 1)[0])
+            if tr and tr.get("algorithmic_bytes_per_step") == algo:
+                out[name]["traffic"] = tr.get("hbm_bytes_per_launch")
+                out[name]["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / algo, 4)
+                out[name]["traffic_source"] = "static: %s (rocprofv3 --pmc, not this run)" % tr.get("source", "?")
             b.destroy()
             del src, dst
         except Exception as e:                      # noqa: BLE001 -- a side table must not break the bench line
@@ -343,13 +354,30 @@ def other_configs(dev, local_rank):
     return out
 
 
-def kernel_source_digest():
-    """sha256 over the sources of the headline kernel: a counter capture is only quoted for the code it was taken on."""
+def kernel_source_digest(all_kernels=False):
+    """sha256 over the sources of the headline kernel (or of every kernel family): a counter capture is only quoted
+    for the code it was taken on."""
     h = hashlib.sha256()
-    for f in ("smol_kernels.hip.h", "smol_k_stream.hip", "smol_jobdev.h"):
+    names = ("smol_kernels.hip.h", "smol_k_stream.hip", "smol_jobdev.h")
+    if all_kernels:
+        names = sorted(f for f in os.listdir(os.path.join(ROOT, "smolscale_amd", "csrc"))
+                       if f.endswith((".hip.h", ".hip", "smol_jobdev.h", ".inc.h")))
+    for f in names:
         with open(os.path.join(ROOT, "smolscale_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def recorded_traffic_table():
+    """{config name: capture} for the side table: profiles/traffic_configs_latest.json (tools/profile_summary.py),
+    quoted only for the kernel sources it was taken on."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_configs_latest.json")))
+    except Exception:                               # noqa: BLE001
+        return {}
+    if t.get("kernel_source_digest_all") != kernel_source_digest(all_kernels=True):
+        return {}
+    return t.get("configs", {})
 
 
 def recorded_traffic(bytes_per_launch):
@@ -412,6 +440,74 @@ def e2e_c4(w, local_rank, reps=3):
     return out
 
 
+def e2e_c2(local_rank, frame0, want0, reps=3, n_callers=16):
+    """The headline geometry through the DROP-IN API on HOST memory: smol_scale_new() + smol_scale_batch() +
+    smol_scale_destroy() of include/smolscale.h (a per-image context, as the reference's callers make,
+    smolscale.h:48-83), one caller and `n_callers' concurrent callers (threads, one context and frame each; ctypes
+    releases the GIL), page-locked and pageable memory. PCIe inclusive: every call uploads its source rows and
+    downloads its output rows; the time of context creation and destruction is inside. Never `value'."""
+    import threading
+    out = {}
+    frame_bytes, out_bytes = W_IN * H_IN * 4, W_OUT * H_OUT * 4
+    moved = frame_bytes + out_bytes
+
+    def one_call(src, dst):
+        with sm.SmolScaleCtx(src, PIX_TYPE, W_IN, H_IN, W_IN * 4, dst, PIX_TYPE, W_OUT, H_OUT, W_OUT * 4) as c:
+            c.batch(0, H_OUT)
+
+    for mode in ("pinned", "pageable"):
+        srcs, dsts, keep = [], [], []
+        try:
+            for _ in range(n_callers):
+                if mode == "pinned":
+                    a, b = sm.PinnedArray(frame_bytes), sm.PinnedArray(out_bytes)
+                    keep += [a, b]
+                    a.array[:] = frame0[:frame_bytes]
+                    srcs.append(a.array)
+                    dsts.append(b.array)
+                else:
+                    srcs.append(frame0[:frame_bytes].copy())
+                    dsts.append(np.zeros(out_bytes, np.uint8))
+            one_call(srcs[0], dsts[0])                               # warm-up: lanes, slabs, streams
+            t1 = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                one_call(srcs[0], dsts[0])
+                t1.append(time.perf_counter() - t0)
+            ok = bool(np.array_equal(dsts[0], want0))
+
+            def worker(k, n_each):
+                for _ in range(n_each):
+                    one_call(srcs[k], dsts[k])
+            n_each = 4
+            tn = []
+            for _ in range(2):
+                th = [threading.Thread(target=worker, args=(k, n_each)) for k in range(n_callers)]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                tn.append(time.perf_counter() - t0)
+            ok = ok and all(bool(np.array_equal(d, want0)) for d in dsts)
+            best1, bestn = min(t1), min(tn) / (n_callers * n_each)
+            out[mode] = {
+                "one_caller": {"ms_per_frame": round(best1 * 1e3, 3), "Mpix_out_per_s": round(W_OUT * H_OUT / best1 / 1e6, 1),
+                               "GBps_over_pcie": round(moved / best1 / 1e9, 1)},
+                "%d_callers" % n_callers: {"ms_per_frame": round(bestn * 1e3, 3),
+                                           "Mpix_out_per_s": round(W_OUT * H_OUT / bestn / 1e6, 1),
+                                           "GBps_over_pcie": round(moved / bestn / 1e9, 1)},
+                "bit_exact_vs_oracle": ok}
+        except Exception as e:                                      # noqa: BLE001
+            out[mode] = {"error": repr(e)}
+        for k in keep:
+            k.free()
+    out["bytes_over_pcie_per_frame"] = moved
+    out["what"] = ("4096x4096->1024x1024 RGBA8 premultiplied frames in HOST memory through smol_scale_new/batch/destroy "
+                   "(the drop-in API): source up and result down over the PCIe link on every call; best of %d" % reps)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,6 +519,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the side table of the other BASELINE configs (N=1 only, a few seconds)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the host-memory legs through the public API (N=1, c2: a few seconds)")
     ap.add_argument("--backend", default="auto",
                     help="process group for the timing barrier: auto = RCCL ('nccl') when it comes up on every rank, "
                          "else gloo; or force 'nccl' / 'gloo'")
@@ -576,6 +674,13 @@ def main():
                 line["e2e"] = {"error": repr(e)}
         if world == 1 and not args.no_other_configs and args.config == "c2":
             line["other_baseline_configs"] = other_configs(dev, local_rank)
+        if world == 1 and not args.no_e2e and args.config == "c2":
+            try:
+                H = checker()
+                f0 = H.make_input(PIX_TYPE, W_IN, H_IN, seed=0, valid=True, pad=16)
+                line["e2e"] = e2e_c2(local_rank, f0, H.oracle_scale(f0, PIX_TYPE, W_IN, H_IN, PIX_TYPE, W_OUT, H_OUT))
+            except Exception as e:                  # noqa: BLE001
+                line["e2e"] = {"error": repr(e)}
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if ref_want is not None:

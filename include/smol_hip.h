@@ -211,7 +211,7 @@ int smol_hip_batch_multi_time (SmolHipBatchMulti *batch, uint32_t warmup, uint32
 void smol_hip_batch_multi_destroy (SmolHipBatchMulti *batch);
 
 /* Releases what the library holds per process: staging lanes (streams, slabs, events)
- * of every device and the worker threads. Slabs above 64 MB also go when the last plan
+ * of every device and the worker threads. Slabs above 256 MB also go when the last plan
  * on a device is destroyed. Call with no smol_hip_* call in flight. */
 void smol_hip_shutdown (void);
 

@@ -293,7 +293,9 @@ device_release_lanes (int device)
  * pins 0.8 GB), keep streams, events and ordinary-sized slabs -- one-shot callers (smol_scale_simple()
  * creates and destroys a plan per call) would otherwise pay stream + event + hipMalloc set-up on
  * every image (measured: 5 ms per 1080p call against 0.4 ms). */
-constexpr size_t LANE_KEEP_BYTES = 64u << 20;
+/* (256 MB, not 64: the source slab of ONE 4096 x 4096 RGBA frame is 64 MB + a few bytes, and a caller that makes a
+ * context per frame -- smol_scale_simple() in a loop -- paid a 64 MB hipFree + hipMalloc on every frame) */
+constexpr size_t LANE_KEEP_BYTES = 256u << 20;
 
 void
 device_trim_lanes (int device)

@@ -70,16 +70,22 @@ __device__ __forceinline__ Px2 tap2 (Px2 p, Px2 q, uint32_t F)
     return r;
 }
 
-/* lane-wise a + b and a >> n on both halves (sums of at most 4 taps: <= 1020) */
+/* lane-wise a + b on both 16-bit halves. Every sum this file forms stays below 2^16 per lane (at most 4 taps of
+ * 8 bits; box sums of at most 256 pixels of 8 bits, smolscale-generic.c:1427-1479 relies on the same bound), so no
+ * carry ever crosses the lanes and a plain 32-bit add IS the packed add -- and v_add_u32 issues in half the time of
+ * v_pk_add_u16 (2 against 4 cycles per wave: tools/microbench/valu_rate.hip, profiles/r03a_valu_rate.txt). Spelled as
+ * an asm statement because the compiler turns (a + b) >> 1 on packed lanes into a per-lane average otherwise. */
 __device__ __forceinline__ uint32_t pk_add_u16 (uint32_t a, uint32_t b)
 {
 #ifdef SMOL_KERNEL_EMU
     return as_u32 (as_u16x2 (a) + as_u16x2 (b));
-#else
-    /* spelled out: left to itself the compiler turns (a + b) >> 1 on packed lanes into a per-lane
-     * average (two 16-bit adds, two shifts and a v_perm instead of v_pk_add + v_pk_lshrrev) */
+#elif defined (SMOL_TILE_PK_ADD)
     uint32_t r;
     asm ("v_pk_add_u16 %0, %1, %2" : "=v" (r) : "v" (a), "v" (b));
+    return r;
+#else
+    uint32_t r;
+    asm ("v_add_u32 %0, %1, %2" : "=v" (r) : "v" (a), "v" (b));
     return r;
 #endif
 }

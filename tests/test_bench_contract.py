@@ -39,8 +39,14 @@ def test_single_gpu_line():
     assert set(line["roofline"]["step_us_each"]) == {"min", "median", "mean"}
     assert "traffic_source" in line["roofline"]
     rows = line["other_baseline_configs"]
-    assert len(rows) == 6 and all("error" not in r for r in rows.values()), rows
+    assert len(rows) == 7 and all("error" not in r for r in rows.values()), rows
     assert any(k.startswith("BOX") for k in rows) and any(k.startswith("C5mix") for k in rows)
+    assert any(k.startswith("C2CROP") for k in rows)        # the alignment cliff is a measured row now
+    # the drop-in API on host memory (PCIe inclusive) is stated in the line, beside cpu_baseline
+    e = line["e2e"]
+    for mode in ("pinned", "pageable"):
+        assert e[mode]["bit_exact_vs_oracle"] is True, e
+        assert e[mode]["one_caller"]["Mpix_out_per_s"] > 0 and e[mode]["16_callers"]["Mpix_out_per_s"] > 0
 
 
 def _torchrun(n, port, *extra):

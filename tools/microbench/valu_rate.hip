@@ -51,6 +51,9 @@ KERNEL (v_bfe_u32,        "v_bfe_u32 %0, %0, 8, 8")
 KERNEL (v_lshrrev_b32,    "v_lshrrev_b32 %0, 3, %0")
 KERNEL (v_cndmask,        "v_cndmask_b32 %0, %0, %1, vcc")
 KERNEL (v_cndmask_s,      "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+KERNEL (cmp_cnd_vcc,      "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc")
+KERNEL (cmp_cnd_sgpr,     "v_cmp_lt_u32 s[10:11], %0, %1\n v_cndmask_b32_e64 %0, %0, %2, s[10:11]")
+KERNEL (cnd_vcc_e64,      "v_cndmask_b32_e64 %0, %0, %1, vcc")
 KERNEL (v_mov_b32,        "v_mov_b32 %0, %1")
 KERNEL (v_or_b32,         "v_or_b32 %0, %0, %1")
 KERNEL (v_lshl_add_u32,   "v_lshl_add_u32 %0, %0, 2, %1")
@@ -185,7 +188,7 @@ int main ()
     RUN (v_dot2_u32_u16) RUN (v_lshl_or_b32) RUN (v_and_or_b32) RUN (v_bfe_u32) RUN (v_lshrrev_b32) RUN (v_cndmask)
     RUN (v_mov_dpp_shr1) RUN (v_add_dpp_shr1) RUN (v_sad_u8) RUN (v_mul_sdwa_b0) RUN (v_pk_mul_sgpr)
     RUN (v_cvt_f32_ubyte0) RUN (v_fma_f32) RUN (v_pk_fma_f16) RUN (v_pk_mul_f16) RUN (v_cvt_pk_u8_f32)
-    RUN (v_cndmask_s) RUN (v_mov_b32) RUN (v_or_b32) RUN (v_lshl_add_u32) RUN (v_add3_u32) RUN (v_pk_sub_u16) RUN (v_cmp_lt_u32)
+    RUN (v_cndmask_s) RUN (cmp_cnd_vcc) RUN (cmp_cnd_sgpr) RUN (cnd_vcc_e64) RUN (v_mov_b32) RUN (v_or_b32) RUN (v_lshl_add_u32) RUN (v_add3_u32) RUN (v_pk_sub_u16) RUN (v_cmp_lt_u32)
     RUN (v_readfirstlane) RUN (v_readlane) RUN (v_bfi_b32) RUN (v_lshlrev_b32) RUN (v_xor_b32) RUN (v_sub_u32) RUN (v_max_u32)
     RUN (v_add_u16) RUN (v_mad_u16) RUN (v_mul_lo_u16) RUN (v_mad_u32_u16) RUN (v_lshrrev_sdwa) RUN (v_and_sdwa_b1) RUN (v_add_sdwa_w1)
     RUN (v_mul_f32) RUN (v_cvt_u32_f32)
