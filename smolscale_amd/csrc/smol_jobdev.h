@@ -117,8 +117,9 @@ swizzle_make (uint32_t gx, uint32_t gy, uint32_t gz, bool enable, uint32_t *n_ou
     z.on = 1;
     z.gx = gx;
     z.gxgy = (uint32_t) gxgy;
-    z.inv_gx = (uint32_t) (((uint64_t) 1 << 32) / gx) + 1u;
-    z.inv_gxgy = (uint32_t) (((uint64_t) 1 << 32) / gxgy) + 1u;
+    /* floor (2^32 / d) + 1 does not fit 32 bits for d = 1: 0 stands for "divide by one" (a one-tile-wide image) */
+    z.inv_gx = (gx == 1) ? 0u : (uint32_t) (((uint64_t) 1 << 32) / gx) + 1u;
+    z.inv_gxgy = (gxgy == 1) ? 0u : (uint32_t) (((uint64_t) 1 << 32) / gxgy) + 1u;
     z.q = (uint32_t) (n / 8);
     z.r = (uint32_t) (n % 8);
     *n_out = (uint32_t) n;

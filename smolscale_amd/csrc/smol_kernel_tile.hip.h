@@ -38,6 +38,9 @@ constexpr uint32_t TILE_COLS = 64;
 #ifndef SMOL_TILE_BOXBATCH
 #define SMOL_TILE_BOXBATCH 1
 #endif
+#ifndef SMOL_TILE_BOXROT
+#define SMOL_TILE_BOXROT 1      /* per-lane rotated read order inside a batch of four box pixels */
+#endif
 
 constexpr uint32_t PAIR_MASK = 0x00ff00ffu;
 
@@ -837,6 +840,10 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     const uint32_t box_nfree = (HBOX && box_fs >= 2u) ? box_fs - 2u : 0u;
     /* (as values in vector registers, applied with v_and: a v_cndmask on a lane mask held in scalar registers
      * costs six times a plain vector instruction -- tools/microbench/valu_rate.hip) */
+    uint32_t box_rot [4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+        box_rot [k] = BPP * ((k + lane) & 3u);
     uint32_t box_m0 = (box_nfree < box_n) ? 0xffffffffu : 0u;
     uint32_t box_m1 = (box_nfree + 1u < box_n) ? 0xffffffffu : 0u;
 #ifndef SMOL_KERNEL_EMU
@@ -1106,14 +1113,18 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
                     Px2 a = { 0, 0 };
                     while (left >= 4u)
                     {
+                        /* the four pixels of a batch in a per-lane rotated order (box_rot [k] = BPP * ((k + lane) & 3)):
+                         * at ratios like 64/7 the lanes 7 apart start a whole number of bank rows apart and every read
+                         * of the plain order is a 5-way bank conflict (80 % of the LDS cycles of 4096 -> 448 were
+                         * conflict cycles: profiles/r03c_sq_box.txt); rotated, those lanes read four different words */
                         TapRaw q4 [4];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++)
-                            q4 [k] = tile_tap_load<TAP, false> (rowb, off + k * BPP);
+                            q4 [k] = tile_tap_load<TAP, false> (rowb, off + (SMOL_TILE_BOXROT ? box_rot [k] : k * BPP));
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++)
                         {
-                            tile_tap_unpack<TAP, false> (J, q4 [k], off + k * BPP, pp, qq);
+                            tile_tap_unpack<TAP, false> (J, q4 [k], off + (SMOL_TILE_BOXROT ? box_rot [k] : k * BPP), pp, qq);
                             a = px2_add (a, pp);
                         }
                         off += 4u * BPP;

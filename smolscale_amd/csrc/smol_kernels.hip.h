@@ -877,9 +877,9 @@ __device__ __forceinline__ void tile_coords (const TileSwz &S, uint32_t &bx, uin
     }
     const uint32_t o = blockIdx.x, xcd = o & 7u, slot = o >> 3;
     const uint32_t w = (xcd < S.r ? xcd * (S.q + 1u) : S.r * (S.q + 1u) + (xcd - S.r) * S.q) + slot;
-    bz = (uint32_t) (((uint64_t) w * S.inv_gxgy) >> 32);
+    bz = S.inv_gxgy ? (uint32_t) (((uint64_t) w * S.inv_gxgy) >> 32) : w;      /* 0: divide by one */
     const uint32_t rem = w - bz * S.gxgy;
-    by = (uint32_t) (((uint64_t) rem * S.inv_gx) >> 32);
+    by = S.inv_gx ? (uint32_t) (((uint64_t) rem * S.inv_gx) >> 32) : rem;
     bx = rem - by * S.gx;
 }
 

@@ -110,6 +110,59 @@ def test_pow2_streaming_kernels_on_cropped_and_odd_stride_sources():
         assert np.array_equal(got, want), (h, w_out, h_out, t_in, t_out, x0, parent_w, first, n)
 
 
+def test_one_tile_wide_and_tall_images_under_the_xcd_aware_order():
+    """Launches of 64 and more workgroups run in the XCD-aware order, whose tile index is decoded with host-made
+    reciprocals: images ONE tile wide (gx = 1: the reciprocal of 1 does not fit 32 bits) and a few tiles wide,
+    thousands of row tiles tall -- the shape of verify.c's vertical ordering test (1 x 16384 -> 1 x 16383,
+    verify.c:163-166) -- through k_tile, k_pow2 and k_pow2x, plus batches of many small images (gx * gy = 1)."""
+    cases = [
+        (0, 1, 16384, 8, 1, 16383),          # verify.c: V rgba -> rgb
+        (8, 1, 16384, 0, 1, 16383),
+        (0, 3, 9000, 1, 3, 4100),            # bilinear V, copy H
+        (0, 40, 20000, 4, 17, 7000),         # one column tile, bilinear both
+        (0, 70, 12000, 0, 65, 5000),         # two column tiles
+        (0, 128, 32768, 0, 32, 8192),        # exact 4:1, one column tile: k_pow2
+        (4, 128, 16384, 9, 64, 8192),        # exact 2:1, mixed types: k_pow2x
+        (0, 600, 9000, 0, 40, 600),          # box both axes (ratio 15): two passes
+        (0, 500, 4500, 0, 50, 450),          # box both axes (ratio 9-10): k_tile
+    ]
+    for (t_in, w_in, h_in, t_out, w_out, h_out) in cases:
+        src = H.make_input(t_in, w_in, h_in, seed=w_in, valid=True, pad=32)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out)
+        assert np.array_equal(got, want), ("host", t_in, w_in, h_in, t_out, w_out, h_out)
+        got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, src_misalign=4)
+        assert np.array_equal(got, want), ("device+4", t_in, w_in, h_in, t_out, w_out, h_out)
+    # many one-tile images in one launch
+    rng = random.Random(9)
+    specs, images, bufs, wants = [], [], [], []
+    for i in range(200):
+        t_in, t_out = rng.randrange(10), rng.randrange(10)
+        w_in, h_in = rng.randint(20, 60), rng.randint(20, 60)
+        w_out, h_out = rng.randint(5, 19), rng.randint(5, 15)
+        src = H.make_input(t_in, w_in, h_in, seed=i, valid=True, pad=16)
+        dsrc, ddst = sm.DeviceBuffer(src.size + 16), sm.DeviceBuffer(w_out * h_out * H.bpp(t_out) + 16)
+        dsrc.upload(src)
+        im = sm.SmolHipImage()
+        im.job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+        im.src, im.dst = dsrc.ptr, ddst.ptr
+        im.rowstride_in, im.rowstride_out = w_in * H.bpp(t_in), w_out * H.bpp(t_out)
+        im.first_row, im.n_rows = 0, h_out
+        images.append(im)
+        bufs.append((dsrc, ddst))
+        specs.append((t_in, w_in, h_in, t_out, w_out, h_out))
+        wants.append(H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out))
+    b = sm.HipBatch(images)
+    b.launch()
+    sm.check(sm.lib().smol_hip_device_synchronize(0), "sync")
+    for spec, (dsrc, ddst), want in zip(specs, bufs, wants):
+        assert np.array_equal(ddst.download(want.size), want), spec
+    b.destroy()
+    for a, d in bufs:
+        a.free()
+        d.free()
+
+
 def test_pow2x_every_type_pair_and_storage_class():
     """k_pow2x (exact 2:1/4:1/8:1, any pixel types, 64bpp and 128bpp classes) through
     the host-pointer API and from caller-owned device buffers."""

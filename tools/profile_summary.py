@@ -71,6 +71,20 @@ with open(os.path.join(P, tag + "_kernel_by_grid.csv"), "w", newline="") as fh:
     wr.writeheader()
     wr.writerows(rows)
 
+# what the traced runs measured themselves (hipEvents inside the traced process): the line of the traced bench.py run
+# and the tools/bench_configs.py line of every traced side config -- tools/roofline_check.py compares trace and events
+# of the SAME process (run-to-run spread on one box is +-5 %, so a second process is no yardstick)
+with open(os.path.join(P, tag + "_traced_runs.jsonl"), "w") as fh:
+    for log, run in [("kt_bench.log", "bench_c2")] + [(os.path.basename(d) + ".log", os.path.basename(d)[len("kt_cfg_"):])
+                                                       for d in sorted(glob.glob(os.path.join(O, "kt_cfg_*"))) if os.path.isdir(d)]:
+        try:
+            lines = [ln for ln in open(os.path.join(O, log)).read().splitlines() if ln.startswith("{")]
+            d = json.loads(lines[-1])
+            d["run"] = run
+            fh.write(json.dumps(d) + "\n")
+        except Exception:       # noqa: BLE001
+            pass
+
 f = first("kt_bench/**/*kernel_stats.csv")
 if f:
     open(os.path.join(P, tag + "_kernel_stats.csv"), "w").write(open(f).read())
