@@ -117,6 +117,9 @@ EXPORTS = {
     "smol_hip_shutdown": (None, []),
     # include/smol_cpu.h
     "smol_cpu_scale_rows": (_int, [ctypes.POINTER(SmolHipJob), _vp, _u32, _vp, _u32, _u32, _u32]),
+    "smol_cpu_plan_create": (_int, [ctypes.POINTER(SmolHipJob), ctypes.POINTER(_vp)]),
+    "smol_cpu_plan_scale_rows": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32]),
+    "smol_cpu_plan_destroy": (None, [_vp]),
     "smol_hip_malloc": (_int, [_int, _u64, ctypes.POINTER(_vp)]),
     "smol_hip_free": (_int, [_int, _vp]),
     "smol_hip_memcpy_h2d": (_int, [_int, _vp, _vp, _u64]),

@@ -38,6 +38,9 @@ constexpr uint32_t TILE_COLS = 64;
 #ifndef SMOL_TILE_BOXBATCH
 #define SMOL_TILE_BOXBATCH 1
 #endif
+#ifndef SMOL_TILE_PRIO
+#define SMOL_TILE_PRIO 1        /* s_setprio around the staging requests */
+#endif
 #ifndef SMOL_TILE_BOXROT
 #define SMOL_TILE_BOXROT 1      /* per-lane rotated read order inside a batch of four box pixels */
 #endif
@@ -383,6 +386,17 @@ __device__ __forceinline__ void smol_global_load_lds16 (const void *gptr, uint8_
 __device__ __forceinline__ void smol_wait_vmcnt0 ()
 {
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+/* issue priority of this wave among the waves of its SIMD (0-3): raised while a wave requests its next row group, so
+ * that the request is not queued behind the arithmetic of the waves next door */
+template <int P>
+__device__ __forceinline__ void smol_setprio ()
+{
+#if SMOL_TILE_PRIO
+    if (P == 0) asm volatile ("s_setprio 0" ::: "memory");
+    else asm volatile ("s_setprio 3" ::: "memory");
+#endif
 }
 
 /* index of this wave in its workgroup, as a SCALAR (threadIdx.x >> 6 is wave-uniform, but the compiler keeps it
@@ -1018,6 +1032,9 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
              * the next group into the other buffer so that it streams in during the consume.
              * A counted wait that lets the stores fly (vmcnt(n) for the n stores issued since) measured
              * the same as draining everything (profiles/r02p_wait_ab.txt) and cost scalar bookkeeping. */
+#if SMOL_TILE_PRIO == 2
+            smol_setprio<3> ();
+#endif
             smol_wait_vmcnt0 ();
             /* the workgroup is a single wave: no s_barrier needed, and __syncthreads()
              * would make hipcc drain every outstanding store (vmcnt(0)) */
@@ -1026,8 +1043,10 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
             if (nfirst <= row_last && !dbg_nostage)
             {
                 const uint32_t nn = (row_last - nfirst + 1 < J.group_rows) ? row_last - nfirst + 1 : J.group_rows;
+                smol_setprio<3> ();
                 tile_stage<true, false> (J, sbuf + (cur ^ 1u) * buf_bytes, lane, nfirst, nn, g0, g1);
             }
+            smol_setprio<0> ();
             if (STAGE == TILE_STAGE_DMA_PREMUL && !dbg_notaps)
             {
                 tile_premul_lds (J, buf, lane, nrows);

@@ -139,3 +139,42 @@ def test_default_backend_still_fails_loudly_without_a_gpu_and_auto_says_what_it_
     assert "using cpu" in run.stderr                                          # never silent
     run = _run_api("bogus")
     assert run.returncode != 0 and "is not one of" in run.stderr
+
+
+def test_cpu_plan_handle_row_batches_and_hand_built_jobs():
+    """smol_cpu_plan_*: the tap tables are built once per plan -- rows asked for one at a time (the reference's own row
+    loop, smolscale.c:507-546) through ONE plan from several threads equal the oracle; a hand-built job that the planner
+    could not have produced is rejected instead of indexing outside the image."""
+    import threading
+    lib = sm.lib()
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in ((0, 640, 480, 1, 213, 160, 0), (8, 900, 40, 9, 31, 7, 1),
+                                                          (4, 77, 300, 5, 200, 90, 0)):
+        src = H.make_input(t_in, w_in, h_in, seed=5, valid=True, pad=16)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        plan = ctypes.c_void_p()
+        assert lib.smol_cpu_plan_create(ctypes.byref(job), ctypes.byref(plan)) == 0
+        got = np.zeros_like(want)
+        s_out = w_out * H.bpp(t_out)
+
+        def rows(first, n):
+            for y in range(first, first + n):
+                rc = lib.smol_cpu_plan_scale_rows(plan, src.ctypes.data, w_in * H.bpp(t_in),
+                                                  got.ctypes.data + y * s_out, s_out, y, 1)
+                assert rc == 0
+        ts = [threading.Thread(target=rows, args=sm.strip_rows(k, 4, h_out)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        lib.smol_cpu_plan_destroy(plan)
+    # hand-built jobs: bilinear over one pixel, a filter id / halving count / pixel type out of range, copy with unequal sizes
+    good = H.plan_job(0, 64, 64, 0, 32, 32, 0)
+    for field, value in (("width_in", 1), ("filter_h", 7), ("halvings_v", 3), ("pixel_type_in", 12)):
+        bad = sm.SmolHipJob.from_buffer_copy(bytes(good))
+        setattr(bad, field, value)
+        plan = ctypes.c_void_p()
+        assert lib.smol_cpu_plan_create(ctypes.byref(bad), ctypes.byref(plan)) < 0, field
+        buf = np.zeros(64 * 64 * 4, np.uint8)
+        assert lib.smol_cpu_scale_rows(ctypes.byref(bad), buf.ctypes.data, 256, buf.ctypes.data, 128, 0, 1) < 0, field
