@@ -188,9 +188,16 @@ tile_setup (JobDev &d)
      * row loop's scalar work was cut (r02p), one column per lane is faster there (4096^2 -> 2731^2 123 -> 108 us,
      * -> 3413^2 174 -> 153, H down / V up 113 -> 82; at ratio 1.9, from 24-bit or unassociated sources 4 columns
      * stay 3-5 % ahead: profiles/r02p_cpl_ab.txt) */
+    /* (round 3: that held only because the 4-column store demanded 16-byte aligned output rows, which those sizes
+     * did not have. With vector stores on any dword-aligned row 4 columns win over the whole range 1-2 -- ratio 1.03
+     * 107 -> 86 us, 1.2 130 -> 110, 1.5 98 -> 93, 1.7 96 -> 89 (profiles/r03d_cpl4_rows.txt) -- and one column per
+     * lane stays for a vertical magnification under a horizontal minification and for destinations that are not
+     * dword aligned) */
     if (d.tile_cpl == 4 && d.filter_h == F_BILINEAR && d.halv_h == 0 && d.bpp_in == 4 && !d.unassoc_in
         && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0 && d.bpp_out == 4
-        && d.step_x >= ((uint64_t) 1 << 32) && d.step_x < ((uint64_t) 7 << 30))
+        && d.step_x >= ((uint64_t) 1 << 32) && d.step_x < ((uint64_t) 7 << 30)
+        && (tune_env ("SMOL_TILE_CPL1_BELOW_175") || (((uintptr_t) d.dst) | d.dst_stride) & 3
+            || (d.filter_v == F_BILINEAR && d.step_y < ((uint64_t) 1 << 32))))
         d.tile_cpl = 1;
     if (const char *e = tune_env ("SMOL_TILE_CPL"))
         if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX)
@@ -251,7 +258,17 @@ tile_setup (JobDev &d)
          * rows, ratio 2.5 and 3 four, ratio 6 two; below ~1.4 sixteen) */
         const uint64_t rows_per_out = d.step_y << d.halv_v;                 /* 32.32 source rows per output row */
         if (d.step_y < ((uint64_t) 1 << 32))
-            th = 32;
+            /* magnification on both axes (below ~1.7: smol_jobdev.h up_setup sends it here): 12 rows
+             * (3840x2160 x1.1: 12 rows 72 us, 8 rows 75, 32 rows 78; profiles/r03d_vec_store_align.txt) */
+            th = (d.filter_h == F_BILINEAR && d.step_x < ((uint64_t) 1 << 32) && !d.wide) ? 12 : 32;
+        else if (!d.wide && d.tile_cpl == 4 && d.halv_v == 0 && d.halv_h == 0 && d.filter_h == F_BILINEAR
+                 && d.bpp_in == 4 && !d.unassoc_in && d.bpp_out == 4 && d.step_y < ((uint64_t) 2 << 32))
+        {
+            /* 4 columns per lane at ratios 1-2: about 8 source rows per tile (profiles/r03d_cpl4_rows.txt) */
+            th = (uint32_t) ((((uint64_t) 8 << 32) + d.step_y / 2) / d.step_y);
+            if (th < 4) th = 4;
+            if (th > 8) th = 8;
+        }
         else if (d.wide || (d.unassoc_in && d.bpp_in == 4))
             th = d.halv_v ? (16u >> d.halv_v) : 8u;                         /* k_wtile, and sources premultiplied group by group in LDS
                                                                              * (4000x3000 rgbA -> 1600x1200: 8 rows 137 us, 5 rows 146): as in round 1 */
@@ -313,7 +330,12 @@ tile_setup (JobDev &d)
         d.tile_vm = TILE_VM_PAIR;
     else if (d.filter_v == F_BOX && hm >= 4 && !tune_env ("SMOL_NO_TILE_VM"))
         d.tile_vm = TILE_VM_BOX;
-    d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 15) == 0);
+    /* 4-byte alignment is all a 16-byte store needs (global_store_dwordx4 wants dword alignment; the lanes' stores are
+     * contiguous either way). Rounds 1-2 demanded 16-byte aligned rows and sent every odd output width -- three sizes
+     * out of four in the reference's proportional sweep -- to per-pixel stores: 1080p -> 4993x2809 (k_up) 206 -> 97 us,
+     * 4K -> 5261x2959 185 -> 115, ratio 1.03 with 4 columns per lane 139 -> 89 (profiles/r03d_vec_store_align.txt).
+     * SMOL_VEC16_ALIGNED (tuning builds): the old rule, for A/B. */
+    d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & (tune_env ("SMOL_VEC16_ALIGNED") ? 15 : 3)) == 0);
     d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);
 
     /* ONE staging buffer of twice the size and no prefetch of the next row group (the resident waves cover
@@ -543,6 +565,17 @@ up_setup (JobDev &d)
         return false;
     if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_UP") || (flavour >= 2 && tune_env ("SMOL_NO_UP_GEN")))
         return false;
+
+    /* 64bpp class, slight magnification (below ~1.7 on either axis): every source row feeds barely more than one
+     * output row, k_up's per-tile horizontal pass over 10 source rows is not amortised and the row-streaming k_tile
+     * wins -- 3840x2160 x1.1: 143 -> 79 us, x1.3: 154 -> 105, x1.5: 156 -> 133, x1.75: equal, x3: k_up 104 against
+     * 142 (profiles/r03d_up_vs_tile.txt). This is the upper half of the reference's own proportional sweep. */
+    if (flavour == 0 && !tune_env ("SMOL_UP_ALWAYS"))
+    {
+        const uint64_t lim = ((uint64_t) 58 << 32) / 100;          /* step 0.58 = magnification 1.72 */
+        if (d.step_x > lim || d.step_y > lim)
+            return false;
+    }
 
     d.up_wide = (uint8_t) flavour;
     d.tile_band = tune_env ("SMOL_NO_UP_BAND") ? 0 : 1;     /* tiles dealt out in XCD bands */

@@ -378,7 +378,7 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
                     const u32x4 v = { w [0], w [1 % CPL], w [2 % CPL], w [3 % CPL] };
                     /* non-temporal (this kernel is bound by arithmetic: the write-through asm store and its compiler
                      * barrier cost 66 -> 88 us on the premul16 ratio-1.5 case) */
-                    __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (out_row + (size_t) xl * 4));
+                    store_nt128 (out_row + (size_t) xl * 4, v);
                 }
                 else
                 {

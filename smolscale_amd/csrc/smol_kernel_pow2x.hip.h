@@ -317,7 +317,7 @@ __device__ __forceinline__ void pow2x_body (const JobDev &J)
                 {
                     const u32x4 v4 = { outw [(g * 4 + 0) % C::OPT], outw [(g * 4 + 1) % C::OPT],
                                        outw [(g * 4 + 2) % C::OPT], outw [(g * 4 + 3) % C::OPT] };
-                    store_out128 (reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (dp) + g, v4);
+                    store_out128 (dp + (size_t) g * 16, v4);
                 }
             }
         }

@@ -453,7 +453,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c], inv_tab);
             u32x4 v = { w [0], w [1], w [2], w [3] };
-            store_out128 (reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (rowp) + (size_t) xl * 4), v);
+            store_out128 (gptr (rowp) + (size_t) xl * 4, v);
             return;
         }
     }

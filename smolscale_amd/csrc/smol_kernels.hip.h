@@ -181,14 +181,16 @@ struct LutLds
     const uint16_t *fs, *oq;
     const uint8_t *ts;
 
+    /* (the 64bpp-class instantiations of the shared bodies pass no table copy: offsets from the integer value, never
+     * arithmetic on a null pointer) */
     __device__ __forceinline__ explicit LutLds (const uint8_t *base)
-        : p8 (reinterpret_cast<const uint32_t *> (base)),
-          p8l (reinterpret_cast<const uint32_t *> (base + 1024)),
-          p16 (reinterpret_cast<const uint32_t *> (base + 2048)),
-          p16l (reinterpret_cast<const uint32_t *> (base + 3072)),
-          fs (reinterpret_cast<const uint16_t *> (base + 4096)),
-          oq (reinterpret_cast<const uint16_t *> (base + 6656)),
-          ts (base + 4608) {}
+        : p8 (reinterpret_cast<const uint32_t *> ((uintptr_t) base)),
+          p8l (reinterpret_cast<const uint32_t *> ((uintptr_t) base + 1024)),
+          p16 (reinterpret_cast<const uint32_t *> ((uintptr_t) base + 2048)),
+          p16l (reinterpret_cast<const uint32_t *> ((uintptr_t) base + 3072)),
+          fs (reinterpret_cast<const uint16_t *> ((uintptr_t) base + 4096)),
+          oq (reinterpret_cast<const uint16_t *> ((uintptr_t) base + 6656)),
+          ts (reinterpret_cast<const uint8_t *> ((uintptr_t) base + 4608)) {}
 
     __device__ __forceinline__ uint32_t inv_p8 (uint32_t a) const { return p8 [a]; }
     __device__ __forceinline__ uint32_t inv_p8l (uint32_t a) const { return p8l [a]; }
@@ -853,15 +855,25 @@ typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 typedef u32x4 u32x4a4 __attribute__ ((aligned (4)));       /* a 16-byte load unit on a 4-byte boundary (cropped images) */
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
 
-/* 16-byte write-through output store (see store_out32) */
-__device__ __forceinline__ void store_out128 (SMOL_AS_GLOBAL u32x4 *p, u32x4 v)
+/* 16-byte NON-TEMPORAL output store on a dword-aligned address (the store-bound kernels: k_up, k_down) */
+__device__ __forceinline__ void store_nt128 (gbyte *p, u32x4 v)
 {
 #if defined (SMOL_KERNEL_EMU)
-    *p = v;
+    __builtin_memcpy (p, &v, 16);
+#else
+    __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p));
+#endif
+}
+
+/* 16-byte write-through output store (see store_out32) */
+__device__ __forceinline__ void store_out128 (gbyte *p, u32x4 v)
+{
+#if defined (SMOL_KERNEL_EMU)
+    __builtin_memcpy (p, &v, 16);       /* (the address is only dword aligned: smol_jobdev.h out_vec16_ok) */
 #elif defined (SMOL_STORES_NT)
-    __builtin_nontemporal_store (v, p);
+    __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p));
 #elif defined (SMOL_STORES_PLAIN)
-    *p = v;
+    *reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p) = v;
 #else
     asm volatile ("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v" (p), "v" (v) : "memory");
 #endif

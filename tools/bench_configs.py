@@ -38,11 +38,22 @@ CONFIGS = {
     "C2CROP12": (0, 4096, 4096, 4112 * 4, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul, crop of a 4112-wide parent at x=3 (base + 12 B), 8 frames", 0, 12),
     "C2CROP0": (0, 4096, 4096, 4112 * 4, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul, crop of a 4112-wide parent at x=0 (aligned; control), 8 frames", 0, 0),
     "C2ODD": (0, 4096, 4096, 4097 * 4, 0, 1024, 1024, 8, "4096^2->1024^2 RGBA8 premul, stride 16388 (every row another 16-byte phase), 8 frames", 0, 0),
+    # slight magnifications (the upper half of the reference's own proportional sweep, bench.sh:39-43: scales 1 .. 2)
+    "U1.1": (0, 3840, 2160, None, 0, 4224, 2376, 6, "3840x2160->4224x2376 RGBA8 premul (magnify x1.1), 6 frames"),
+    "U1.3": (0, 3840, 2160, None, 0, 4992, 2808, 6, "3840x2160->4992x2808 RGBA8 premul (magnify x1.3), 6 frames"),
+    "U1.5": (0, 3840, 2160, None, 0, 5760, 3240, 6, "3840x2160->5760x3240 RGBA8 premul (magnify x1.5), 6 frames"),
+    "U1.75": (0, 3840, 2160, None, 0, 6720, 3780, 6, "3840x2160->6720x3780 RGBA8 premul (magnify x1.75), 6 frames"),
+    "U1.37": (0, 3840, 2160, None, 0, 5261, 2959, 6, "3840x2160->5261x2959 RGBA8 premul (magnify x1.37, output rows not 16-byte aligned), 6 frames"),
+    "U2.6": (0, 1920, 1080, None, 0, 4993, 2809, 8, "1920x1080->4993x2809 RGBA8 premul (magnify x2.6, output rows not 16-byte aligned), 8 frames"),
+    "U2": (0, 3840, 2160, None, 0, 7680, 4320, 6, "3840x2160->7680x4320 RGBA8 premul (magnify x2), 6 frames"),
+    "U3": (0, 1920, 1080, None, 0, 5760, 3240, 8, "1920x1080->5760x3240 RGBA8 premul (magnify x3), 8 frames"),
     "C5": (0, 256, 256, None, 0, 64, 64, 10000, "10000 thumbnails 256^2->64^2 RGBA8 premul (1H/1H), one batch"),
     "C5mix": (-1, 256, 256, None, -1, 64, 64, 10000, "10000 thumbnails 256^2->64^2, pixel types drawn uniformly from the 10x10 table"),
     "BOX": (0, 4096, 4096, None, 0, 448, 448, 8, "4096^2->448^2 RGBA8 premul (BOX/BOX 64bpp), 8 frames per launch"),
     # arbitrary (non power-of-two) ratios through k_tile
     "R1.5": (0, 4096, 4096, None, 0, 2731, 2731, 6, "4096^2->2731^2 RGBA8 premul (0H, ratio 1.5), 6 frames"),
+    "R1.03": (0, 4096, 4096, None, 0, 3977, 3977, 4, "4096^2->3977^2 RGBA8 premul (0H, ratio 1.03), 4 frames"),
+    "R1.1": (0, 4096, 4096, None, 0, 3724, 3724, 4, "4096^2->3724^2 RGBA8 premul (0H, ratio 1.1), 4 frames"),
     "R1.2": (0, 4096, 4096, None, 0, 3413, 3413, 6, "4096^2->3413^2 RGBA8 premul (0H, ratio 1.2), 6 frames"),
     "R1.9": (0, 4096, 4096, None, 0, 2156, 2156, 6, "4096^2->2156^2 RGBA8 premul (0H, ratio 1.9), 6 frames"),
     "R1.5RGB": (8, 4096, 4096, None, 0, 2731, 2731, 6, "4096^2 RGB8 ->2731^2 RGBA8 (0H, ratio 1.5), 6 frames"),
