@@ -566,13 +566,15 @@ up_setup (JobDev &d)
     if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_UP") || (flavour >= 2 && tune_env ("SMOL_NO_UP_GEN")))
         return false;
 
-    /* 64bpp class, slight magnification (below ~1.7 on either axis): every source row feeds barely more than one
+    /* 64bpp class, slight magnification (below 2 on either axis): every source row feeds barely more than one
      * output row, k_up's per-tile horizontal pass over 10 source rows is not amortised and the row-streaming k_tile
      * wins -- 3840x2160 x1.1: 143 -> 79 us, x1.3: 154 -> 105, x1.5: 156 -> 133, x1.75: equal, x3: k_up 104 against
      * 142 (profiles/r03d_up_vs_tile.txt). This is the upper half of the reference's own proportional sweep. */
     if (flavour == 0 && !tune_env ("SMOL_UP_ALWAYS"))
     {
-        const uint64_t lim = ((uint64_t) 58 << 32) / 100;          /* step 0.58 = magnification 1.72 */
+        /* (between 1.7 and 2 the two are equal on 16-byte aligned output rows and k_tile is 6-12 % ahead on the odd
+         * widths of the sweep: 3840x2160 -> 6758x3801 641 -> 569 us, -> 7411x4168 674 -> 634: profiles/r03d_sweep_points.txt) */
+        const uint64_t lim = (uint64_t) 1 << 31;                    /* step 0.5 = magnification 2 */
         if (d.step_x > lim || d.step_y > lim)
             return false;
     }

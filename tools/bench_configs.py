@@ -45,6 +45,21 @@ CONFIGS = {
     "U1.75": (0, 3840, 2160, None, 0, 6720, 3780, 6, "3840x2160->6720x3780 RGBA8 premul (magnify x1.75), 6 frames"),
     "U1.37": (0, 3840, 2160, None, 0, 5261, 2959, 6, "3840x2160->5261x2959 RGBA8 premul (magnify x1.37, output rows not 16-byte aligned), 6 frames"),
     "U2.6": (0, 1920, 1080, None, 0, 4993, 2809, 8, "1920x1080->4993x2809 RGBA8 premul (magnify x2.6, output rows not 16-byte aligned), 8 frames"),
+    # points of the reference's proportional sweep (ARGB8 premultiplied, test.c:20) that read low in profiles/r03*_sweep
+    "S8K93": (2, 7680, 4320, None, 2, 7145, 4019, 5, "sweep point 7680x4320->7145x4019 ARGB8 premul (ratio 1.075), 5 frames"),
+    "S4K97": (2, 3840, 2160, None, 2, 3724, 2094, 19, "sweep point 3840x2160->3724x2094 ARGB8 premul (ratio 1.03), 19 frames"),
+    "S4K89": (2, 3840, 2160, None, 2, 3417, 1922, 19, "sweep point 3840x2160->3417x1922 ARGB8 premul (ratio 1.12), 19 frames"),
+    "S4K81": (2, 3840, 2160, None, 2, 3110, 1749, 19, "sweep point 3840x2160->3110x1749 ARGB8 premul (ratio 1.235), 19 frames"),
+    "S4K73": (2, 3840, 2160, None, 2, 2803, 1577, 19, "sweep point 3840x2160->2803x1577 ARGB8 premul (ratio 1.37), 19 frames"),
+    "S4K65": (2, 3840, 2160, None, 2, 2496, 1404, 19, "sweep point 3840x2160->2496x1404 ARGB8 premul (ratio 1.54), 19 frames"),
+    "S4K57": (2, 3840, 2160, None, 2, 2188, 1231, 19, "sweep point 3840x2160->2188x1231 ARGB8 premul (ratio 1.755), 19 frames"),
+    "S4K110": (2, 3840, 2160, None, 2, 4224, 2376, 12, "sweep point 3840x2160->4224x2376 ARGB8 premul (magnify x1.1), 12 frames"),
+    "S4K140": (2, 3840, 2160, None, 2, 5376, 3024, 12, "sweep point 3840x2160->5376x3024 ARGB8 premul (magnify x1.4), 12 frames"),
+    "S4K176": (2, 3840, 2160, None, 2, 6758, 3801, 19, "sweep point 3840x2160->6758x3801 ARGB8 premul (magnify x1.76), 19 frames"),
+    "S4K193": (2, 3840, 2160, None, 2, 7411, 4168, 19, "sweep point 3840x2160->7411x4168 ARGB8 premul (magnify x1.93), 19 frames"),
+    "S1080T": (2, 1920, 1080, None, 2, 76, 42, 64, "sweep point 1920x1080->76x42 ARGB8 premul (box ratio 25), 64 frames"),
+    "S4K49": (2, 3840, 2160, None, 2, 1881, 1057, 19, "sweep point 3840x2160->1881x1057 ARGB8 premul (ratio 2.04, 1H), 19 frames"),
+    "S4K25": (2, 3840, 2160, None, 2, 959, 539, 19, "sweep point 3840x2160->959x539 ARGB8 premul (ratio 4.004, 2H), 19 frames"),
     "U2": (0, 3840, 2160, None, 0, 7680, 4320, 6, "3840x2160->7680x4320 RGBA8 premul (magnify x2), 6 frames"),
     "U3": (0, 1920, 1080, None, 0, 5760, 3240, 8, "1920x1080->5760x3240 RGBA8 premul (magnify x3), 8 frames"),
     "C5": (0, 256, 256, None, 0, 64, 64, 10000, "10000 thumbnails 256^2->64^2 RGBA8 premul (1H/1H), one batch"),
@@ -68,6 +83,8 @@ CONFIGS = {
     "R7": (0, 4096, 4096, None, 0, 585, 585, 8, "4096^2->585^2 RGBA8 premul (2H, ratio 7), 8 frames"),
     "R6": (0, 4096, 4096, None, 0, 683, 683, 8, "4096^2->683^2 RGBA8 premul (2H, ratio 6), 8 frames"),
     "PHOTO": (8, 4000, 3000, None, 8, 1600, 1200, 12, "4000x3000 RGB8 -> 1600x1200 RGB8 (1H, ratio 2.5), 12 frames"),
+    "PHOTOODD": (8, 4000, 3000, None, 8, 1601, 1201, 12, "4000x3000 RGB8 -> 1601x1201 RGB8 (1H; 24-bit output rows that do not start on 4-byte boundaries), 12 frames"),
+    "PHOTO32ODD": (8, 4001, 3001, 4001 * 3, 0, 1601, 1201, 12, "4001x3001 RGB8 (stride 12003) -> 1601x1201 RGBA8 (1H; odd 24-bit input rows), 12 frames"),
     "PNG": (4, 4000, 3000, None, 0, 1600, 1200, 10, "4000x3000 RGBA unassociated -> 1600x1200 RGBA premul (1H), 10 frames"),
     # 128bpp-class rows: premul16 and sRGB-linear internal formats
     "P16": (4, 4096, 4096, None, 4, 1024, 1024, 4, "4096^2->1024^2 RGBA8 unassociated->unassociated (premul16, 128bpp class), 4 frames"),
