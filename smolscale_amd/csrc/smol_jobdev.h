@@ -71,7 +71,7 @@ struct JobDev
     uint8_t tile_band;             /* k_tile: deal tiles out in XCD bands (very wide images) */
     uint8_t tile_vm;               /* k_tile: vertical specialisation (TILE_VM_*): 0 decided at run time, 1 copy, 2 bilinear, 3 box */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
-    uint8_t out3_ok;               /* 24-bit output rows start on 4-byte boundaries          */
+    uint8_t out3_ok;               /* 24-bit output whose full-width tiles leave as aligned dwords (any row alignment) */
     uint8_t px_kind;               /* k_pow2x: PX_* input kind                           */
     uint8_t px_lpr_shift;          /* k_pow2x: log2 (lanes of a wave per output row)     */
     uint8_t tile_single;           /* k_tile: one staging buffer, no prefetch of the next row group (more resident waves) */
@@ -176,7 +176,7 @@ tile_setup (JobDev &d)
     /* few taps per column (COPY/ONE/one sample) and a wide enough image: a lane
      * takes 4 adjacent columns, which amortises the wave's scalar bookkeeping and
      * turns its stores into 16-byte ones */
-    d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);
+    d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && (!tune_env ("SMOL_OUT3_ALIGNED") || ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0));
     d.tile_cpl = (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX
                   && (d.filter_h != F_BILINEAR || d.halv_h == 0) && d.w_out >= 256) ? 4 : 1;
     /* 24-bit output: 4 pixels per lane leave as one 12-byte store (measured: 4000x3000 ->
@@ -336,7 +336,9 @@ tile_setup (JobDev &d)
      * 4K -> 5261x2959 185 -> 115, ratio 1.03 with 4 columns per lane 139 -> 89 (profiles/r03d_vec_store_align.txt).
      * SMOL_VEC16_ALIGNED (tuning builds): the old rule, for A/B. */
     d.out_vec16_ok = (d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & (tune_env ("SMOL_VEC16_ALIGNED") ? 15 : 3)) == 0);
-    d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0);
+    /* (any row alignment since round 3: the dword-granular 24-bit store shifts the tile's byte run onto aligned dwords
+     * itself, smol_kernel_tile.hip.h tile_store_cols; SMOL_OUT3_ALIGNED in tuning builds = the old 4-byte rule, for A/B) */
+    d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && (!tune_env ("SMOL_OUT3_ALIGNED") || ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0));
 
     /* ONE staging buffer of twice the size and no prefetch of the next row group (the resident waves cover
      * each other's latency, as in k_boxh) for the entry points where it measured ahead -- compiled in there

@@ -459,30 +459,100 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
     }
     if (OUT == OUT_ANY && full24)
     {
+        /* A full-width tile of 24-bit pixels is one run of 64 * CPL * 3 bytes. It leaves as whole ALIGNED dwords
+         * whatever byte the row starts on: m = (address of the run) & 3 is the same for every lane, the lanes cut the
+         * run into dwords of the aligned stream -- each dword is 4 bytes of the run starting m bytes early, i.e. a
+         * lane's bytes preceded by the last m bytes of the lane below it -- and only the first 4 - m and the last m
+         * bytes of the run go out as single bytes (lanes 0 and 63). Rounds 1-2 stored 3 bytes per pixel one by one
+         * whenever the row was not 4-byte aligned: every output width that is not a multiple of 4. */
+        const uint32_t j = threadIdx.x & 63u;          /* (a no-op in one-wave workgroups) */
+        gbyte *run = gptr (rowp) + (size_t) (xl - j * CPL) * 3;                 /* first byte of the tile's run */
+#ifdef SMOL_KERNEL_EMU
+        const uint32_t m = (uint32_t) (uintptr_t) run & 3u;
+#else
+        const uint32_t m = (uint32_t) __builtin_amdgcn_readfirstlane ((int) ((uint32_t) (uintptr_t) run & 3u));
+#endif
+        SMOL_AS_GLOBAL uint32_t *aligned = reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (run - m);
         if (CPL == 4)
         {
             uint32_t w [4];
 #pragma unroll
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c], inv_tab) & 0x00ffffffu;
-            /* three consecutive dwords (the backend merges them into one dwordx3 store) */
-            SMOL_AS_GLOBAL uint32_t *d3 = reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) xl * 3);
-            d3 [0] = w [0] | (w [1] << 24);
-            d3 [1] = (w [1] >> 8) | (w [2] << 16);
-            d3 [2] = (w [2] >> 16) | (w [3] << 8);
+            /* this lane's 12 bytes of the run */
+            const uint32_t d0 = w [0] | (w [1] << 24);
+            const uint32_t d1 = (w [1] >> 8) | (w [2] << 16);
+            const uint32_t d2 = (w [2] >> 16) | (w [3] << 8);
+            SMOL_AS_GLOBAL uint32_t *d3 = aligned + j * 3u;
+            if (m == 0)
+            {
+                /* three consecutive dwords (the backend merges them into one dwordx3 store) */
+                d3 [0] = d0;
+                d3 [1] = d1;
+                d3 [2] = d2;
+                return;
+            }
+            const uint32_t prev2 = smol_shfl_idx (d2, (j + 63u) & 63u);        /* the lane below's last dword */
+            const uint32_t sh = 4u - m;
+            const uint32_t t0 = __builtin_amdgcn_alignbyte (d0, prev2, sh);
+            const uint32_t t1 = __builtin_amdgcn_alignbyte (d1, d0, sh);
+            const uint32_t t2 = __builtin_amdgcn_alignbyte (d2, d1, sh);
+            if (j != 0)
+                d3 [0] = t0;
+            d3 [1] = t1;
+            d3 [2] = t2;
+            if (j == 0)
+            {
+                /* the run's first 4 - m bytes */
+                for (uint32_t b = 0; b < sh; b++)
+                    run [b] = (uint8_t) (d0 >> (8u * b));
+            }
+            if (j == 63u)
+            {
+                /* ... and its last m bytes: the top of this lane's last dword */
+                gbyte *tail = reinterpret_cast<gbyte *> (aligned + 192u);
+                for (uint32_t b = 0; b < m; b++)
+                    tail [b] = (uint8_t) (d2 >> (8u * (sh + b)));
+            }
         }
         else
         {
-            /* dword j of the tile's 192 output bytes starts in pixel a = 4j/3 at byte b = 4j%3 */
-            const uint32_t j = threadIdx.x & 63u;      /* (a no-op in one-wave workgroups) */
+            /* one pixel per lane: dword k of the aligned stream = bytes 4k - m .. 4k - m + 3 of the 192-byte run;
+             * byte B of the run sits in pixel B / 3 at byte B % 3. Lanes 0..48 each build one dword from the (at most
+             * two) pixels it touches, fetched with two in-wave shuffles. */
             const uint32_t w = tile_pack<OUT> (J, o [0], inv_tab) & 0x00ffffffu;
-            const uint32_t a = (j * 4u) / 3u;
-            const uint32_t b = (j * 4u) - a * 3u;
-            const uint32_t wa = smol_shfl_idx (w, a & 63u);
-            const uint32_t wb = smol_shfl_idx (w, (a + 1u) & 63u);
-            const uint32_t d = (wa >> (8u * b)) | (wb << (24u - 8u * b));
-            if (j < 48u)
-                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) (xl - j) * 3 + (size_t) j * 4) = d;
+            const uint32_t B = j * 4u + 3u - m;                         /* run offset of the dword's LAST byte: never negative */
+            const uint32_t la = (B < 192u ? B : 191u) / 3u;             /* pixel of the last byte  */
+            const uint32_t fa = (B >= 3u ? B - 3u : 0u) / 3u;           /* pixel of the first byte (clamped for lane 0) */
+            const uint32_t wa = smol_shfl_idx (w, fa & 63u);
+            const uint32_t wb = smol_shfl_idx (w, la & 63u);
+            /* the 6 bytes of pixels fa, fa + 1 as one 64-bit value; the dword starts at byte (B - 3) - 3 * fa of it */
+            const uint32_t second = (la != fa) ? wb : 0u;
+            const uint64_t six = (uint64_t) wa | ((uint64_t) second << 24);
+            const int32_t first = (int32_t) B - 3;                      /* run offset of the dword's first byte (lane 0: negative) */
+            if (m == 0)
+            {
+                if (j < 48u)
+                    aligned [j] = (uint32_t) (six >> (8u * ((uint32_t) first - 3u * fa)));
+                return;
+            }
+            if (j >= 1u && j < 48u)
+                aligned [j] = (uint32_t) (six >> (8u * ((uint32_t) first - 3u * fa)));
+            if (j == 0)
+            {
+                /* the run's first 4 - m bytes: bytes 0 .. of pixels 0 (and 1) */
+                const uint32_t sh = 4u - m;
+                for (uint32_t b = 0; b < sh; b++)
+                    run [b] = (uint8_t) (six >> (8u * b));
+            }
+            if (j == 48u)
+            {
+                /* its last m bytes: run bytes 192 - m .. 191, the tail of pixel 63 (m <= 3 bytes: one pixel) */
+                gbyte *tail = reinterpret_cast<gbyte *> (aligned + 48u);
+                const uint32_t w63 = wb;                                /* la == 63 for this lane */
+                for (uint32_t b = 0; b < m; b++)
+                    tail [b] = (uint8_t) (w63 >> (8u * (3u - m + b)));
+            }
         }
         return;
     }

@@ -163,6 +163,33 @@ def test_one_tile_wide_and_tall_images_under_the_xcd_aware_order():
         d.free()
 
 
+def test_24bit_output_rows_at_every_byte_alignment():
+    """24-bit output whose rows start on any byte (every width that is not a multiple of 4, odd strides, a destination
+    1-3 bytes past a dword): full-width tiles leave as aligned dwords shifted inside the wave (tile_store_cols), the
+    run's first and last bytes singly. Through k_tile (1 and 4 columns per lane), k_up, k_hspan; bytes between the
+    rows and around the image must stay untouched."""
+    rng = random.Random(2424)
+    shapes = [
+        (1.3, 1.3), (1.9, 1.6), (2.5, 2.5), (3.7, 2.2), (6.0, 5.0), (9.5, 9.5),      # k_tile, bilinear and box
+        (0.4, 0.5), (0.8, 0.9), (0.27, 0.3),                                          # magnification: k_tile / k_up
+        (2.0, 1.0), (4.0, 1.0),                                                       # k_hspan (vertical copy)
+    ]
+    for it in range(66):
+        rx, ry = shapes[it % len(shapes)]
+        w_out = rng.choice([256, 257, 258, 259, 300, 513, 1025])
+        h_out = rng.randint(3, 40)
+        w_in, h_in = max(2, int(round(w_out * rx))), max(2, int(round(h_out * ry)))
+        if ry == 1.0:
+            h_in = h_out
+        t_in, t_out = rng.choice([0, 2, 4, 8, 9]), rng.choice([8, 9])
+        sout = w_out * 3 + rng.choice([0, 1, 2, 3, 7])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=True, pad=32)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, None, sout, fill=0xA5)
+        got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, None, sout, fill=0xA5,
+                                 dst_misalign=it % 4)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sout, it % 4)
+
+
 def test_pow2x_every_type_pair_and_storage_class():
     """k_pow2x (exact 2:1/4:1/8:1, any pixel types, 64bpp and 128bpp classes) through
     the host-pointer API and from caller-owned device buffers."""
