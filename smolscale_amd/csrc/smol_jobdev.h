@@ -199,6 +199,14 @@ tile_setup (JobDev &d)
         && (tune_env ("SMOL_TILE_CPL1_BELOW_175") || (((uintptr_t) d.dst) | d.dst_stride) & 3
             || (d.filter_v == F_BILINEAR && d.step_y < ((uint64_t) 1 << 32))))
         d.tile_cpl = 1;
+    /* one halving just above ratio 2 (the two samples of a column sit about a pixel apart, four columns share most of
+     * their taps' pixels): 4 columns per lane -- 3840x2160 -> 1881x1057 168 -> 147 us; from ratio 2.5 on equal or behind
+     * (profiles/r03d_cpl4_1h.txt) */
+    if (!d.wide && d.tile_cpl == 1 && d.filter_h == F_BILINEAR && d.halv_h == 1 && d.filter_v == F_BILINEAR
+        && d.bpp_in == 4 && !d.unassoc_in && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0
+        && d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0 && d.w_out >= 256
+        && d.step_x < ((uint64_t) 115 << 32) / 100)                 /* per-sample step: ratio < 2.3 */
+        d.tile_cpl = 4;
     if (const char *e = tune_env ("SMOL_TILE_CPL"))
         if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX)
             d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
@@ -272,6 +280,8 @@ tile_setup (JobDev &d)
         else if (d.wide || (d.unassoc_in && d.bpp_in == 4))
             th = d.halv_v ? (16u >> d.halv_v) : 8u;                         /* k_wtile, and sources premultiplied group by group in LDS
                                                                              * (4000x3000 rgbA -> 1600x1200: 8 rows 137 us, 5 rows 146): as in round 1 */
+        else if (d.tile_cpl == 4 && d.halv_h == 1 && d.halv_v == 1 && d.bpp_in == 4 && !d.unassoc_in && d.bpp_out == 4)
+            th = 6;                                                         /* the ratio 2-2.3 family above */
         else if (rows_per_out < ((uint64_t) 14 << 32) / 10)                 /* < 1.4 */
             th = 16;
         else
