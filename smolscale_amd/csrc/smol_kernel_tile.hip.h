@@ -41,6 +41,12 @@ constexpr uint32_t TILE_COLS = 64;
 #ifndef SMOL_TILE_PRIO
 #define SMOL_TILE_PRIO 1        /* s_setprio around the staging requests */
 #endif
+#ifndef SMOL_TILE_UNALIGNED_LDS
+#define SMOL_TILE_UNALIGNED_LDS 0   /* byte-addressed ds_read_b64 / b32 for 24-bit and unaligned 32-bit taps: they return the right bytes
+                                     * on gfx950 (tools/microbench/lds_unaligned.hip) but a misaligned LDS read is far slower than
+                                     * three aligned dwords + v_alignbyte: 4000x3000 RGB8 -> 1600x1200 118 -> 233 us, gamma-correct
+                                     * thumbnails 248 -> 439 (profiles/r03d_unaligned_lds.txt). Off. */
+#endif
 #ifndef SMOL_TILE_BOXROT
 #define SMOL_TILE_BOXROT 1      /* per-lane rotated read order inside a batch of four box pixels */
 #endif
@@ -190,8 +196,14 @@ __device__ __forceinline__ uint32_t premul_word (uint32_t w, uint32_t ain)
 /* 4 bytes starting at an arbitrary LDS byte offset, through 4-byte aligned reads */
 __device__ __forceinline__ uint32_t lds_load_unaligned (const uint8_t *sb, uint32_t off)
 {
+#if SMOL_TILE_UNALIGNED_LDS
+    /* ds_read_b32 takes any byte address on gfx950 (tools/microbench/lds_unaligned.hip) */
+    typedef uint32_t u32a1 __attribute__ ((aligned (1)));
+    return *reinterpret_cast<const u32a1 *> (sb + off);
+#else
     const uint32_t *pp = reinterpret_cast<const uint32_t *> (sb + (off & ~3u));
     return __builtin_amdgcn_alignbyte (pp [1], pp [0], off & 3u);
+#endif
 }
 
 /* unassociated word -> premultiplied Px2 directly, in packed 16-bit lanes:
@@ -247,6 +259,27 @@ __device__ __forceinline__ TapRaw tile_tap_load (const uint8_t *rowb, uint32_t o
         r.d1 = PAIR ? pp [1] : 0u;
         r.d2 = 0u;
     }
+    else if (SMOL_TILE_UNALIGNED_LDS)
+    {
+        /* ONE LDS read at the pixel's own byte address: ds_read_b64 / ds_read_b32 take any address on gfx950 (a
+         * misaligned one costs two LDS passes -- tools/microbench/lds_unaligned.hip -- which is what the three aligned
+         * dwords cost before) and the bytes arrive where the unpack wants them: no address masking, no v_alignbyte.
+         * 24-bit and unaligned 32-bit sources are bound by exactly that arithmetic. */
+        typedef uint64_t u64a1 __attribute__ ((aligned (1)));
+        typedef uint32_t u32a1 __attribute__ ((aligned (1)));
+        if (PAIR)
+        {
+            const uint64_t v = *reinterpret_cast<const u64a1 *> (rowb + off);
+            r.d0 = (uint32_t) v;
+            r.d1 = (uint32_t) (v >> 32);
+        }
+        else
+        {
+            r.d0 = *reinterpret_cast<const u32a1 *> (rowb + off);
+            r.d1 = 0u;
+        }
+        r.d2 = 0u;
+    }
     else
     {
         /* 4-byte aligned reads around the pixel(s); v_alignbyte does the rest in tile_tap_unpack */
@@ -271,12 +304,20 @@ __device__ __forceinline__ void tile_tap_unpack (const JobDev &J, const TapRaw &
     }
     else if (TAP == TAP_U4)
     {
-        /* v_alignbyte shifts by the low two bits of its third operand: `off' goes in as is */
-        wp = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);
-        if (PAIR)
-            wq = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
+        if (SMOL_TILE_UNALIGNED_LDS)
+        {
+            wp = r.d0;
+            wq = PAIR ? r.d1 : wp;
+        }
         else
-            wq = wp;
+        {
+            /* v_alignbyte shifts by the low two bits of its third operand: `off' goes in as is */
+            wp = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);
+            if (PAIR)
+                wq = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
+            else
+                wq = wp;
+        }
         if (J.unassoc_in)
         {
             p = premul_px2 (wp, J.pos_in [3]);
@@ -286,12 +327,12 @@ __device__ __forceinline__ void tile_tap_unpack (const JobDev &J, const TapRaw &
     }
     else
     {
-        const uint32_t b0 = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);     /* bytes 0..3 from p */
+        const uint32_t b0 = SMOL_TILE_UNALIGNED_LDS ? r.d0 : __builtin_amdgcn_alignbyte (r.d1, r.d0, off);     /* bytes 0..3 from p */
         if (PAIR)
         {
             /* bytes 0..7 from p hold both pixels (p = bytes 0-2, q = bytes 3-5): four v_perm pick
              * the packed halves directly -- selector 0x0c = 0x00, 0x0d = 0xff (the alpha lane) */
-            const uint32_t b1 = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
+            const uint32_t b1 = SMOL_TILE_UNALIGNED_LDS ? r.d1 : __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
             p.lo = __builtin_amdgcn_perm (b1, b0, 0x0c020c00u);
             p.hi = __builtin_amdgcn_perm (b1, b0, 0x0c0d0c01u);
             q.lo = __builtin_amdgcn_perm (b1, b0, 0x0c050c03u);
