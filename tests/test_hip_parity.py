@@ -563,6 +563,16 @@ def test_ten_thousand_mixed_thumbnails_every_output_checked():
             bad.append((i, key, "padding"))
     assert not bad, bad[:10]
     assert len(want) > 700
+    # the same 10 000 images as BASELINE words config 5: a hipGraph of one kernel node per image
+    # (smol_hip_batch_use_graph), every output compared again
+    ddst.fill(0x5A)
+    batch.use_graph(True)
+    batch.launch()
+    sm.check(lib.smol_hip_device_synchronize(0))
+    got = ddst.download()
+    bad = [(i, key) for i, ((t_in, k, t_out), off) in enumerate(zip(picks, out_off))
+           for key in [(t_in, k, t_out)] if not np.array_equal(got[off:off + want[key].size], want[key])]
+    assert not bad, ("graph", bad[:10])
     batch.destroy()
     for d in dsrc.values():
         d.free()

@@ -16,11 +16,20 @@ struct Geo { const uint8_t *src; uint8_t *dst; uint32_t w_in, h_in, w_out, h_out
 
 // NW waves per workgroup (side by side on one output row), NL loads per lane and source row, NS pixel pairs per column,
 // GR source rows loaded together
-template <int NW, int NL, int NS, int GR>
-__global__ void __launch_bounds__ (64 * NW) k_vspan (const Geo g)
+// SWZ (round 3): 1-D launch in the XCD-aware order -- workgroup o runs tile (o % 8) * (n / 8) + o / 8, so that each XCD takes a
+// contiguous eighth of the (x, y, image) tiles and the source rows two neighbouring output rows share meet in ONE L2
+template <int NW, int NL, int NS, int GR, bool SWZ = false>
+__global__ void __launch_bounds__ (64 * NW) k_vspan (const Geo g, const uint32_t gx, const uint32_t gy, const uint32_t n)
 {
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
-    const uint32_t x0 = (blockIdx.x * NW + wave) * 256, y = blockIdx.y, img = blockIdx.z;
+    uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (SWZ)
+    {
+        const uint32_t o = blockIdx.x, q = n / 8, r = n % 8, xcd = o & 7;
+        const uint32_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (o >> 3);
+        bz = w / (gx * gy); const uint32_t rem = w - bz * gx * gy; by = rem / gx; bx = rem - by * gx;
+    }
+    const uint32_t x0 = (bx * NW + wave) * 256, y = by, img = bz;
     if (x0 >= g.w_out) return;
     const uint32_t S = g.rows_per_out;
     uint32_t r0 = (uint32_t) (y * g.ry); if (r0 + S > g.h_in) r0 = g.h_in - S;
@@ -81,14 +90,16 @@ __global__ void __launch_bounds__ (64 * NW) k_vspan (const Geo g)
 }
 
 static hipEvent_t e0, e1;
-template <int NW, int NL, int NS, int GR>
+template <int NW, int NL, int NS, int GR, bool SWZ = false>
 static void run (const char *name, Geo g)
 {
-    const dim3 grid ((g.w_out + 256 * NW - 1) / (256 * NW), g.h_out, g.n_img);
+    dim3 grid ((g.w_out + 256 * NW - 1) / (256 * NW), g.h_out, g.n_img);
+    const uint32_t gx = grid.x, gy = grid.y, n = grid.x * grid.y * grid.z;
+    if (SWZ) grid = dim3 (n);
     const size_t lds_b = (size_t) NW * GR * (NL * 1024 + 32);
     if (lds_b > 160 * 1024) { printf ("%-40s needs %zu KB LDS: skipped\n", name, lds_b / 1024); return; }
-    (void) hipFuncSetAttribute ((const void *) k_vspan<NW, NL, NS, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_b);
-    auto launch = [&] { hipLaunchKernelGGL ((k_vspan<NW, NL, NS, GR>), grid, dim3 (64 * NW), lds_b, 0, g); };
+    (void) hipFuncSetAttribute ((const void *) k_vspan<NW, NL, NS, GR, SWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_b);
+    auto launch = [&] { hipLaunchKernelGGL ((k_vspan<NW, NL, NS, GR, SWZ>), grid, dim3 (64 * NW), lds_b, 0, g, gx, gy, n); };
     for (int i = 0; i < 3; i++) launch ();
     (void) hipEventRecord (e0, 0);
     const int it = 20;
@@ -112,18 +123,29 @@ int main ()
     run<4, 4, 2, 4> ("ratio 3   NW4 GR4", g3);
     run<4, 4, 2, 2> ("ratio 3   NW4 GR2", g3);
     run<6, 4, 2, 4> ("ratio 3   NW6 GR4 (whole row)", g3);
+    run<1, 4, 2, 4, true> ("ratio 3   NW1 GR4 XCD-aware order", g3);
+    run<2, 4, 2, 4, true> ("ratio 3   NW2 GR4 XCD-aware order", g3);
+    run<4, 4, 2, 2, true> ("ratio 3   NW4 GR2 XCD-aware order", g3);
     Geo g15 = { s, d, 4096, 4096, 2731, 2731, 4096.f / 2731, 4096.f / 2731, 6, 2 };
     run<1, 2, 1, 2> ("ratio 1.5 NW1 GR2 (2 rows per output row)", g15);
     run<4, 2, 1, 2> ("ratio 1.5 NW4 GR2", g15);
     run<11, 2, 1, 2> ("ratio 1.5 NW11 GR2 (whole row)", g15);
+    run<1, 2, 1, 2, true> ("ratio 1.5 NW1 GR2 XCD-aware order", g15);
+    run<4, 2, 1, 2, true> ("ratio 1.5 NW4 GR2 XCD-aware order", g15);
     Geo g9 = { s, d, 4096, 4096, 448, 448, 4096.f / 448, 4096.f / 448, n, 11 };
     run<1, 10, 4, 2> ("ratio 9.14 NW1 GR2 (11 rows per output row)", g9);
     run<2, 10, 4, 2> ("ratio 9.14 NW2 GR2", g9);
     run<2, 10, 4, 3> ("ratio 9.14 NW2 GR3", g9);
     run<2, 10, 4, 1> ("ratio 9.14 NW2 GR1", g9);
+    run<1, 10, 4, 2, true> ("ratio 9.14 NW1 GR2 XCD-aware order", g9);
+    run<2, 10, 4, 2, true> ("ratio 9.14 NW2 GR2 XCD-aware order", g9);
+    run<2, 10, 4, 4, true> ("ratio 9.14 NW2 GR4 XCD-aware order", g9);
     Geo g6 = { s, d, 4096, 4096, 683, 683, 4096.f / 683, 4096.f / 683, n, 7 };
     run<1, 7, 4, 2> ("ratio 6    NW1 GR2 (7 rows per output row)", g6);
     run<3, 7, 4, 2> ("ratio 6    NW3 GR2 (whole row)", g6);
     run<3, 7, 4, 4> ("ratio 6    NW3 GR4", g6);
+    run<1, 7, 4, 2, true> ("ratio 6    NW1 GR2 XCD-aware order", g6);
+    run<3, 7, 4, 2, true> ("ratio 6    NW3 GR2 XCD-aware order", g6);
+    run<1, 7, 4, 7, true> ("ratio 6    NW1 GR7 (all rows at once) XCD-aware order", g6);
     return 0;
 }
