@@ -24,13 +24,6 @@ inline const char *tune_env (const char *) { return nullptr; }
 
 enum : uint8_t { F_COPY = 0, F_ONE = 1, F_BILINEAR = 2, F_BOX = 3 };
 
-/* build-time A/B switch: register-prefetch staging for k_tile (smol_kernel_tile.hip.h TILE_STAGE_RPF). Measured
- * 3-10 % SLOWER than the LDS-DMA double buffer on every row of the config table although it keeps 1.5x the bytes in
- * flight per CU (profiles/r03a_tile_rpf_ab.txt): off. */
-#ifndef SMOL_TILE_RPF
-#define SMOL_TILE_RPF 0
-#endif
-
 /* k_tile: vertical mode compiled into the entry point (JobDev::tile_vm), and the most vertical
  * samples a tile may hold (its schedule is one register: lane k = sample k, lane 63 a sentinel) */
 enum : uint8_t { TILE_VM_ANY = 0, TILE_VM_COPY = 1, TILE_VM_PAIR = 2, TILE_VM_BOX = 3 };
@@ -81,7 +74,6 @@ struct JobDev
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
     uint8_t box2_vlpc;             /* k_boxv: lanes per output pixel (1 or 8)           */
     uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
-    uint8_t tile_rpf;              /* k_tile: register-prefetch staging (TILE_STAGE_RPF): the ring holds >= 1 row of the span */
     uint8_t dbg;                   /* -DSMOL_TUNING builds only (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores; else 0 */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
@@ -366,31 +358,12 @@ tile_setup (JobDev &d)
         if (rows2 > d.group_rows)
             d.group_rows = (uint16_t) rows2;
     }
-
-    /* Register-prefetch staging (smol_kernel_tile.hip.h, TILE_STAGE_RPF): the next group of rows waits in the wave's
-     * registers (RQ 16-byte chunks per lane) while LDS holds ONE group. For every job whose span fits the ring;
-     * premultiply-while-staging through registers (tapsel 1), the 8-lanes-per-column box and the 128bpp class keep
-     * their staging. */
-    d.tile_rpf = 0;
-    {
-        const uint32_t rq = (hm == 4 || d.tile_cpl == 4) ? 6u : 4u;         /* = tile_rq<HM, CPL> () */
-        if (SMOL_TILE_RPF && !d.wide && tapsel != 1 && hm != 5 && d.span_chunks <= rq * 64u && !tune_env ("SMOL_TILE_NO_RPF"))
-        {
-            uint32_t rows3 = rq * 64u / d.span_chunks;
-            if (rows3 > 16) rows3 = 16;
-            d.tile_rpf = 1;
-            d.tile_single = 1;
-            d.group_rows = (uint16_t) rows3;
-        }
-    }
 }
 
 inline uint32_t
 tile_lds_bytes (const JobDev &d)
 {
     uint32_t bytes = (d.tile_single ? 1u : 2u) * d.group_rows * d.span_chunks * 16 + 32;
-    if (d.tile_rpf)
-        bytes = (((d.tile_variant >> 2) & 7u) == 4 || d.tile_cpl == 4 ? 6u : 4u) * 1024u + 32;  /* the whole ring lands in LDS */
     if (!d.wide && d.unassoc_out)
         bytes += 1024;                          /* k_tile: LDS copy of the inverse-alpha table */
     if (d.wide)

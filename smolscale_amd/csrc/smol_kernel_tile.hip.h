@@ -30,22 +30,15 @@ namespace smolhip {
 
 constexpr uint32_t TILE_COLS = 64;
 
-/* build-time A/B switches (tools/build_tuning.sh): bit 0 / bit 1 of SMOL_TILE_PREFETCH = software-pipelined tap
- * reads for the one-column / four-column entry points, SMOL_TILE_BOXBATCH = batched box interior */
-#ifndef SMOL_TILE_PREFETCH
-#define SMOL_TILE_PREFETCH 0    /* measured (profiles/r03a_tile_ab.txt): 2-8 % SLOWER -- the kernel is bound by vector issue, not by LDS latency */
-#endif
+/* build-time A/B switches (tools/build_tuning.sh "-DSMOL_TILE_...=0"): the batched box interior, its per-lane
+ * rotated read order and the raised issue priority around the staging requests. Three experiments of round 3 that
+ * measured SLOWER are not in the source any more (git 6a0830b, b1ae108, cd7fed3; numbers in DESIGN.md 4.2):
+ * register-prefetch staging, software-pipelined tap reads, byte-addressed LDS reads. */
 #ifndef SMOL_TILE_BOXBATCH
 #define SMOL_TILE_BOXBATCH 1
 #endif
 #ifndef SMOL_TILE_PRIO
 #define SMOL_TILE_PRIO 1        /* s_setprio around the staging requests */
-#endif
-#ifndef SMOL_TILE_UNALIGNED_LDS
-#define SMOL_TILE_UNALIGNED_LDS 0   /* byte-addressed ds_read_b64 / b32 for 24-bit and unaligned 32-bit taps: they return the right bytes
-                                     * on gfx950 (tools/microbench/lds_unaligned.hip) but a misaligned LDS read is far slower than
-                                     * three aligned dwords + v_alignbyte: 4000x3000 RGB8 -> 1600x1200 118 -> 233 us, gamma-correct
-                                     * thumbnails 248 -> 439 (profiles/r03d_unaligned_lds.txt). Off. */
 #endif
 #ifndef SMOL_TILE_BOXROT
 #define SMOL_TILE_BOXROT 1      /* per-lane rotated read order inside a batch of four box pixels */
@@ -196,14 +189,9 @@ __device__ __forceinline__ uint32_t premul_word (uint32_t w, uint32_t ain)
 /* 4 bytes starting at an arbitrary LDS byte offset, through 4-byte aligned reads */
 __device__ __forceinline__ uint32_t lds_load_unaligned (const uint8_t *sb, uint32_t off)
 {
-#if SMOL_TILE_UNALIGNED_LDS
-    /* ds_read_b32 takes any byte address on gfx950 (tools/microbench/lds_unaligned.hip) */
-    typedef uint32_t u32a1 __attribute__ ((aligned (1)));
-    return *reinterpret_cast<const u32a1 *> (sb + off);
-#else
+    /* (byte-addressed ds_read_b32 / b64 work on gfx950 but are far slower: DESIGN.md 4.2) */
     const uint32_t *pp = reinterpret_cast<const uint32_t *> (sb + (off & ~3u));
     return __builtin_amdgcn_alignbyte (pp [1], pp [0], off & 3u);
-#endif
 }
 
 /* unassociated word -> premultiplied Px2 directly, in packed 16-bit lanes:
@@ -259,27 +247,6 @@ __device__ __forceinline__ TapRaw tile_tap_load (const uint8_t *rowb, uint32_t o
         r.d1 = PAIR ? pp [1] : 0u;
         r.d2 = 0u;
     }
-    else if (SMOL_TILE_UNALIGNED_LDS)
-    {
-        /* ONE LDS read at the pixel's own byte address: ds_read_b64 / ds_read_b32 take any address on gfx950 (a
-         * misaligned one costs two LDS passes -- tools/microbench/lds_unaligned.hip -- which is what the three aligned
-         * dwords cost before) and the bytes arrive where the unpack wants them: no address masking, no v_alignbyte.
-         * 24-bit and unaligned 32-bit sources are bound by exactly that arithmetic. */
-        typedef uint64_t u64a1 __attribute__ ((aligned (1)));
-        typedef uint32_t u32a1 __attribute__ ((aligned (1)));
-        if (PAIR)
-        {
-            const uint64_t v = *reinterpret_cast<const u64a1 *> (rowb + off);
-            r.d0 = (uint32_t) v;
-            r.d1 = (uint32_t) (v >> 32);
-        }
-        else
-        {
-            r.d0 = *reinterpret_cast<const u32a1 *> (rowb + off);
-            r.d1 = 0u;
-        }
-        r.d2 = 0u;
-    }
     else
     {
         /* 4-byte aligned reads around the pixel(s); v_alignbyte does the rest in tile_tap_unpack */
@@ -304,20 +271,12 @@ __device__ __forceinline__ void tile_tap_unpack (const JobDev &J, const TapRaw &
     }
     else if (TAP == TAP_U4)
     {
-        if (SMOL_TILE_UNALIGNED_LDS)
-        {
-            wp = r.d0;
-            wq = PAIR ? r.d1 : wp;
-        }
+        /* v_alignbyte shifts by the low two bits of its third operand: `off' goes in as is */
+        wp = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);
+        if (PAIR)
+            wq = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
         else
-        {
-            /* v_alignbyte shifts by the low two bits of its third operand: `off' goes in as is */
-            wp = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);
-            if (PAIR)
-                wq = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
-            else
-                wq = wp;
-        }
+            wq = wp;
         if (J.unassoc_in)
         {
             p = premul_px2 (wp, J.pos_in [3]);
@@ -327,12 +286,12 @@ __device__ __forceinline__ void tile_tap_unpack (const JobDev &J, const TapRaw &
     }
     else
     {
-        const uint32_t b0 = SMOL_TILE_UNALIGNED_LDS ? r.d0 : __builtin_amdgcn_alignbyte (r.d1, r.d0, off);     /* bytes 0..3 from p */
+        const uint32_t b0 = __builtin_amdgcn_alignbyte (r.d1, r.d0, off);     /* bytes 0..3 from p */
         if (PAIR)
         {
             /* bytes 0..7 from p hold both pixels (p = bytes 0-2, q = bytes 3-5): four v_perm pick
              * the packed halves directly -- selector 0x0c = 0x00, 0x0d = 0xff (the alpha lane) */
-            const uint32_t b1 = SMOL_TILE_UNALIGNED_LDS ? r.d1 : __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
+            const uint32_t b1 = __builtin_amdgcn_alignbyte (r.d2, r.d1, off);
             p.lo = __builtin_amdgcn_perm (b1, b0, 0x0c020c00u);
             p.hi = __builtin_amdgcn_perm (b1, b0, 0x0c0d0c01u);
             q.lo = __builtin_amdgcn_perm (b1, b0, 0x0c050c03u);
@@ -623,25 +582,8 @@ enum : int
 {
     TILE_STAGE_DMA = 0,             /* global_load_lds, double buffered                                   */
     TILE_STAGE_REG_PREMUL = 1,      /* through registers, premultiplying on the way (re-used pixels)      */
-    TILE_STAGE_DMA_PREMUL = 2,      /* DMA, then one in-place premultiply pass over the group in LDS      */
-    TILE_STAGE_RPF = 3,             /* registers hold the NEXT group in flight while LDS holds the one being consumed */
-    TILE_STAGE_RPF_PREMUL = 4       /* ... premultiplying between register and LDS                        */
+    TILE_STAGE_DMA_PREMUL = 2       /* DMA, then one in-place premultiply pass over the group in LDS      */
 };
-
-/* Register-prefetch staging (TILE_STAGE_RPF*). What bounds the DMA variants is the number of bytes the chip has in
- * flight, and with LDS-DMA that is capped by the LDS itself: every byte in flight needs its landing place there, and
- * half of a wave's LDS is the group being consumed (profiles/r03a_tile_budget_sweep.txt: 2 to 6 KiB per buffer, 13 to
- * 32 waves per CU, all within 2 % -- the product is what counts, and it is fixed). Here the landing place is the
- * register file: a wave keeps TILE_RQ 16-byte chunks per lane (RQ KiB per wave) requested for the whole time it
- * filters the previous group, then moves them to its ONE LDS buffer (ds_write_b128, lanes contiguous) and asks for
- * the next group at once. Chunk slot c = u * 64 + lane of a group is (row c / span_chunks, chunk c % span_chunks):
- * all 64 lanes load whatever the span's width, and a slot's byte offset from the group's first byte is the same for
- * every group of the tile (e [u], computed once). LDS layout and the row loop are those of the DMA variants. */
-template <int HM, int CPL>
-__host__ __device__ constexpr uint32_t tile_rq ()
-{
-    return (HM == 4 || CPL == 4) ? 6u : 4u;
-}
 
 /* unassociated -> premultiplied on a whole pixel word in packed 16-bit lanes: (c + 1) * (a + 1) - 1 == c * (a + 1) + a
  * <= 65535, one v_pk_mad_u16 per pair of channels; asel = v_perm selector that splats the alpha byte into both lanes,
@@ -798,53 +740,11 @@ __device__ __forceinline__ void tile_stage (const JobDev &J, uint8_t *buf, uint3
     }
 }
 
-#ifdef SMOL_KERNEL_EMU
-__device__ __forceinline__ u32x4 tile_load_chunk (uintptr_t a) { return *reinterpret_cast<const u32x4 *> (a); }
-#else
-__device__ __forceinline__ u32x4 tile_load_chunk (uintptr_t a)
-{
-    return __builtin_nontemporal_load (reinterpret_cast<const SMOL_AS_GLOBAL u32x4 *> (a));
-}
-#endif
-
-/* Request the group of source rows [gfirst, gfirst + nrows) into the register ring. e [u]: byte offset of slot
- * u * 64 + lane from the group's first byte (0 for the slots past the group). A slot's address is the 16-byte
- * frame that holds that byte: (G + e) & ~15. `edge': the group is short or holds the image's last row -- slots are
- * then checked one by one, so that no frame without a byte of the image is touched (a frame with one cannot
- * fault: it lies in that byte's page). */
-template <uint32_t RQ>
-__device__ __forceinline__ void tile_rpf_issue (const JobDev &J, u32x4 (&ring) [RQ], const uint32_t (&e) [RQ], uint32_t lane,
-                                                uint32_t gfirst, uint32_t nrows, uint32_t g0, uint32_t g1, bool edge)
-{
-    const uintptr_t G = (uintptr_t) J.src + (size_t) gfirst * J.src_stride + g0;
-    const uintptr_t Gb = G & ~(uintptr_t) 15;
-    const uint32_t m0 = (uint32_t) G & 15u;
-
-    if (!edge)
-    {
-#pragma unroll
-        for (uint32_t u = 0; u < RQ; u++)
-            ring [u] = tile_load_chunk (Gb + ((m0 + e [u]) & ~15u));
-        return;
-    }
-    const uint32_t span15 = g1 - g0 + 15u;
-#pragma unroll
-    for (uint32_t u = 0; u < RQ; u++)
-    {
-        const uint32_t c = u * TILE_COLS + lane;
-        const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
-        const uint32_t k = c - i * J.span_chunks;
-        const uint32_t mis = (m0 + e [u]) & 15u;
-        const bool ok = (i < nrows) && (k * 16u < ((mis + span15) & ~15u));
-        ring [u] = tile_load_chunk (Gb + (ok ? ((m0 + e [u]) & ~15u) : 0u));
-    }
-}
-
 /* entry points that may run several waves per workgroup (smol_k_tile.inc.h: tile_wg_shape): plain 32-bit
  * source, one sample and one column per lane, bilinear vertical filter, DMA staging */
 __host__ __device__ constexpr bool tile_multiwave_variant (int tap, int hm, int stage, int cpl, int vm)
 {
-    return tap == 0 /* TAP_A4 */ && (stage == 0 /* TILE_STAGE_DMA */ || stage == 3 /* TILE_STAGE_RPF */) && hm == 1 && cpl == 1 && vm == TILE_VM_PAIR;
+    return tap == 0 /* TAP_A4 */ && stage == 0 /* TILE_STAGE_DMA */ && hm == 1 && cpl == 1 && vm == TILE_VM_PAIR;
 }
 
 /* TAP: how taps are read. HM: 0 = COPY/ONE, 1/2/3 = bilinear with 1/2/4 samples
@@ -866,15 +766,11 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     constexpr uint32_t BPP = (TAP == TAP_U3) ? 3u : 4u;
     constexpr uint32_t TW = TILE_COLS * CPL / LPC;
     static_assert (!HBOX || CPL == 1, "box columns are one per lane group");
-    constexpr bool RPF = (STAGE == TILE_STAGE_RPF || STAGE == TILE_STAGE_RPF_PREMUL);
-    constexpr uint32_t RQ = tile_rq<HM, CPL> ();
-    constexpr bool DMA = (STAGE != TILE_STAGE_REG_PREMUL) && !RPF;
+    constexpr bool DMA = (STAGE != TILE_STAGE_REG_PREMUL);
     /* one staging buffer, no prefetch of the next group: a property of the entry point (smol_jobdev.h sizes the
      * LDS and the groups for it under the same condition: tile_setup) */
-    constexpr bool single = (STAGE == TILE_STAGE_DMA_PREMUL) || RPF
+    constexpr bool single = (STAGE == TILE_STAGE_DMA_PREMUL)
                             || (STAGE == TILE_STAGE_DMA && TAP == TAP_A4 && HM == 1 && CPL == 1 && VM == TILE_VM_PAIR);
-    /* software-pipelined tap reads (the next row's LDS words are in flight during this row's arithmetic) */
-    constexpr bool PF = !HBOX && (CPL == 1 ? (SMOL_TILE_PREFETCH & 1) : (SMOL_TILE_PREFETCH & 2)) != 0;
 
     /* grid = (groups of column tiles, row tiles, jobs): raster order over the tiles, no integer division at the
      * head of a workgroup. A workgroup is 1 wave or 4 waves on 4 neighbouring column tiles (smol_k_tile.inc.h);
@@ -1060,7 +956,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     const uint32_t *inv_tab = nullptr;
     if (OUT == OUT_U4 || (OUT == OUT_ANY && J.unassoc_out))
     {
-        uint8_t *tab = sbuf + (RPF ? RQ * 1024u : (single ? 1u : 2u) * buf_bytes);
+        uint8_t *tab = sbuf + (single ? 1u : 2u) * buf_bytes;
         smol_global_load_lds16 (reinterpret_cast<const uint8_t *> (smol_inv_p8_lut) + lane * 16u, tab, lane);
         if (!DMA)
             smol_wait_vmcnt0 ();
@@ -1070,60 +966,11 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     if (DMA && !dbg_nostage && !single)
         tile_stage<true, false> (J, sbuf, lane, gfirst, nrows, g0, g1);
 
-    /* register prefetch: slot offsets (the same for every group of the tile), first group requested */
-    u32x4 ring [RQ];
-    uint32_t ring_e [RQ];
-    const uint32_t rpf_apos = J.pos_in [3] & 3u;          /* (0xff for 24-bit sources, which are never premultiplied) */
-    const uint32_t rpf_asel = 0x0c000c00u | rpf_apos | (rpf_apos << 16);
-    const uint32_t rpf_amask = 0xffu << (8u * rpf_apos);
-    if (RPF)
-    {
-#pragma unroll
-        for (uint32_t u = 0; u < RQ; u++)
-        {
-            const uint32_t c = u * TILE_COLS + lane;
-            const uint32_t i = (uint32_t) (((uint64_t) c * J.span_chunks_inv) >> 32);
-            const uint32_t k = c - i * J.span_chunks;
-            ring_e [u] = (i < J.group_rows) ? i * J.src_stride + k * 16u : 0u;
-            ring [u] = u32x4 { 0, 0, 0, 0 };
-        }
-        if (!dbg_nostage)
-            tile_rpf_issue<RQ> (J, ring, ring_e, lane, gfirst, nrows, g0, g1,
-                                nrows < J.group_rows || gfirst + nrows >= J.h_in);
-    }
-
     while (true)
     {
         uint8_t *buf = sbuf + cur * buf_bytes;
 
-        if (RPF)
-        {
-            /* the previous group has been consumed (LDS operations of a wave complete in order): park this one in
-             * LDS -- the compiler's own s_waitcnt guards the ring registers -- and request the next */
-            smol_wave_sync ();
-#pragma unroll
-            for (uint32_t u = 0; u < RQ; u++)
-            {
-                u32x4 v = ring [u];
-                if (STAGE == TILE_STAGE_RPF_PREMUL && !dbg_notaps)
-                {
-                    v.x = premul_word_pk (v.x, rpf_asel, rpf_amask);
-                    v.y = premul_word_pk (v.y, rpf_asel, rpf_amask);
-                    v.z = premul_word_pk (v.z, rpf_asel, rpf_amask);
-                    v.w = premul_word_pk (v.w, rpf_asel, rpf_amask);
-                }
-                *reinterpret_cast<u32x4 *> (buf + (u * TILE_COLS + lane) * 16u) = v;
-            }
-            smol_wave_sync ();
-            const uint32_t nfirst = gfirst + nrows;
-            if (nfirst <= row_last && !dbg_nostage)
-            {
-                const uint32_t nn = (row_last - nfirst + 1 < J.group_rows) ? row_last - nfirst + 1 : J.group_rows;
-                tile_rpf_issue<RQ> (J, ring, ring_e, lane, nfirst, nn, g0, g1,
-                                    nn < J.group_rows || nfirst + nn >= J.h_in);
-            }
-        }
-        else if (DMA && single)
+        if (DMA && single)
         {
             /* one buffer: request the group, wait for it (the waves next door fill the gap) */
             smol_wave_sync ();
@@ -1175,21 +1022,6 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
         /* ---- consume the staged rows in order ------------------------------------- */
         uint32_t ra_lo = (uint32_t) (src_base + (size_t) gfirst * J.src_stride + g0);   /* low bits of the row's first byte */
         const uint8_t *rowbase = buf;
-        /* PF: the LDS words of row i + 1's taps are requested before row i's arithmetic, so that a row
-         * costs the wave one LDS round trip less (the chain read -> wait -> 26 vector instructions was
-         * 40 % round trip at 5 waves per SIMD) */
-        TapRaw nraw [CPL][NSX];
-        if (PF)
-        {
-            const uint32_t mis0 = ra_lo & 15u;
-            const uint8_t *rowb0 = rowbase + ((TAP == TAP_A4) ? mis0 : 0u);
-            const uint32_t tmis0 = (TAP == TAP_A4) ? 0u : mis0;
-#pragma unroll
-            for (int c = 0; c < CPL; c++)
-#pragma unroll
-                for (uint32_t s = 0; s < NSX; s++)
-                    nraw [c][s] = tile_tap_load<TAP, HPAIR> (rowb0, tap_ofs [c][s] + tmis0);
-        }
         for (uint32_t i = 0; i < nrows; i++, ra_lo += J.src_stride, rowbase += row_pitch)
         {
             const uint32_t r = gfirst + i;
@@ -1199,25 +1031,6 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
              * unaligned reader's dword loads stay 4-byte aligned in LDS. */
             const uint8_t *rowb = rowbase + ((TAP == TAP_A4) ? mis : 0u);
             const uint32_t tmis = (TAP == TAP_A4) ? 0u : mis;
-
-            TapRaw raw [CPL][NSX];
-            if (PF)
-            {
-                /* the last row of a group asks for itself again (wave-uniform select, no branch) */
-                const bool more = i + 1u < nrows;
-                const uint32_t nmis = (ra_lo + (more ? J.src_stride : 0u)) & 15u;
-                const uint8_t *nbase = rowbase + (more ? row_pitch : 0u);
-                const uint8_t *nrowb = nbase + ((TAP == TAP_A4) ? nmis : 0u);
-                const uint32_t ntmis = (TAP == TAP_A4) ? 0u : nmis;
-#pragma unroll
-                for (int c = 0; c < CPL; c++)
-#pragma unroll
-                    for (uint32_t s = 0; s < NSX; s++)
-                    {
-                        raw [c][s] = nraw [c][s];
-                        nraw [c][s] = tile_tap_load<TAP, HPAIR> (nrowb, tap_ofs [c][s] + ntmis);
-                    }
-            }
 
             Px2 h [CPL];
 #pragma unroll
@@ -1327,10 +1140,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
                 else if (HM == 0)
                 {
                     Px2 pp, qq;
-                    if (PF)
-                        tile_tap_unpack<TAP, false> (J, raw [c][0], tap_ofs [c][0] + tmis, pp, qq);
-                    else
-                        tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, pp, qq);
+                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, pp, qq);
                     h [c] = pp;
                 }
                 else
@@ -1339,10 +1149,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
                     for (uint32_t s = 0; s < NSX; s++)
                     {
                         Px2 pp, qq;
-                        if (PF)
-                            tile_tap_unpack<TAP, true> (J, raw [c][s], tap_ofs [c][s] + tmis, pp, qq);
-                        else
-                            tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
+                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
                         const Px2 t = tap2 (pp, qq, tap_f [c][s]);
                         h [c] = s ? px2_add (h [c], t) : t;
                     }
@@ -1531,19 +1338,6 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
  * while staging, 2 U4, 3 U3, 4 A4 after an in-LDS premultiply pass (smol_jobdev.h: tile_setup) */
 __device__ __forceinline__ void tile_dispatch (const JobDev &J, uint8_t *sbuf)
 {
-#if SMOL_TILE_RPF
-    if (J.tile_rpf)
-    {
-        switch (J.tile_variant >> 5)
-        {
-            case 0:  tile_dispatch_hm<TAP_A4, TILE_STAGE_RPF> (J, sbuf); return;
-            case 2:  tile_dispatch_hm<TAP_U4, TILE_STAGE_RPF> (J, sbuf); return;
-            case 3:  tile_dispatch_hm<TAP_U3, TILE_STAGE_RPF> (J, sbuf); return;
-            case 4:  tile_dispatch_hm<TAP_A4, TILE_STAGE_RPF_PREMUL> (J, sbuf); return;
-            default: break;
-        }
-    }
-#endif
     switch (J.tile_variant >> 5)
     {
         case 0:  tile_dispatch_hm<TAP_A4, TILE_STAGE_DMA> (J, sbuf); break;
@@ -1567,15 +1361,6 @@ __device__ __forceinline__ void tile_entry (const JobDev &J, uint8_t *sbuf, cons
 {
     constexpr int TAP = (TS <= 1 || TS == 4) ? TAP_A4 : (TS == 2 ? TAP_U4 : TAP_U3);
     constexpr int STAGE = (TS == 1) ? TILE_STAGE_REG_PREMUL : (TS == 4 ? TILE_STAGE_DMA_PREMUL : TILE_STAGE_DMA);
-#if SMOL_TILE_RPF
-    /* register-prefetch staging where the host found the span to fit the ring (JobDev::tile_rpf) */
-    constexpr int STAGE_R = (TS == 4) ? TILE_STAGE_RPF_PREMUL : TILE_STAGE_RPF;
-    if (TS != 1 && HM != 5 && J.tile_rpf)
-    {
-        tile_dispatch_out<TAP, HM, STAGE_R, CPL, VM> (J, sbuf, bx, by, wg_waves);
-        return;
-    }
-#endif
     tile_dispatch_out<TAP, HM, STAGE, CPL, VM> (J, sbuf, bx, by, wg_waves);
 }
 
