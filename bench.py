@@ -451,6 +451,57 @@ def e2e_c2(local_rank, frame0, want0, reps=3, n_callers=16):
     frame_bytes, out_bytes = W_IN * H_IN * 4, W_OUT * H_OUT * 4
     moved = frame_bytes + out_bytes
 
+    # The caller's threads and buffers should sit on the NUMA node the GPU hangs off (a two-socket host copies at half
+    # the link rate from the far socket, and this process has just been spread over every core by the cpu_baseline
+    # leg): probe each node with one page-locked frame, keep the best for both legs, restore the affinity afterwards.
+    nodes = {}
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if d.startswith("node") and d[4:].isdigit():
+                cpus = set()
+                for part in open("/sys/devices/system/node/%s/cpulist" % d).read().strip().split(","):
+                    if part:
+                        a, _, b = part.partition("-")
+                        cpus.update(range(int(a), int(b or a) + 1))
+                if cpus:
+                    nodes[int(d[4:])] = cpus
+    except OSError:
+        pass
+    old_aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+
+    def probe():
+        a, b = sm.PinnedArray(frame_bytes), sm.PinnedArray(out_bytes)
+        a.array[:] = frame0[:frame_bytes]                      # first touch on the current node
+        try:
+            with sm.SmolScaleCtx(a.array, PIX_TYPE, W_IN, H_IN, W_IN * 4, b.array, PIX_TYPE, W_OUT, H_OUT, W_OUT * 4) as c:
+                c.batch(0, H_OUT)
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    c.batch(0, H_OUT)
+                    best = min(best, time.perf_counter() - t0)
+        finally:
+            a.free()
+            b.free()
+        return best
+
+    if old_aff is not None and len(nodes) > 1:
+        per_node = {}
+        for k, cpus in nodes.items():
+            allowed = cpus & old_aff
+            if not allowed:
+                continue
+            try:
+                os.sched_setaffinity(0, allowed)
+                per_node[k] = probe()
+            except Exception:                                   # noqa: BLE001
+                pass
+        if per_node:
+            best_node = min(per_node, key=per_node.get)
+            os.sched_setaffinity(0, nodes[best_node] & old_aff)
+            out["numa"] = {"nodes_probed_ms": {str(k): round(v * 1e3, 3) for k, v in per_node.items()},
+                           "callers_pinned_to_node": best_node}
+
     def one_call(src, dst):
         with sm.SmolScaleCtx(src, PIX_TYPE, W_IN, H_IN, W_IN * 4, dst, PIX_TYPE, W_OUT, H_OUT, W_OUT * 4) as c:
             c.batch(0, H_OUT)
@@ -502,6 +553,11 @@ def e2e_c2(local_rank, frame0, want0, reps=3, n_callers=16):
             out[mode] = {"error": repr(e)}
         for k in keep:
             k.free()
+    if old_aff is not None:
+        try:
+            os.sched_setaffinity(0, old_aff)
+        except OSError:
+            pass
     out["bytes_over_pcie_per_frame"] = moved
     out["what"] = ("4096x4096->1024x1024 RGBA8 premultiplied frames in HOST memory through smol_scale_new/batch/destroy "
                    "(the drop-in API): source up and result down over the PCIe link on every call; best of %d" % reps)
