@@ -457,14 +457,15 @@ __global__ void k_down_one (const JobDev J)
     }
     if (J.tile_cpl == 4)
     {
-        down_body<0, 4, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
+        /* (DOWN_P16 has no table copy: the table argument is any valid LDS address, never dereferenced) */
+        down_body<0, 4, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x);
         return;
     }
     switch (J.halv_h)
     {
-        case 0: down_body<0, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
-        case 1: down_body<1, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
-        default: down_body<2, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
+        case 0: down_body<0, 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x); break;
+        case 1: down_body<1, 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x); break;
+        default: down_body<2, 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x); break;
     }
 }
 #else
@@ -474,14 +475,14 @@ __global__ void __launch_bounds__ (64)
 k_down_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x);
 }
 
 template <int HC>
 __global__ void __launch_bounds__ (64)
 k_down_one (const JobDev J)
 {
-    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x);
 }
 
 template <int HX, int MODE>

@@ -181,16 +181,17 @@ struct LutLds
     const uint16_t *fs, *oq;
     const uint8_t *ts;
 
-    /* (the 64bpp-class instantiations of the shared bodies pass no table copy: offsets from the integer value, never
-     * arithmetic on a null pointer) */
+    /* Plain pointer arithmetic on `base': going through an integer here made the compiler forget that the tables live
+     * in LDS (flat_load instead of ds_read: the gamma-correct rows ran 10-20 % slower for a few commits of round 3).
+     * The 64bpp-class instantiations of the shared bodies have no table copy; they pass any valid LDS address. */
     __device__ __forceinline__ explicit LutLds (const uint8_t *base)
-        : p8 (reinterpret_cast<const uint32_t *> ((uintptr_t) base)),
-          p8l (reinterpret_cast<const uint32_t *> ((uintptr_t) base + 1024)),
-          p16 (reinterpret_cast<const uint32_t *> ((uintptr_t) base + 2048)),
-          p16l (reinterpret_cast<const uint32_t *> ((uintptr_t) base + 3072)),
-          fs (reinterpret_cast<const uint16_t *> ((uintptr_t) base + 4096)),
-          oq (reinterpret_cast<const uint16_t *> ((uintptr_t) base + 6656)),
-          ts (reinterpret_cast<const uint8_t *> ((uintptr_t) base + 4608)) {}
+        : p8 (reinterpret_cast<const uint32_t *> (base)),
+          p8l (reinterpret_cast<const uint32_t *> (base + 1024)),
+          p16 (reinterpret_cast<const uint32_t *> (base + 2048)),
+          p16l (reinterpret_cast<const uint32_t *> (base + 3072)),
+          fs (reinterpret_cast<const uint16_t *> (base + 4096)),
+          oq (reinterpret_cast<const uint16_t *> (base + 6656)),
+          ts (base + 4608) {}
 
     __device__ __forceinline__ uint32_t inv_p8 (uint32_t a) const { return p8 [a]; }
     __device__ __forceinline__ uint32_t inv_p8l (uint32_t a) const { return p8l [a]; }
