@@ -31,13 +31,16 @@
 namespace smolhip {
 
 
-/* One staged source pixel at byte offset `off' of the LDS row (any alignment). */
+template <bool V> struct BoxAligned { static constexpr bool value = V; };
+
+/* One staged source pixel at byte offset `off' of the LDS row. AL (compile time, chosen once per wave outside the
+ * row loop -- as a per-read test it cost the 24-bit thumbnails 4-8 %): 32-bit pixels on 4-byte boundaries, which sit
+ * on 4-byte LDS boundaries too (the staged row keeps the source's phase): one aligned read (gamma-correct 4096^2 ->
+ * 448^2 286 -> 271 us); everything else through two aligned dwords and v_alignbyte. */
+template <bool AL>
 __device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t *rowb, uint32_t off)
 {
-    /* 32-bit pixels on 4-byte boundaries sit on 4-byte LDS boundaries too (the staged row keeps the source's phase):
-     * one aligned read (gamma-correct 4096^2 -> 448^2 286 -> 271 us); everything else through two aligned dwords and
-     * v_alignbyte */
-    if (J.in_dword_ok)
+    if (AL)
         return *reinterpret_cast<const uint32_t *> (rowb + off);
     const uint32_t w = lds_load_unaligned (rowb, off);
     return (J.bpp_in == 3) ? (w | 0xff000000u) : w;
@@ -90,6 +93,9 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
     const LutLds lut (lut_lds);
     const uintptr_t src_base = (uintptr_t) J.src;
 
+    auto rows = [&] (auto aligned_tag)
+    {
+    constexpr bool AL = decltype (aligned_tag)::value;
     for (uint32_t r = r0; r <= r1; r++)
     {
         /* one row buffer per wave: request the row, wait for it, sum it (the waves next door fill the gap) */
@@ -108,11 +114,11 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             uint32_t acc [4] = { 0, 0, 0, 0 }, c [4];
             if (edges)
             {
-                unpack_word<true> (J, box2_px_word (J, rowb, off), c, lut);
+                unpack_word<true> (J, box2_px_word<AL> (J, rowb, off), c, lut);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     acc [i] = ((c [i] * wl) >> 8) & 0x00ffffffu;
-                unpack_word<true> (J, box2_px_word (J, rowb, last_ofs + mis), c, lut);
+                unpack_word<true> (J, box2_px_word<AL> (J, rowb, last_ofs + mis), c, lut);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     acc [i] += ((c [i] * fr) >> 8) & 0x00ffffffu;
@@ -124,7 +130,7 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                 uint32_t w4 [4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++)
-                    w4 [u] = (k + u < n_int) ? box2_px_word (J, rowb, off + u * bpp) : 0u;
+                    w4 [u] = (k + u < n_int) ? box2_px_word<AL> (J, rowb, off + u * bpp) : 0u;
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++)
                 {
@@ -160,9 +166,9 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             Px2 a = { 0, 0 };
             if (edges)
             {
-                w = box2_px_word (J, rowb, off);
+                w = box2_px_word<AL> (J, rowb, off);
                 a = px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), wl);
-                w = box2_px_word (J, rowb, last_ofs + mis);
+                w = box2_px_word<AL> (J, rowb, last_ofs + mis);
                 a = px2_add (a, px2_mulw (pm ? premul_px2 (w, ain) : px2_from_word (w), fr));
             }
             off = int_ofs + mis;
@@ -208,7 +214,7 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                     uint32_t w4 [4];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++)
-                        w4 [u] = (k + u < n_int) ? box2_px_word (J, rowb, off + u * bpp) : 0u;
+                        w4 [u] = (k + u < n_int) ? box2_px_word<AL> (J, rowb, off + u * bpp) : 0u;
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++)
                         a = px2_add (a, pm ? premul_px2 (w4 [u], ain) : px2_from_word (w4 [u]));
@@ -233,6 +239,11 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
         if (x < xn && sub == 0)
             *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (gptr (J.tmp) + ((size_t) (r - J.tmp_row0) * J.w_out + x) * 8) = res;
     }
+    };
+    if (J.in_dword_ok)
+        rows (BoxAligned<true> ());
+    else
+        rows (BoxAligned<false> ());
 }
 
 /* LPC = lanes per output pixel: 1, or 8 for tall boxes (the lanes take every 8th row of the
