@@ -74,6 +74,7 @@ struct JobDev
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
     uint8_t box2_vlpc;             /* k_boxv: lanes per output pixel (1 or 8)           */
     uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
+    uint8_t reserved0;             /* (keeps the 16-bit fields below on even offsets)     */
     uint8_t dbg;                   /* -DSMOL_TUNING builds only (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores; else 0 */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */

@@ -119,7 +119,13 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
     /* ---- staging ---------------------------------------------------------------------------- */
     const uint32_t buf_pitch = (J.span_px * PXB + 15u) & ~15u;      /* one LDS row buffer (host bound on the span) */
     uint32_t *inv_lut = reinterpret_cast<uint32_t *> (lds + 2 * (size_t) buf_pitch);       /* DOWN_P16 only */
-    const LutLds lut (lut_lds);                                                            /* table-driven flavours */
+    /* table-driven flavours only; DOWN_P16 has no table copy and passes nullptr (never dereferenced -- the host build, which
+     * UBSan checks, does not offset it either) */
+#ifdef SMOL_KERNEL_EMU
+    const LutLds lut (GEN ? lut_lds : lds);
+#else
+    const LutLds lut (lut_lds);
+#endif
     const uint32_t sr = 8u * J.pos_in [0], sg = 8u * J.pos_in [1], sb = 8u * J.pos_in [2], sa = 8u * J.pos_in [3];
     const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;   /* row being loaded */
 
@@ -457,15 +463,14 @@ __global__ void k_down_one (const JobDev J)
     }
     if (J.tile_cpl == 4)
     {
-        /* (DOWN_P16 has no table copy: the table argument is any valid LDS address, never dereferenced) */
-        down_body<0, 4, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x);
+        down_body<0, 4, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
         return;
     }
     switch (J.halv_h)
     {
-        case 0: down_body<0, 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x); break;
-        case 1: down_body<1, 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x); break;
-        default: down_body<2, 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x); break;
+        case 0: down_body<0, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
+        case 1: down_body<1, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
+        default: down_body<2, 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x); break;
     }
 }
 #else
@@ -475,14 +480,14 @@ __global__ void __launch_bounds__ (64)
 k_down_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x);
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
 }
 
 template <int HC>
 __global__ void __launch_bounds__ (64)
 k_down_one (const JobDev J)
 {
-    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, smol_dyn_lds, threadIdx.x, blockIdx.x);
+    down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
 }
 
 template <int HX, int MODE>
