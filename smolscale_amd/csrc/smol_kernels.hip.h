@@ -65,6 +65,19 @@ __device__ __forceinline__ const gbyte *gptr (const void *p)
     return reinterpret_cast<const gbyte *> (reinterpret_cast<uintptr_t> (p));
 }
 
+/* "every active lane of the wave sees an opaque pixel": the sRGB-linear conversions have a two-look-up shortcut for
+ * alpha = 255 whose results equal the general chain's. Taken per lane it makes a wave with ANY translucent pixel run
+ * both sides of the branch; taken per wave, photographs (all opaque) run the short side only and everything else the
+ * general side only. The host emulation runs lanes one after the other and decides per lane (same bytes either way). */
+__device__ __forceinline__ bool smol_wave_all_opaque (uint32_t a)
+{
+#ifdef SMOL_KERNEL_EMU
+    return a == 255u;
+#else
+    return __builtin_amdgcn_ballot_w64 (a != 255u) == 0;
+#endif
+}
+
 /* Descriptor `idx' of a device-resident table (idx wave-uniform). Fetched as whole dwords: the
  * compiler then uses scalar loads (s_load_dwordxN through the scalar cache) and picks the 8- and
  * 16-bit fields out of SGPRs. A plain struct copy loads every sub-dword member with its own
@@ -296,9 +309,9 @@ __device__ __forceinline__ void unpack_word (const JobDev &J, uint32_t w, uint32
     }
     else if (WIDE && J.linear)
     {
-        if (a == 255u)
+        if (smol_wave_all_opaque (a))
         {
-            /* opaque pixel (most pixels of most images): un-premultiplying by 255 is the
+            /* opaque pixels (most pixels of most images): un-premultiplying by 255 is the
              * identity, so premultiplied and unassociated input alike reduce to the fused table */
 #pragma unroll
             for (int i = 0; i < 3; i++)
@@ -391,7 +404,7 @@ __device__ __forceinline__ void pack_px_channels (const JobDev &J, const uint32_
         {
             c [i] = J.unassoc_out ? unpremul8 (s, a, lut) : (s & 0xffu);
         }
-        else if (a == 255u && !J.quirk24)
+        else if (!J.quirk24 && smol_wave_all_opaque (a))
         {
             /* opaque pixel: the inverse for 255 is 1028 = 1024 + 4, so (s * 1028) >> 10 is
              * s + (s >> 8) exactly, and premultiplying the sRGB byte by 255 is the identity:
