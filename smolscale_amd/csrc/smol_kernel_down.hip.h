@@ -127,6 +127,7 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
     const LutLds lut (lut_lds);
 #endif
     const uint32_t sr = 8u * J.pos_in [0], sg = 8u * J.pos_in [1], sb = 8u * J.pos_in [2], sa = 8u * J.pos_in [3];
+    const int uk = GEN ? wide_unpack_kind (J) : WU_P16, pk = GEN ? wide_pack_kind (J) : WP_P16;
     const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;   /* row being loaded */
 
     /* DOWN_P16 moves 4-pixel chunks (16-byte loads, cheap conversion); the table-driven
@@ -188,20 +189,44 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
     {
         if (GEN)
         {
-#pragma unroll
-            for (int l = 0; l < NRAW; l++)
+            /* the conversion's flavour is chosen once per row and wave (WideUnpack: branch-free inside, the look-ups
+             * of a lane's pixels in flight together); a row whose pixels are all opaque takes the fused table */
+            auto conv = [&] (const auto &un)
             {
-                const uint32_t i = (uint32_t) l * 64u + lane;
-                if ((uint32_t) l * 64u < npx && i < npx)
+#pragma unroll
+                for (int l = 0; l < NRAW; l++)
                 {
-                    uint32_t ch [4];
-                    unpack_word<true> (J, rawpx [l], ch, lut);
-                    if (MODE == DOWN_GEN32)
-                        *reinterpret_cast<u32x4 *> (buf + (size_t) i * 16) = u32x4 { ch [0], ch [1], ch [2], ch [3] };
-                    else
-                        *reinterpret_cast<u32x2a8 *> (buf + (size_t) i * 8) = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
+                    const uint32_t i = (uint32_t) l * 64u + lane;
+                    if ((uint32_t) l * 64u < npx && i < npx)
+                    {
+                        uint32_t ch [4];
+                        un (rawpx [l], ch);
+                        if (MODE == DOWN_GEN32)
+                            *reinterpret_cast<u32x4 *> (buf + (size_t) i * 16) = u32x4 { ch [0], ch [1], ch [2], ch [3] };
+                        else
+                            *reinterpret_cast<u32x2a8 *> (buf + (size_t) i * 8) = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
+                    }
                 }
+            };
+            if (uk == WU_LIN_P || uk == WU_LIN_U)
+            {
+                uint32_t all = 0xffffffffu;
+#pragma unroll
+                for (int l = 0; l < NRAW; l++)
+                    all &= ((uint32_t) l * 64u + lane < npx) ? rawpx [l] : 0xffffffffu;
+                if (wide_batch_opaque (J, all))
+                    conv (WideUnpack<WU_LIN_O> (J, lut));
+                else if (uk == WU_LIN_P)
+                    conv (WideUnpack<WU_LIN_P> (J, lut));
+                else
+                    conv (WideUnpack<WU_LIN_U> (J, lut));
             }
+            else if (uk == WU_LIN_O)
+                conv (WideUnpack<WU_LIN_O> (J, lut));
+            else if (uk == WU_P16L)
+                conv (WideUnpack<WU_P16L> (J, lut));
+            else
+                conv (WideUnpack<WU_ANY> (J, lut));
             return;
         }
 #pragma unroll
@@ -360,8 +385,26 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     v [i] = acc [0][i] >> hv;
-                if (xl < xn)
-                    store_px<true> (J, reinterpret_cast<uint8_t *> (reinterpret_cast<uintptr_t> (out_row)), xl, v, lut);
+                const bool live = xl < xn;
+                auto put = [&] (const auto &pack)
+                {
+                    const uint32_t w = pack (v);
+                    if (live)
+                        wide_store_word (J, out_row, xl, w);
+                };
+                /* once per output row and wave; all-opaque rows skip the inverse-alpha look-up and multiplies */
+                if ((pk == WP_LIN_P || pk == WP_LIN_U) && smol_wave_all_opaque (live ? v [3] & 0xffu : 255u))
+                    put (WidePack<WP_LIN_O> (J, lut));
+                else if (pk == WP_LIN_P)
+                    put (WidePack<WP_LIN_P> (J, lut));
+                else if (pk == WP_LIN_U)
+                    put (WidePack<WP_LIN_U> (J, lut));
+                else if (pk == WP_LIN_Q)
+                    put (WidePack<WP_LIN_Q> (J, lut));
+                else if (pk == WP_P16L)
+                    put (WidePack<WP_P16L> (J, lut));
+                else
+                    put (WidePack<WP_ANY> (J, lut));
                 s_y = 0;
                 out_row += J.dst_stride;
             }

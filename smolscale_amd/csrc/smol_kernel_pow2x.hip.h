@@ -18,8 +18,9 @@
  *                with v_alignbyte.
  *   IN = PX_W32 / PX_W24 / PX_W16
  *                128bpp class (premul16 and/or sRGB-linear, :470-752): pixels are
- *                unpacked to four 32-bit channels by the same unpack_word<true> /
- *                store_px<true> code k_general uses, tables read from an LDS copy.
+ *                unpacked to four 32-bit channels by WideUnpack / WidePack with the
+ *                flavour chosen once per lane (smol_kernels.hip.h), tables read from
+ *                an LDS copy.
  *
  * With w_in == w_out << (H+1) every sample sits at an even offset with F = 128
  * (closed form of :24-52), so for any channel width a tap
@@ -135,33 +136,15 @@ __device__ __forceinline__ uint32_t pow2x_premul_word (uint32_t w, uint32_t ain,
     return (r & ~amask) | (w & amask);
 }
 
-/* 128bpp-class unpack of one pixel word. P16FAST: premul16 without sRGB (the
- * unassociated -> unassociated default, :522-560) needs no tables and no mode
- * branches; everything else goes through unpack_word<true>. */
-template <bool P16FAST>
-__device__ __forceinline__ void pow2x_unpack_wide (const JobDev &J, uint32_t w, uint32_t (&c) [4], const LutLds &lut)
-{
-    if (P16FAST)
-    {
-        const uint32_t a = (w >> (8 * J.pos_in [3])) & 0xffu;
-        c [0] = __umul24 ((w >> (8 * J.pos_in [0])) & 0xffu, a);
-        c [1] = __umul24 ((w >> (8 * J.pos_in [1])) & 0xffu, a);
-        c [2] = __umul24 ((w >> (8 * J.pos_in [2])) & 0xffu, a);
-        c [3] = (a << 8) | 0x80u;
-    }
-    else
-    {
-        unpack_word<true> (J, w, c, lut);
-    }
-}
-
 /* 128bpp-class accumulation of one lane's source block: acc [o][ch] = sum over the
  * 2^H vertical taps (to be shifted right by H) */
-template <int H, int IN, bool P16FAST>
+template <int H, int IN, int UK>
 __device__ __forceinline__ void pow2x_wide_acc (const JobDev &J, const gbyte *sp, const LutLds &lut,
                                                 uint32_t (&acc) [Pow2xCfg<H, IN>::OPT][4])
 {
     using C = Pow2xCfg<H, IN>;
+    const WideUnpack<UK> unpack (J, lut);
+    const WideUnpack<WU_LIN_O> unpack_opaque (J, lut);
 
 #pragma unroll
     for (int o = 0; o < C::OPT; o++)
@@ -169,62 +152,72 @@ __device__ __forceinline__ void pow2x_wide_acc (const JobDev &J, const gbyte *sp
         for (int i = 0; i < 4; i++)
             acc [o][i] = 0;
 
-    /* One vertical tap = one pair of source rows. The pair loop is kept rolled and
-     * the next pair's loads are issued before the current pair is converted. */
-    typename Pow2xRaw<C::BPP3>::T cur [2][C::NLOAD], nxt [2][C::NLOAD];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int l = 0; l < C::NLOAD; l++)
-            cur [r][l] = pow2x_load<C::BPP3> (sp + (size_t) r * J.src_stride + l * C::LOADB);
-
+    /* One vertical tap = one pair of source rows. Rows come in chunks of up to four, every load of a chunk issued
+     * before the first conversion (a rolled pair loop with a "load the next pair" branch at its head ended up with
+     * those loads at the loop's tail, right in front of their wait: no overlap at all). */
+    constexpr int CH = C::R < 4 ? C::R : 4;
 #pragma unroll 1
-    for (int rp = 0; rp < C::R / 2; rp++)
+    for (int r0 = 0; r0 < C::R; r0 += CH)
     {
-        if (rp + 1 < C::R / 2)
-        {
+        typename Pow2xRaw<C::BPP3>::T raw [CH][C::NLOAD];
 #pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int l = 0; l < C::NLOAD; l++)
-                    nxt [r][l] = pow2x_load<C::BPP3> (sp + (size_t) (2 * rp + 2 + r) * J.src_stride + l * C::LOADB);
-        }
-
-        uint32_t wa [C::PXL], wb [C::PXL];
-        pow2x_words (cur [0], wa);
-        pow2x_words (cur [1], wb);
-
-#pragma unroll
-        for (int o = 0; o < C::OPT; o++)
-        {
-            /* horizontal, per row: 2^H taps of two pixels each, then the halving shift */
-            uint32_t ha [4] = { 0, 0, 0, 0 }, hb [4] = { 0, 0, 0, 0 };
-#pragma unroll
-            for (int t = 0; t < (1 << H); t++)
-            {
-                uint32_t p [4], q [4];
-                pow2x_unpack_wide<P16FAST> (J, wa [o * C::R + 2 * t], p, lut);
-                pow2x_unpack_wide<P16FAST> (J, wa [o * C::R + 2 * t + 1], q, lut);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    ha [i] += (p [i] + q [i]) >> 1;
-                pow2x_unpack_wide<P16FAST> (J, wb [o * C::R + 2 * t], p, lut);
-                pow2x_unpack_wide<P16FAST> (J, wb [o * C::R + 2 * t + 1], q, lut);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    hb [i] += (p [i] + q [i]) >> 1;
-            }
-            /* vertical tap of the two rows' results */
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                acc [o][i] += ((ha [i] >> H) + (hb [i] >> H)) >> 1;
-        }
-
-#pragma unroll
-        for (int r = 0; r < 2; r++)
+        for (int r = 0; r < CH; r++)
 #pragma unroll
             for (int l = 0; l < C::NLOAD; l++)
-                cur [r][l] = nxt [r][l];
+                raw [r][l] = pow2x_load<C::BPP3> (sp + (size_t) (r0 + r) * J.src_stride + l * C::LOADB);
+
+#pragma unroll
+      for (int rp = 0; rp < CH / 2; rp++)
+      {
+        uint32_t wa [C::PXL], wb [C::PXL];
+        pow2x_words (raw [2 * rp], wa);
+        pow2x_words (raw [2 * rp + 1], wb);
+
+        /* photographs with an alpha channel: when every pixel of this row pair is opaque on the whole wave the
+         * conversion is one fused look-up per channel */
+        bool opaque = false;
+        if (UK == WU_LIN_P || UK == WU_LIN_U)
+        {
+            uint32_t all = wa [0] & wb [0];
+#pragma unroll
+            for (int i = 1; i < C::PXL; i++)
+                all &= wa [i] & wb [i];
+            opaque = wide_batch_opaque (J, all);
+        }
+
+        auto taps = [&] (const auto &un)
+        {
+#pragma unroll
+            for (int o = 0; o < C::OPT; o++)
+            {
+                /* horizontal, per row: 2^H taps of two pixels each, then the halving shift */
+                uint32_t ha [4] = { 0, 0, 0, 0 }, hb [4] = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int t = 0; t < (1 << H); t++)
+                {
+                    uint32_t p [4], q [4];
+                    un (wa [o * C::R + 2 * t], p);
+                    un (wa [o * C::R + 2 * t + 1], q);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        ha [i] += (p [i] + q [i]) >> 1;
+                    un (wb [o * C::R + 2 * t], p);
+                    un (wb [o * C::R + 2 * t + 1], q);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        hb [i] += (p [i] + q [i]) >> 1;
+                }
+                /* vertical tap of the two rows' results */
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc [o][i] += ((ha [i] >> H) + (hb [i] >> H)) >> 1;
+            }
+        };
+        if (opaque)
+            taps (unpack_opaque);
+        else
+            taps (unpack);
+      }
     }
 }
 
@@ -334,22 +327,59 @@ __device__ __forceinline__ void pow2x_body (const JobDev &J)
         const LutLds lut (lut_lds);
         uint32_t acc [C::OPT][4];
 
-        pow2x_wide_acc<H, IN, IN == PX_W16> (J, sp, lut, acc);
-
-#pragma unroll
-        for (int o = 0; o < C::OPT; o++)
+        /* the conversions' flavour is fixed here, once per lane (smol_kernels.hip.h WideUnpack / WidePack) */
+        const int uk = wide_unpack_kind (J);
+        if (IN == PX_W16)
+            pow2x_wide_acc<H, IN, WU_P16> (J, sp, lut, acc);                 /* (pow2x_setup: premul16 without sRGB) */
+        else if (IN == PX_W24)
         {
-            uint32_t v [4];
+            if (uk == WU_LIN_O)
+                pow2x_wide_acc<H, IN, WU_LIN_O> (J, sp, lut, acc);
+            else
+                pow2x_wide_acc<H, IN, WU_ANY> (J, sp, lut, acc);
+        }
+        else
+        {
+            switch (uk)
+            {
+                case WU_P16L:  pow2x_wide_acc<H, IN, WU_P16L> (J, sp, lut, acc); break;
+                case WU_LIN_P: pow2x_wide_acc<H, IN, WU_LIN_P> (J, sp, lut, acc); break;
+                case WU_LIN_U: pow2x_wide_acc<H, IN, WU_LIN_U> (J, sp, lut, acc); break;
+                default:       pow2x_wide_acc<H, IN, WU_ANY> (J, sp, lut, acc); break;
+            }
+        }
+
+        auto store = [&] (const auto &pack)
+        {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                v [i] = acc [o][i] >> H;
-            store_px<true> (J, J.dst + (size_t) row * J.dst_stride, tc * C::OPT + o, v, lut);
+            for (int o = 0; o < C::OPT; o++)
+            {
+                uint32_t v [4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    v [i] = acc [o][i] >> H;
+                wide_store_word (J, drow, tc * C::OPT + o, pack (v));
+            }
+        };
+        if (IN == PX_W16)
+            store (WidePack<WP_P16> (J, lut));
+        else switch (wide_pack_kind (J))
+        {
+            case WP_P16L:  store (WidePack<WP_P16L> (J, lut)); break;
+            case WP_LIN_P: store (WidePack<WP_LIN_P> (J, lut)); break;
+            case WP_LIN_U: store (WidePack<WP_LIN_U> (J, lut)); break;
+            case WP_LIN_Q: store (WidePack<WP_LIN_Q> (J, lut)); break;
+            default:       store (WidePack<WP_ANY> (J, lut)); break;
         }
     }
 }
 
+/* 2:1 and 4:1 hold two 1024-thread workgroups per CU (8 waves per SIMD) only up to 64 vector registers: say so
+ * (the specialised 128bpp conversions would otherwise take 76 and halve the occupancy: C5mix 468 -> 500 us) */
+#define SMOL_POW2X_OCC(H) __attribute__ ((amdgpu_waves_per_eu ((H) <= 1 ? 8 : 4)))
+
 template <int H, int IN>
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (1024) SMOL_POW2X_OCC (H)
 k_pow2x_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.z);         /* uniform: scalar loads, once */
@@ -362,7 +392,7 @@ k_pow2x_batch (const JobDev *__restrict__ jobs)
  * each skipping through the arena, lose 8-10 % to their ramps and tails (profiles/r02u_pow2x_types.txt);
  * running them side by side on forked streams is slower still. */
 template <int H>
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (1024) SMOL_POW2X_OCC (H)
 k_pow2x_mixed_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.z);
@@ -377,7 +407,7 @@ k_pow2x_mixed_batch (const JobDev *__restrict__ jobs)
 }
 
 template <int H, int IN>
-__global__ void __launch_bounds__ (1024)
+__global__ void __launch_bounds__ (1024) SMOL_POW2X_OCC (H)
 k_pow2x_one (const JobDev J)
 {
     pow2x_body<H, IN> (J);

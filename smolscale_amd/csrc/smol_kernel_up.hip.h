@@ -463,8 +463,8 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
  * k_up, table-driven flavours: every other 128bpp-class magnification --      *
  * sRGB-linear (with_srgb = 1, gamma-correct scaling; 11-bit channels, W32 = false)  *
  * and premul16 + sRGB (19-bit channels, W32 = true) -- any pixel types, any   *
- * alignment. Pixels go through k_general's unpack_word<true> / store_px<true> *
- * (smolscale-generic.c:470-752, 912-1164); 4 waves per workgroup share one    *
+ * alignment. Pixels go through WideUnpack / WidePack (smol_kernels.hip.h),    *
+ * flavour chosen per batch (smolscale-generic.c:470-752, 912-1164); 4 waves per workgroup share one    *
  * LDS copy of the six tables, each wave works on its own tile.                *
  * ------------------------------------------------------------------------- */
 template <int I, int N, typename F>
@@ -498,6 +498,7 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
     const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;
     const uint32_t xl = x0 + lane * CPL;
     const LutLds lut (lut_lds);
+    const int uk = wide_unpack_kind (J), pk = wide_pack_kind (J);
 
     uint32_t tap_ofs [CPL], tap_f [CPL];
 #pragma unroll
@@ -547,20 +548,43 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                         w [u] = up_load_px<UP_IN_ANY> (J, srow0 + (size_t) srow * J.src_stride, x);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
+            /* conversion flavour chosen once per batch of four pixels per lane (WideUnpack: branch-free inside) */
+            auto conv = [&] (const auto &un)
             {
-                const uint32_t i = i0 + (uint32_t) u * 64u + lane;
-                uint32_t ch [4];
-                unpack_word<true> (J, w [u], ch, lut);
-                if (i < total)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
                 {
-                    if (W32)
-                        *reinterpret_cast<u32x4 *> (lds + (size_t) i * 16) = u32x4 { ch [0], ch [1], ch [2], ch [3] };
-                    else
-                        *reinterpret_cast<u32x2a8 *> (lds + (size_t) i * 8) = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
+                    const uint32_t i = i0 + (uint32_t) u * 64u + lane;
+                    uint32_t ch [4];
+                    un (w [u], ch);
+                    if (i < total)
+                    {
+                        if (W32)
+                            *reinterpret_cast<u32x4 *> (lds + (size_t) i * 16) = u32x4 { ch [0], ch [1], ch [2], ch [3] };
+                        else
+                            *reinterpret_cast<u32x2a8 *> (lds + (size_t) i * 8) = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
+                    }
                 }
+            };
+            if (W32 && uk == WU_P16L)
+                conv (WideUnpack<WU_P16L> (J, lut));
+            else if (!W32 && (uk == WU_LIN_P || uk == WU_LIN_U))
+            {
+                uint32_t all = 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    all &= (i0 + (uint32_t) u * 64u + lane < total) ? w [u] : 0xffffffffu;
+                if (wide_batch_opaque (J, all))
+                    conv (WideUnpack<WU_LIN_O> (J, lut));
+                else if (uk == WU_LIN_P)
+                    conv (WideUnpack<WU_LIN_P> (J, lut));
+                else
+                    conv (WideUnpack<WU_LIN_U> (J, lut));
             }
+            else if (!W32 && uk == WU_LIN_O)
+                conv (WideUnpack<WU_LIN_O> (J, lut));
+            else
+                conv (WideUnpack<WU_ANY> (J, lut));
         }
     }
     smol_wave_sync ();
@@ -616,28 +640,54 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
         while (r < nrows && (e & 0xffffu) == (uint32_t) s)
         {
             const uint32_t F = e >> 16, G = 256u - F;
-            uint32_t wv [CPL];
+            uint32_t wv [CPL], vv [CPL][4];
 #pragma unroll
             for (int c = 0; c < CPL; c++)
             {
-                uint32_t v [4];
                 if (W32)
                 {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        v [i] = (__umul24 (h [s][c][i % NCH], F) + __umul24 (h [s + 1][c][i % NCH], G)) >> 8;
+                        vv [c][i] = (__umul24 (h [s][c][i % NCH], F) + __umul24 (h [s + 1][c][i % NCH], G)) >> 8;
                 }
                 else
                 {
                     const uint32_t rg = up16_tap<false> (h [s][c][0], h [s + 1][c][0], F, G);
                     const uint32_t ba = up16_tap<false> (h [s][c][1], h [s + 1][c][1], F, G);
-                    v [0] = rg & 0xffffu; v [1] = rg >> 16; v [2] = ba & 0xffffu; v [3] = ba >> 16;
+                    vv [c][0] = rg & 0xffffu; vv [c][1] = rg >> 16; vv [c][2] = ba & 0xffffu; vv [c][3] = ba >> 16;
                 }
-                if (vec_ok)
-                    wv [c] = pack_px_word<true> (J, v, lut);
-                else if (xl + c < xn)
-                    store_px<true> (J, out_row, xl + c, v, lut);
             }
+            /* pack: flavour chosen once per output row and wave (WidePack: the row's 2-4 pixels per lane convert in one
+             * branch-free block); all-opaque rows skip the inverse-alpha look-up */
+            auto put = [&] (const auto &pack)
+            {
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                {
+                    wv [c] = pack (vv [c]);
+                    if (!vec_ok && xl + c < xn)
+                        wide_store_word (J, gptr (out_row), xl + c, wv [c]);
+                }
+            };
+            if (W32 && pk == WP_P16L)
+                put (WidePack<WP_P16L> (J, lut));
+            else if (!W32 && (pk == WP_LIN_P || pk == WP_LIN_U))
+            {
+                uint32_t all = 0xffu;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    all &= (xl + c < xn) ? vv [c][3] : 0xffu;
+                if (smol_wave_all_opaque (all & 0xffu))
+                    put (WidePack<WP_LIN_O> (J, lut));
+                else if (pk == WP_LIN_P)
+                    put (WidePack<WP_LIN_P> (J, lut));
+                else
+                    put (WidePack<WP_LIN_U> (J, lut));
+            }
+            else if (!W32 && pk == WP_LIN_Q)
+                put (WidePack<WP_LIN_Q> (J, lut));
+            else
+                put (WidePack<WP_ANY> (J, lut));
             if (vec_ok)
             {
                 /* the lane's adjacent pixels leave as ONE non-temporal store (16 or 8 bytes) */

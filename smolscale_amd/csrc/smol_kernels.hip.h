@@ -473,6 +473,221 @@ __device__ __forceinline__ void store_px (const JobDev &J, uint8_t *rowp, uint32
 }
 
 /* ------------------------------------------------------------------------- *
+ * 128bpp class: conversions with the flavour fixed at COMPILE time           *
+ *                                                                            *
+ * unpack_word<true> / pack_px_channels<true> above decide the flavour from   *
+ * the job's flags at every pixel: a dozen scalar branches per pixel, each    *
+ * ending the compiler's scheduling region, so that a lane converts its       *
+ * pixels one after the other with an LDS round trip (table look-up, wait,    *
+ * multiply, look-up, wait) between any two instructions -- 46 vector and 19  *
+ * scalar instructions per source pixel in the gamma-correct 4:1 case         *
+ * (profiles/r03g_sq_srgb.txt). The kernels that matter switch ONCE per lane  *
+ * (wide_unpack_kind / wide_pack_kind) into code specialised by these         *
+ * functors: no branches, the look-ups of all the pixels a lane holds in      *
+ * flight together. Same arithmetic, same tables (:470-752, :912-1164).       *
+ * ------------------------------------------------------------------------- */
+enum : int { WU_ANY = 0,       /* run-time flags (unpack_word<true>): compressed 128bpp, anything unusual        */
+             WU_P16,           /* premul16, no tables: c * a, A = (a << 8) | 0x80                    :616-625    */
+             WU_P16L,          /* premul16 + linear: from_srgb (c) * a                               :627-660    */
+             WU_LIN_P,         /* linear, premultiplied 32-bit input: unpremul8 -> from_srgb -> premul8l :481-535 */
+             WU_LIN_U,         /* linear, unassociated 32-bit input: from_srgb -> premul8l           :588-614    */
+             WU_LIN_O };       /* linear, every pixel opaque (24-bit input; or the caller saw alpha = 255 on the
+                                * whole wave): one fused look-up per channel                                     */
+enum : int { WP_ANY = 0, WP_P16, WP_P16L,
+             WP_LIN_P,         /* linear -> premultiplied 32-bit: unpremul8l -> to_srgb -> premul8   :1096-1109  */
+             WP_LIN_U,         /* linear -> unassociated 32-bit, or 24-bit through the `321' packer  :1122-1134, :1010-1023 */
+             WP_LIN_Q,         /* linear -> 24-bit through the `123' packer: to_srgb of the raw lane :922-935 (quirk24) */
+             WP_LIN_O };       /* WP_LIN_P / WP_LIN_U when the caller saw alpha = 255 on the whole wave: the inverse for 255 is
+                                * 1028 = 1024 + 4, (s * 1028) >> 10 = s + (s >> 8), premultiplying by 255 is the identity */
+
+__device__ __forceinline__ int wide_unpack_kind (const JobDev &J)
+{
+    if (J.p16)
+        return J.bpp_in == 4 ? (J.linear ? WU_P16L : WU_P16) : WU_ANY;
+    if (!J.linear)
+        return WU_ANY;
+    if (J.bpp_in == 3)
+        return WU_LIN_O;
+    return J.unassoc_in ? WU_LIN_U : WU_LIN_P;
+}
+
+__device__ __forceinline__ int wide_pack_kind (const JobDev &J)
+{
+    if (J.p16)
+        return J.bpp_out == 4 ? (J.linear ? WP_P16L : WP_P16) : WP_ANY;
+    if (!J.linear)
+        return WP_ANY;
+    if (J.bpp_out == 3)
+        return J.quirk24 ? WP_LIN_Q : WP_LIN_U;
+    return J.unassoc_out ? WP_LIN_U : WP_LIN_P;
+}
+
+template <int K>
+struct WideUnpack
+{
+    const JobDev &J;
+    const LutLds &lut;
+    uint32_t sr, sg, sb, sa;
+
+    __device__ __forceinline__ WideUnpack (const JobDev &job, const LutLds &l)
+        : J (job), lut (l), sr (8u * job.pos_in [0]), sg (8u * job.pos_in [1]), sb (8u * job.pos_in [2]),
+          sa (8u * (job.pos_in [3] & 3u)) {}
+
+    /* w: the pixel's bytes in memory order (24-bit pixels: the low three) */
+    __device__ __forceinline__ void operator() (uint32_t w, uint32_t (&c) [4]) const
+    {
+        if (K == WU_ANY)
+        {
+            unpack_word<true> (J, w, c, lut);
+            return;
+        }
+        const uint32_t r = (w >> sr) & 0xffu, g = (w >> sg) & 0xffu, b = (w >> sb) & 0xffu;
+        if (K == WU_LIN_O)
+        {
+            c [0] = lut.opaque_lin (r);
+            c [1] = lut.opaque_lin (g);
+            c [2] = lut.opaque_lin (b);
+            c [3] = 255u;
+            return;
+        }
+        const uint32_t a = (w >> sa) & 0xffu;
+        if (K == WU_P16)
+        {
+            c [0] = __umul24 (r, a);
+            c [1] = __umul24 (g, a);
+            c [2] = __umul24 (b, a);
+            c [3] = (a << 8) | 0x80u;
+        }
+        else if (K == WU_P16L)
+        {
+            c [0] = __umul24 (lut.from_srgb (r), a);
+            c [1] = __umul24 (lut.from_srgb (g), a);
+            c [2] = __umul24 (lut.from_srgb (b), a);
+            c [3] = (a << 8) | 0x80u;
+        }
+        else
+        {
+            /* premul8l (l, a) = ((l + 1) * (8a + 1) - 1) >> 11 = (l * (8a + 1) + 8a) >> 11, below 2^11 as it stands
+             * (l <= 2047: at most 2048 * 2041 - 1 before the shift) */
+            const uint32_t a8 = a << 3, a81 = a8 | 1u;
+            uint32_t u0 = r, u1 = g, u2 = b;
+            if (K == WU_LIN_P)
+            {
+                const uint32_t inv = lut.inv_p8 (a);
+                u0 = (inv_mul (r, inv) >> 13) & 0xffu;
+                u1 = (inv_mul (g, inv) >> 13) & 0xffu;
+                u2 = (inv_mul (b, inv) >> 13) & 0xffu;
+            }
+            c [0] = (__umul24 (lut.from_srgb (u0), a81) + a8) >> 11;
+            c [1] = (__umul24 (lut.from_srgb (u1), a81) + a8) >> 11;
+            c [2] = (__umul24 (lut.from_srgb (u2), a81) + a8) >> 11;
+            c [3] = a;
+        }
+    }
+};
+
+/* "every one of these pixel words is opaque, on every active lane": lets a lane take WU_LIN_O for a whole batch
+ * of 32-bit pixels (photographs with an alpha channel). AND of the words, one ballot. */
+__device__ __forceinline__ bool wide_batch_opaque (const JobDev &J, uint32_t and_of_words)
+{
+    return smol_wave_all_opaque ((and_of_words >> (8u * (J.pos_in [3] & 3u))) & 0xffu);
+}
+
+template <int K>
+struct WidePack
+{
+    const JobDev &J;
+    const LutLds &lut;
+    uint32_t dr, dg, db, da;
+
+    __device__ __forceinline__ WidePack (const JobDev &job, const LutLds &l)
+        : J (job), lut (l), dr (8u * job.pos_out [0]), dg (8u * job.pos_out [1]), db (8u * job.pos_out [2]),
+          da (8u * (job.pos_out [3] & 3u)) {}
+
+    /* internal channels -> the destination pixel's bytes in memory order (bpp_out == 3: the low three bytes) */
+    __device__ __forceinline__ uint32_t operator() (const uint32_t (&v) [4]) const
+    {
+        if (K == WP_ANY)
+        {
+            uint32_t a, c [3];
+            pack_px_channels<true> (J, v, lut, c, a);
+            const uint32_t w = (c [0] << dr) | (c [1] << dg) | (c [2] << db);
+            return J.bpp_out == 4 ? w | (a << da) : w;
+        }
+        uint32_t c0, c1, c2, a;
+        if (K == WP_P16 || K == WP_P16L)
+        {
+            a = (v [3] >> 8) & 0xffu;
+            if (K == WP_P16)
+            {
+                const uint32_t inv = lut.inv_p16 (a);
+                c0 = (inv_mul (v [0], inv) >> 16) & 0xffu;
+                c1 = (inv_mul (v [1], inv) >> 16) & 0xffu;
+                c2 = (inv_mul (v [2], inv) >> 16) & 0xffu;
+            }
+            else
+            {
+                const uint32_t inv = lut.inv_p16l (a);
+                c0 = lut.to_srgb ((inv_mul (v [0], inv) >> 19) & 0x7ffu);
+                c1 = lut.to_srgb ((inv_mul (v [1], inv) >> 19) & 0x7ffu);
+                c2 = lut.to_srgb ((inv_mul (v [2], inv) >> 19) & 0x7ffu);
+            }
+            return (c0 << dr) | (c1 << dg) | (c2 << db) | (a << da);
+        }
+        a = v [3] & 0xffu;
+        if (K == WP_LIN_O)
+        {
+            c0 = lut.to_srgb ((v [0] + (v [0] >> 8)) & 0x7ffu);
+            c1 = lut.to_srgb ((v [1] + (v [1] >> 8)) & 0x7ffu);
+            c2 = lut.to_srgb ((v [2] + (v [2] >> 8)) & 0x7ffu);
+            const uint32_t w = (c0 << dr) | (c1 << dg) | (c2 << db);
+            return J.bpp_out == 4 ? w | (0xffu << da) : w;
+        }
+        if (K == WP_LIN_Q)
+        {
+            c0 = lut.to_srgb (v [0] & 0x7ffu);
+            c1 = lut.to_srgb (v [1] & 0x7ffu);
+            c2 = lut.to_srgb (v [2] & 0x7ffu);
+            return (c0 << dr) | (c1 << dg) | (c2 << db);
+        }
+        const uint32_t inv = lut.inv_p8l (a);
+        c0 = lut.to_srgb ((inv_mul (v [0], inv) >> 10) & 0x7ffu);
+        c1 = lut.to_srgb ((inv_mul (v [1], inv) >> 10) & 0x7ffu);
+        c2 = lut.to_srgb ((inv_mul (v [2], inv) >> 10) & 0x7ffu);
+        if (K == WP_LIN_P)
+        {
+            /* premul8 (s, a) = ((s + 1) * (a + 1) - 1) >> 8 = (s * (a + 1) + a) >> 8, at most 65535 before the shift */
+            const uint32_t a1 = a + 1u;
+            c0 = (__umul24 (c0, a1) + a) >> 8;
+            c1 = (__umul24 (c1, a1) + a) >> 8;
+            c2 = (__umul24 (c2, a1) + a) >> 8;
+        }
+        const uint32_t w = (c0 << dr) | (c1 << dg) | (c2 << db);
+        return J.bpp_out == 4 ? w | (a << da) : w;
+    }
+};
+
+/* the destination word of WidePack at pixel x of the row at rowp */
+__device__ __forceinline__ void wide_store_word (const JobDev &J, gbyte *rowp, uint32_t x, uint32_t w)
+{
+    if (J.bpp_out == 4)
+    {
+        gbyte *p = rowp + (size_t) x * 4;
+        if (J.out_dword_ok)
+            *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (p) = w;
+        else
+        {
+            p [0] = (uint8_t) w; p [1] = (uint8_t) (w >> 8); p [2] = (uint8_t) (w >> 16); p [3] = (uint8_t) (w >> 24);
+        }
+    }
+    else
+    {
+        gbyte *p = rowp + (size_t) x * 3;
+        p [0] = (uint8_t) w; p [1] = (uint8_t) (w >> 8); p [2] = (uint8_t) (w >> 16);
+    }
+}
+
+/* ------------------------------------------------------------------------- *
  * Closed-form sample positions (host twins: smol_plan.c)                    *
  * ------------------------------------------------------------------------- */
 __device__ __forceinline__ void bilin_tap (uint64_t pos, uint32_t dim_in, uint32_t &ofs, uint32_t &F)
