@@ -376,7 +376,11 @@ __device__ __forceinline__ void pow2x_body (const JobDev &J)
 
 /* 2:1 and 4:1 hold two 1024-thread workgroups per CU (8 waves per SIMD) only up to 64 vector registers: say so
  * (the specialised 128bpp conversions would otherwise take 76 and halve the occupancy: C5mix 468 -> 500 us) */
+#ifdef SMOL_KERNEL_EMU
+#define SMOL_POW2X_OCC(H)
+#else
 #define SMOL_POW2X_OCC(H) __attribute__ ((amdgpu_waves_per_eu ((H) <= 1 ? 8 : 4)))
+#endif
 
 template <int H, int IN>
 __global__ void __launch_bounds__ (1024) SMOL_POW2X_OCC (H)
