@@ -640,15 +640,20 @@ down_setup (JobDev &d)
     uint32_t mode;
     if (d.p16 && !d.linear && aligned32)
         mode = 0;
-    else if (d.p16 && d.linear)
-        mode = 2;
+    else if (d.p16)
+        mode = 2;                               /* 16- to 19-bit channels (premul16 + sRGB; premul16 on unaligned rows) */
     else
-        mode = 1;
+        mode = 1;                               /* channels of at most 11 bits: packed taps */
     if (mode && tune_env ("SMOL_NO_DOWN_GEN"))
         return false;
 
-    /* one sample per column and a wide enough image: 4 columns per lane (mode 0 only) */
-    const uint32_t cpl = (mode == 0 && d.halv_h == 0 && d.w_out >= 256 && !tune_env ("SMOL_DOWN_CPL1")) ? 4 : 1;
+    /* one sample per column and a wide enough image: 4 columns per lane (premul16 fast path). The 11-bit table-driven
+     * flavour has the same variant compiled in (SMOL_DOWNG_CPL4 in tuning builds) but keeps one column: with four its
+     * two row buffers take 8 KiB per wave, 4 waves per SIMD instead of 8 stay resident and the gamma-correct ratio-1.5
+     * row goes 97 -> 116 us (profiles/r03h_downg_cpl4_ab.txt) -- the kernel lives on covering its table look-ups'
+     * latency with other waves */
+    const uint32_t cpl = (d.halv_h == 0 && d.w_out >= 256 && !tune_env ("SMOL_DOWN_CPL1")
+                          && (mode == 0 || (mode == 1 && tune_env ("SMOL_DOWNG_CPL4")))) ? 4 : 1;
 
     /* source pixels a tile can reach, rounded up to whole 4-pixel chunks */
     uint64_t span = ((((uint64_t) (64u * cpl) << d.halv_h) * d.step_x) >> 32) + 3;

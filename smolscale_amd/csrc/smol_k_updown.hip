@@ -40,6 +40,11 @@ template <int MODE>
 void
 launch_downg_m (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
+    if (MODE == smolhip::DOWN_GEN16 && rep.tile_cpl == 4)
+    {
+        launch_downg_k<MODE == smolhip::DOWN_GEN16 ? 3 : 0, MODE> (jobs_dev, rep, grid, lds, s);
+        return;
+    }
     switch (rep.halv_h)
     {
         case 0:  launch_downg_k<0, MODE> (jobs_dev, rep, grid, lds, s); break;

@@ -46,7 +46,7 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
     constexpr uint32_t TW = TILE_COLS * CPL;            /* output columns per tile */
     constexpr uint32_t PXB = (MODE == DOWN_GEN32) ? 16u : 8u;      /* LDS bytes per staged pixel */
     constexpr bool GEN = (MODE != DOWN_P16);
-    static_assert (!GEN || CPL == 1, "the table-driven flavours take one column per lane");
+    static_assert (!GEN || CPL == 1 || (MODE == DOWN_GEN16 && HX == 0), "table-driven flavours: one column per lane, or four without horizontal halvings (11-bit channels)");
 
     const uint32_t tiles_x = (J.w_out + TW - 1) / TW;
     const uint32_t tx = tile % tiles_x;
@@ -85,6 +85,12 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
 #pragma unroll
         for (uint32_t s = 0; s < NSX; s++)
             tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * PXB;          /* byte offset in the LDS row     */
+    Lerp11W tap_w [CPL][NSX];                                       /* DOWN_GEN16: 11-bit channels, packed taps (lerp11_pk) */
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+            tap_w [c][s] = lerp11_weights (tap_f [c][s]);
     if (MODE == DOWN_P16)
     {
 #pragma unroll
@@ -133,10 +139,10 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
     /* DOWN_P16 moves 4-pixel chunks (16-byte loads, cheap conversion); the table-driven
      * flavours spread single pixels over all 64 lanes, because their conversion is the
      * expensive part and a short span would otherwise keep most lanes idle */
-    constexpr int NRAW = GEN ? (2 << HX) + 1 : DOWN_NL;          /* a 64-column tile spans < 64 * 2^(HX+1) + 3 pixels */
+    constexpr int NRAW = GEN ? (2 << HX) * CPL + 1 : DOWN_NL;    /* a tile of 64 * CPL columns spans < 64 * CPL * 2^(HX+1) + 3 pixels */
     const uint32_t npx = sx1 - sx0 + 1;                             /* pixels per staged row */
     u32x4 raw [GEN ? 1 : DOWN_NL];
-    uint32_t rawpx [GEN ? (2 << HX) + 1 : 1];
+    uint32_t rawpx [GEN ? (2 << HX) * CPL + 1 : 1];
 
     auto load_row = [&] ()
     {
@@ -329,11 +335,17 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
                     hs [3] = s ? hs [3] + d3 : d3;
                     continue;
                 }
-                const uint32_t F = tap_f [c][s], G = 256u - F;
-                hs [0] += (__umul24 (pq.x & 0xffffu, F) + __umul24 (pq.z & 0xffffu, G)) >> 8;
-                hs [1] += (__umul24 (pq.x >> 16, F) + __umul24 (pq.z >> 16, G)) >> 8;
-                hs [2] += (__umul24 (pq.y & 0xffffu, F) + __umul24 (pq.w & 0xffffu, G)) >> 8;
-                hs [3] += (__umul24 (pq.y >> 16, F) + __umul24 (pq.w >> 16, G)) >> 8;
+                /* DOWN_GEN16: both channel pairs stay packed; the sums of 2^HX taps stay below 2^13 per lane */
+                const uint32_t t01 = lerp11_pk (pq.x, pq.z, tap_w [c][s]);
+                const uint32_t t23 = lerp11_pk (pq.y, pq.w, tap_w [c][s]);
+                hs [0] = s ? hs [0] + t01 : t01;
+                hs [2] = s ? hs [2] + t23 : t23;
+            }
+            if (MODE == DOWN_GEN16)
+            {
+                h0 [c] = (hs [0] >> HX) & (0xffffu >> HX) * 0x00010001u;
+                h1 [c] = (hs [2] >> HX) & (0xffffu >> HX) * 0x00010001u;
+                continue;
             }
             h0 [c] = (hs [0] >> HX) | ((hs [1] >> HX) << 16);
             h1 [c] = (hs [2] >> HX) | ((hs [3] >> HX) << 16);
@@ -367,10 +379,11 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
                 }
                 else
                 {
-                    t0 = (__umul24 (hp0 [c] & 0xffffu, Fy) + __umul24 (h0 [c] & 0xffffu, G)) >> 8;
-                    t1 = (__umul24 (hp0 [c] >> 16, Fy) + __umul24 (h0 [c] >> 16, G)) >> 8;
-                    t2 = (__umul24 (hp1 [c] & 0xffffu, Fy) + __umul24 (h1 [c] & 0xffffu, G)) >> 8;
-                    t3 = (__umul24 (hp1 [c] >> 16, Fy) + __umul24 (h1 [c] >> 16, G)) >> 8;
+                    /* DOWN_GEN16: packed pairs in acc [c][0] (R, G) and acc [c][2] (B, A) */
+                    const Lerp11W wy = lerp11_weights (Fy);
+                    t0 = lerp11_pk (hp0 [c], h0 [c], wy);
+                    t2 = lerp11_pk (hp1 [c], h1 [c], wy);
+                    t1 = t3 = 0;
                 }
                 acc [c][0] = s_y ? acc [c][0] + t0 : t0;
                 acc [c][1] = s_y ? acc [c][1] + t1 : t1;
@@ -381,19 +394,39 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
             ks++;
             if (s_y == nsy && GEN)
             {
-                uint32_t v [4];
+                uint32_t v [CPL][4], all_a = 255u;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    v [i] = acc [0][i] >> hv;
-                const bool live = xl < xn;
+                for (int c = 0; c < CPL; c++)
+                {
+                    if (MODE == DOWN_GEN16)
+                    {
+                        v [c][0] = (acc [c][0] & 0xffffu) >> hv; v [c][1] = acc [c][0] >> (16u + hv);
+                        v [c][2] = (acc [c][2] & 0xffffu) >> hv; v [c][3] = acc [c][2] >> (16u + hv);
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            v [c][i] = acc [c][i] >> hv;
+                    }
+                    all_a &= (xl + c < xn) ? v [c][3] & 0xffu : 255u;
+                }
+                const bool vec = (CPL == 4) && interior;
                 auto put = [&] (const auto &pack)
                 {
-                    const uint32_t w = pack (v);
-                    if (live)
-                        wide_store_word (J, out_row, xl, w);
+                    uint32_t w [CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; c++)
+                    {
+                        w [c] = pack (v [c]);
+                        if (!vec && xl + c < xn)
+                            wide_store_word (J, out_row, xl + c, w [c]);
+                    }
+                    if (vec)
+                        store_nt128 (out_row + (size_t) xl * 4, u32x4 { w [0], w [1 % CPL], w [2 % CPL], w [3 % CPL] });
                 };
                 /* once per output row and wave; all-opaque rows skip the inverse-alpha look-up and multiplies */
-                if ((pk == WP_LIN_P || pk == WP_LIN_U) && smol_wave_all_opaque (live ? v [3] & 0xffu : 255u))
+                if ((pk == WP_LIN_P || pk == WP_LIN_U) && smol_wave_all_opaque (all_a))
                     put (WidePack<WP_LIN_O> (J, lut));
                 else if (pk == WP_LIN_P)
                     put (WidePack<WP_LIN_P> (J, lut));
@@ -472,20 +505,20 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
 
 /* table-driven flavours: 4 waves per workgroup share one LDS copy of the tables, each
  * wave works on its own tile in its own LDS region */
-template <int HX, int MODE>
+template <int HX, int CPL, int MODE>
 __device__ __forceinline__ void down_gen_entry (const JobDev &J, uint8_t *lds)
 {
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
-    down_body<HX, 1, MODE> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    down_body<HX, CPL, MODE> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     const uint32_t wave = threadIdx.x >> 6;
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     const uint32_t pitch = (J.span_px * (MODE == DOWN_GEN32 ? 16u : 8u) + 15u) & ~15u;
-    down_body<HX, 1, MODE> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * 2u * pitch, lds,
-                            threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    down_body<HX, CPL, MODE> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * 2u * pitch, lds,
+                              threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
 }
 
@@ -496,11 +529,16 @@ __global__ void k_down_one (const JobDev J)
     if (J.down_mode == DOWN_GEN16 || J.down_mode == DOWN_GEN32)
     {
         const bool w32 = J.down_mode == DOWN_GEN32;
+        if (J.tile_cpl == 4)
+        {
+            down_gen_entry<0, 4, DOWN_GEN16> (J, smol_dyn_lds);
+            return;
+        }
         switch (J.halv_h)
         {
-            case 0: if (w32) down_gen_entry<0, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<0, DOWN_GEN16> (J, smol_dyn_lds); break;
-            case 1: if (w32) down_gen_entry<1, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<1, DOWN_GEN16> (J, smol_dyn_lds); break;
-            default: if (w32) down_gen_entry<2, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<2, DOWN_GEN16> (J, smol_dyn_lds); break;
+            case 0: if (w32) down_gen_entry<0, 1, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<0, 1, DOWN_GEN16> (J, smol_dyn_lds); break;
+            case 1: if (w32) down_gen_entry<1, 1, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<1, 1, DOWN_GEN16> (J, smol_dyn_lds); break;
+            default: if (w32) down_gen_entry<2, 1, DOWN_GEN32> (J, smol_dyn_lds); else down_gen_entry<2, 1, DOWN_GEN16> (J, smol_dyn_lds); break;
         }
         return;
     }
@@ -517,6 +555,8 @@ __global__ void k_down_one (const JobDev J)
     }
 }
 #else
+/* (amdgpu_waves_per_eu 6 or 8 on these kernels: premul16 ratio 1.5 57 -> 85 / 147 us -- spills --, the table-driven
+ * flavours within 3 % either way: profiles/r03i_down_occ_ab.txt) */
 /* HC: horizontal halvings 0-2 with one column per lane, or 3 = no halvings, 4 columns per lane */
 template <int HC>
 __global__ void __launch_bounds__ (64)
@@ -533,19 +573,20 @@ k_down_one (const JobDev J)
     down_body<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, DOWN_P16> (J, smol_dyn_lds, nullptr, threadIdx.x, blockIdx.x);
 }
 
-template <int HX, int MODE>
+/* HC: horizontal halvings 0-2 with one column per lane, or 3 = no halvings, 4 columns per lane (DOWN_GEN16 only) */
+template <int HC, int MODE>
 __global__ void __launch_bounds__ (256)
 k_downg_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    down_gen_entry<HX, MODE> (J, smol_dyn_lds);
+    down_gen_entry<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, MODE> (J, smol_dyn_lds);
 }
 
-template <int HX, int MODE>
+template <int HC, int MODE>
 __global__ void __launch_bounds__ (256)
 k_downg_one (const JobDev J)
 {
-    down_gen_entry<HX, MODE> (J, smol_dyn_lds);
+    down_gen_entry<HC == 3 ? 0 : HC, HC == 3 ? 4 : 1, MODE> (J, smol_dyn_lds);
 }
 #endif
 

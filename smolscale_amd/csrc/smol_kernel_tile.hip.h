@@ -62,6 +62,35 @@ typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 __device__ __forceinline__ u16x2 as_u16x2 (uint32_t v) { return __builtin_bit_cast (u16x2, v); }
 __device__ __forceinline__ uint32_t as_u32 (u16x2 v) { return __builtin_bit_cast (uint32_t, v); }
 
+/* One bilinear tap for the sRGB-linear class -- 11-bit values, two per register -- in packed 16-bit arithmetic:
+ *      q + (((p - q) * F) >> 8)                                        (smolscale-generic.c:1317, :1704)
+ * needs 20 bits for the product, but with F = 16 * Fh + Fl and d = p - q
+ *      floor (d * F / 256) = floor ((d * Fh + floor (d * Fl / 16)) / 16)
+ * every intermediate fits a signed 16-bit lane: |d * Fl| <= 2047 * 15, |d * Fh + ...| <= 2047 * 15 + 1920 for
+ * F <= 255 and exactly 16 * d for F = 256. Six packed instructions for two channels, no unpacking of the halves
+ * (the 32-bit form: eleven). Exhaustively checked on the host over every (d, F): tests/test_emu_kernels.py. */
+typedef short i16x2 __attribute__ ((ext_vector_type (2)));
+__device__ __forceinline__ i16x2 as_i16x2 (uint32_t v) { return __builtin_bit_cast (i16x2, v); }
+__device__ __forceinline__ uint32_t as_u32 (i16x2 v) { return __builtin_bit_cast (uint32_t, v); }
+
+struct Lerp11W { uint32_t fh2, fl2; };          /* (F >> 4, F & 15), each in both halves */
+
+__device__ __forceinline__ Lerp11W lerp11_weights (uint32_t F)
+{
+    Lerp11W w;
+    w.fh2 = (F >> 4) * 0x00010001u;
+    w.fl2 = (F & 15u) * 0x00010001u;
+    return w;
+}
+
+__device__ __forceinline__ uint32_t lerp11_pk (uint32_t p, uint32_t q, const Lerp11W &w)
+{
+    const i16x2 d = as_i16x2 (p) - as_i16x2 (q);
+    const i16x2 y = (d * as_i16x2 (w.fl2)) >> 4;
+    const i16x2 x = (d * as_i16x2 (w.fh2) + y) >> 4;
+    return as_u32 (as_i16x2 (q) + x);
+}
+
 /* (p*F + q*(256-F)) >> 8 per 16-bit lane. For 8-bit p, q and F in 0..256 the sum
  * is at most 255*256 < 2^16, so 16-bit lane arithmetic is exact and the result
  * needs no mask. */

@@ -508,6 +508,10 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
         bilin_tap (J.frac0_x + (uint64_t) xc * J.step_x, J.w_in, tap_ofs [c], tap_f [c]);
     }
     const uint32_t sx0 = smol_readlane (tap_ofs [0], 0);
+    Lerp11W tap_w [CPL];                                /* W32 = false: 11-bit channels, packed taps (lerp11_pk) */
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        tap_w [c] = lerp11_weights (tap_f [c]);
 
     uint32_t my_oy, my_f;
     {
@@ -618,8 +622,8 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                 else
                 {
                     const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (lds + (size_t) k * 8);
-                    h [s][c][0] = up16_tap<false> (pq.x, pq.z, F, G);
-                    h [s][c][1] = up16_tap<false> (pq.y, pq.w, F, G);
+                    h [s][c][0] = lerp11_pk (pq.x, pq.z, tap_w [c]);
+                    h [s][c][1] = lerp11_pk (pq.y, pq.w, tap_w [c]);
                 }
             }
         }
@@ -640,6 +644,7 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
         while (r < nrows && (e & 0xffffu) == (uint32_t) s)
         {
             const uint32_t F = e >> 16, G = 256u - F;
+            const Lerp11W wy = lerp11_weights (F);
             uint32_t wv [CPL], vv [CPL][4];
 #pragma unroll
             for (int c = 0; c < CPL; c++)
@@ -652,8 +657,8 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                 }
                 else
                 {
-                    const uint32_t rg = up16_tap<false> (h [s][c][0], h [s + 1][c][0], F, G);
-                    const uint32_t ba = up16_tap<false> (h [s][c][1], h [s + 1][c][1], F, G);
+                    const uint32_t rg = lerp11_pk (h [s][c][0], h [s + 1][c][0], wy);
+                    const uint32_t ba = lerp11_pk (h [s][c][1], h [s + 1][c][1], wy);
                     vv [c][0] = rg & 0xffffu; vv [c][1] = rg >> 16; vv [c][2] = ba & 0xffffu; vv [c][3] = ba >> 16;
                 }
             }
@@ -766,8 +771,13 @@ k_up_batch (const JobDev *__restrict__ jobs)
         up_body<INK, OUT == OUT_W16 ? OUT_P4 : OUT> (J, smol_dyn_lds);
 }
 
+/* registers against resident waves (profiles/r03i_upg_occ_ab.txt): the 19-bit flavour (99 registers as compiled) gains
+ * 12 % when held to 6 waves per SIMD (premul16 + gamma-correct x4: 100 -> 88 us); the 11-bit flavour, four columns per
+ * lane and 127 registers, loses when squeezed (5 waves 112 -> 116 us, 6 waves 167: spills) */
+#define SMOL_UPG_OCC(W32) __attribute__ ((amdgpu_waves_per_eu ((W32) ? 6 : 4)))
+
 template <bool W32>
-__global__ void __launch_bounds__ (256)
+__global__ void __launch_bounds__ (256) SMOL_UPG_OCC (W32)
 k_upg_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
@@ -775,7 +785,7 @@ k_upg_batch (const JobDev *__restrict__ jobs)
 }
 
 template <bool W32>
-__global__ void __launch_bounds__ (256)
+__global__ void __launch_bounds__ (256) SMOL_UPG_OCC (W32)
 k_upg_one (const JobDev J)
 {
     upg_entry<W32> (J, smol_dyn_lds);

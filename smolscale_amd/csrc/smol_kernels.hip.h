@@ -593,16 +593,37 @@ __device__ __forceinline__ bool wide_batch_opaque (const JobDev &J, uint32_t and
     return smol_wave_all_opaque ((and_of_words >> (8u * (J.pos_in [3] & 3u))) & 0xffu);
 }
 
+/* v_perm selector with byte `pos' of the result taken from source byte `code' (0-3: S1, 4-7: S0; 0x0c elsewhere = 0) */
+__device__ __forceinline__ uint32_t wide_sel (uint32_t sel, uint32_t pos, uint32_t code)
+{
+    return (sel & ~(0xffu << (8u * pos))) | (code << (8u * pos));
+}
+
 template <int K>
 struct WidePack
 {
     const JobDev &J;
     const LutLds &lut;
     uint32_t dr, dg, db, da;
+    /* the destination word is assembled by two v_perm + one OR from the registers the last arithmetic step left its
+     * byte in (byte B of each): perm (c0, c1, sel01) | perm (c2, alpha, sel2a) -- no shifts by 8, 16, 24, no masks */
+    uint32_t sel01, sel2a;
+    static constexpr uint32_t B = (K == WP_LIN_P) ? 1u : (K == WP_P16) ? 2u : 0u;
 
     __device__ __forceinline__ WidePack (const JobDev &job, const LutLds &l)
         : J (job), lut (l), dr (8u * job.pos_out [0]), dg (8u * job.pos_out [1]), db (8u * job.pos_out [2]),
-          da (8u * (job.pos_out [3] & 3u)) {}
+          da (8u * (job.pos_out [3] & 3u))
+    {
+        sel01 = wide_sel (wide_sel (0x0c0c0c0cu, job.pos_out [0], 4u + B), job.pos_out [1], B);
+        sel2a = wide_sel (0x0c0c0c0cu, job.pos_out [2], 4u + B);
+        if (job.bpp_out == 4)
+            sel2a = wide_sel (sel2a, job.pos_out [3] & 3u, 0u);
+    }
+
+    __device__ __forceinline__ uint32_t assemble (uint32_t c0, uint32_t c1, uint32_t c2, uint32_t a) const
+    {
+        return __builtin_amdgcn_perm (c0, c1, sel01) | __builtin_amdgcn_perm (c2, a, sel2a);
+    }
 
     /* internal channels -> the destination pixel's bytes in memory order (bpp_out == 3: the low three bytes) */
     __device__ __forceinline__ uint32_t operator() (const uint32_t (&v) [4]) const
@@ -614,56 +635,40 @@ struct WidePack
             const uint32_t w = (c [0] << dr) | (c [1] << dg) | (c [2] << db);
             return J.bpp_out == 4 ? w | (a << da) : w;
         }
-        uint32_t c0, c1, c2, a;
         if (K == WP_P16 || K == WP_P16L)
         {
-            a = (v [3] >> 8) & 0xffu;
+            const uint32_t a = (v [3] >> 8) & 0xffu;
             if (K == WP_P16)
             {
+                /* (s * inv) >> 16 & 0xff: byte 2 of the product */
                 const uint32_t inv = lut.inv_p16 (a);
-                c0 = (inv_mul (v [0], inv) >> 16) & 0xffu;
-                c1 = (inv_mul (v [1], inv) >> 16) & 0xffu;
-                c2 = (inv_mul (v [2], inv) >> 16) & 0xffu;
+                return assemble (inv_mul (v [0], inv), inv_mul (v [1], inv), inv_mul (v [2], inv), a);
             }
-            else
-            {
-                const uint32_t inv = lut.inv_p16l (a);
-                c0 = lut.to_srgb ((inv_mul (v [0], inv) >> 19) & 0x7ffu);
-                c1 = lut.to_srgb ((inv_mul (v [1], inv) >> 19) & 0x7ffu);
-                c2 = lut.to_srgb ((inv_mul (v [2], inv) >> 19) & 0x7ffu);
-            }
-            return (c0 << dr) | (c1 << dg) | (c2 << db) | (a << da);
+            const uint32_t inv = lut.inv_p16l (a);
+            return assemble (lut.to_srgb ((inv_mul (v [0], inv) >> 19) & 0x7ffu),
+                             lut.to_srgb ((inv_mul (v [1], inv) >> 19) & 0x7ffu),
+                             lut.to_srgb ((inv_mul (v [2], inv) >> 19) & 0x7ffu), a);
         }
-        a = v [3] & 0xffu;
         if (K == WP_LIN_O)
-        {
-            c0 = lut.to_srgb ((v [0] + (v [0] >> 8)) & 0x7ffu);
-            c1 = lut.to_srgb ((v [1] + (v [1] >> 8)) & 0x7ffu);
-            c2 = lut.to_srgb ((v [2] + (v [2] >> 8)) & 0x7ffu);
-            const uint32_t w = (c0 << dr) | (c1 << dg) | (c2 << db);
-            return J.bpp_out == 4 ? w | (0xffu << da) : w;
-        }
+            return assemble (lut.to_srgb ((v [0] + (v [0] >> 8)) & 0x7ffu), lut.to_srgb ((v [1] + (v [1] >> 8)) & 0x7ffu),
+                             lut.to_srgb ((v [2] + (v [2] >> 8)) & 0x7ffu), 0xffu);
+        const uint32_t a = v [3] & 0xffu;
         if (K == WP_LIN_Q)
-        {
-            c0 = lut.to_srgb (v [0] & 0x7ffu);
-            c1 = lut.to_srgb (v [1] & 0x7ffu);
-            c2 = lut.to_srgb (v [2] & 0x7ffu);
-            return (c0 << dr) | (c1 << dg) | (c2 << db);
-        }
+            return assemble (lut.to_srgb (v [0] & 0x7ffu), lut.to_srgb (v [1] & 0x7ffu), lut.to_srgb (v [2] & 0x7ffu), a);
         const uint32_t inv = lut.inv_p8l (a);
-        c0 = lut.to_srgb ((inv_mul (v [0], inv) >> 10) & 0x7ffu);
-        c1 = lut.to_srgb ((inv_mul (v [1], inv) >> 10) & 0x7ffu);
-        c2 = lut.to_srgb ((inv_mul (v [2], inv) >> 10) & 0x7ffu);
+        uint32_t c0 = lut.to_srgb ((inv_mul (v [0], inv) >> 10) & 0x7ffu);
+        uint32_t c1 = lut.to_srgb ((inv_mul (v [1], inv) >> 10) & 0x7ffu);
+        uint32_t c2 = lut.to_srgb ((inv_mul (v [2], inv) >> 10) & 0x7ffu);
         if (K == WP_LIN_P)
         {
-            /* premul8 (s, a) = ((s + 1) * (a + 1) - 1) >> 8 = (s * (a + 1) + a) >> 8, at most 65535 before the shift */
+            /* premul8 (s, a) = ((s + 1) * (a + 1) - 1) >> 8 = (s * (a + 1) + a) >> 8, at most 65535 before the shift:
+             * byte 1 of the sum */
             const uint32_t a1 = a + 1u;
-            c0 = (__umul24 (c0, a1) + a) >> 8;
-            c1 = (__umul24 (c1, a1) + a) >> 8;
-            c2 = (__umul24 (c2, a1) + a) >> 8;
+            c0 = __umul24 (c0, a1) + a;
+            c1 = __umul24 (c1, a1) + a;
+            c2 = __umul24 (c2, a1) + a;
         }
-        const uint32_t w = (c0 << dr) | (c1 << dg) | (c2 << db);
-        return J.bpp_out == 4 ? w | (a << da) : w;
+        return assemble (c0, c1, c2, a);
     }
 };
 

@@ -206,3 +206,31 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
         run_grid (gx, 1, GENERAL_BLOCK, [&] { k_general_one<false> (J); });
     return 0;
 }
+
+/* lerp11_pk (smol_kernel_tile.hip.h) against the reference's tap formula over EVERY (p, q, F) of the sRGB-linear
+ * class: 11-bit p and q in the low lane (the high lane runs a permuted pair), F in 0..256. Returns the number of
+ * mismatches. */
+extern "C" long
+emu_lerp11_exhaustive (void)
+{
+    using namespace smolhip;
+    long bad = 0;
+
+    for (uint32_t F = 0; F <= 256; F++)
+    {
+        const Lerp11W w = lerp11_weights (F);
+
+        for (uint32_t p = 0; p < 2048; p++)
+            for (uint32_t q = 0; q < 2048; q++)
+            {
+                const uint32_t p2 = 2047u - p, q2 = (q * 7u + 3u) & 2047u;
+                const uint32_t r = lerp11_pk (p | (p2 << 16), q | (q2 << 16), w);
+                const int64_t e0 = ((((int64_t) p - (int64_t) q) * (int64_t) F) >> 8) + (int64_t) q;
+                const int64_t e1 = ((((int64_t) p2 - (int64_t) q2) * (int64_t) F) >> 8) + (int64_t) q2;
+
+                if ((r & 0xffffu) != (uint32_t) e0 || (r >> 16) != (uint32_t) e1)
+                    bad++;
+            }
+    }
+    return bad;
+}

@@ -113,6 +113,15 @@ def test_emulated_up_kernel_magnification():
     assert hits >= 130
 
 
+def test_packed_11_bit_tap_equals_the_reference_formula_for_every_input():
+    """lerp11_pk (smol_kernel_tile.hip.h: the sRGB-linear class's bilinear tap in packed 16-bit lanes, split weights)
+    against q + (((p - q) * F) >> 8) (smolscale-generic.c:1317, :1704) for every 11-bit p, q and every F in 0..256."""
+    import ctypes
+    lib = H.emu()
+    lib.emu_lerp11_exhaustive.restype = ctypes.c_long
+    assert lib.emu_lerp11_exhaustive() == 0
+
+
 def test_emulated_up_kernel_table_driven_flavours():
     """k_up flavours 2 and 3: magnification with with_srgb = 1 (sRGB-linear; premul16 + sRGB),
     every type pair incl. 24-bit, odd strides."""
@@ -168,10 +177,12 @@ def test_emulated_down_kernel_table_driven_flavours():
     every input/output type incl. 24-bit, byte-aligned rows."""
     rng = random.Random(999)
     kinds = set()
-    for it in range(110):
-        w_out = rng.choice([1, 2, 7, 40, 64, 65, 130, 256])
+    for it in range(150):
+        # (from 256 columns and below ratio 2 the 11-bit flavour takes four columns per lane and 16-byte stores)
+        w_out = rng.choice([1, 2, 7, 40, 64, 65, 130, 256, 257, 300, 515, 700])
         h_out = rng.choice([1, 2, 5, 17, 33])
-        w_in = max(2, min(int(w_out * rng.uniform(1.01, 7.99)) + rng.randint(0, 1), 8 * w_out - 1))
+        rx = rng.uniform(1.01, 1.99) if it % 3 == 1 else rng.uniform(1.01, 7.99)
+        w_in = max(2, min(int(w_out * rx) + rng.randint(0, 1), 8 * w_out - 1))
         h_in = max(2, min(int(h_out * rng.uniform(1.01, 7.99)) + rng.randint(0, 1), 8 * h_out - 1))
         if w_in <= w_out or h_in <= h_out:
             continue
