@@ -93,9 +93,10 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
     const LutLds lut (lut_lds);
     const uintptr_t src_base = (uintptr_t) J.src;
 
-    auto rows = [&] (auto aligned_tag)
+    auto rows = [&] (auto aligned_tag, const auto &un)
     {
     constexpr bool AL = decltype (aligned_tag)::value;
+    bool try_opaque = true;
     for (uint32_t r = r0; r <= r1; r++)
     {
         /* one row buffer per wave: request the row, wait for it, sum it (the waves next door fill the gap) */
@@ -114,33 +115,60 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             uint32_t acc [4] = { 0, 0, 0, 0 }, c [4];
             if (edges)
             {
-                unpack_word<true> (J, box2_px_word<AL> (J, rowb, off), c, lut);
+                un (box2_px_word<AL> (J, rowb, off), c);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     acc [i] = ((c [i] * wl) >> 8) & 0x00ffffffu;
-                unpack_word<true> (J, box2_px_word<AL> (J, rowb, last_ofs + mis), c, lut);
+                un (box2_px_word<AL> (J, rowb, last_ofs + mis), c);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     acc [i] += ((c [i] * fr) >> 8) & 0x00ffffffu;
             }
             off = int_ofs + mis;
-            /* interior pixels four at a time: the LDS reads of a group are independent */
+            /* interior pixels four at a time, converted in one branch-free block (`un': the conversion's flavour, fixed
+             * per wave); a pixel past the lane's share is a zero word with its channels masked off */
             for (uint32_t k = 0; k < J.box_nmax; k += 4)
             {
-                uint32_t w4 [4];
+                uint32_t w4 [4], c4 [4][4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++)
                     w4 [u] = (k + u < n_int) ? box2_px_word<AL> (J, rowb, off + u * bpp) : 0u;
+                constexpr int UK = std::remove_reference_t<decltype (un)>::KIND;
+                bool opaque = false;
+                if constexpr (UK == WU_LIN_P || UK == WU_LIN_U)
+                if (try_opaque)
+                {
+                    /* photographs with an alpha channel: a group that is opaque on the whole wave takes the fused table.
+                     * The first translucent group ends the looking for the rest of this wave's rows: on translucent
+                     * images the test itself costs 9 % (profiles/r03j_box_opaque_check_ab.txt), on opaque ones the fused
+                     * table saves 14 % */
+                    uint32_t all = 0xffffffffu;
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        all &= (k + u < n_int) ? w4 [u] : 0xffffffffu;
+                    opaque = wide_batch_opaque (J, all);
+                    try_opaque = opaque;
+                }
+                if (opaque)
+                {
+                    const WideUnpack<WU_LIN_O> uno (J, lut);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        uno (w4 [u], c4 [u]);
+                }
+                else
+                {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        un (w4 [u], c4 [u]);
+                }
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++)
                 {
-                    if (k + u < n_int)
-                    {
-                        unpack_word<true> (J, w4 [u], c, lut);
+                    const uint32_t m = (k + u < n_int) ? 0xffffffffu : 0u;
 #pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            acc [i] += c [i];
-                    }
+                    for (int i = 0; i < 4; i++)
+                        acc [i] += c4 [u][i] & m;
                 }
                 off += 4u * bpp;
             }
@@ -240,10 +268,36 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (gptr (J.tmp) + ((size_t) (r - J.tmp_row0) * J.w_out + x) * 8) = res;
     }
     };
-    if (J.in_dword_ok)
-        rows (BoxAligned<true> ());
+    if constexpr (!WIDE)
+    {
+        const WideUnpack<WU_ANY> un (J, lut);                       /* (unused by the 64bpp class) */
+        if (J.in_dword_ok)
+            rows (BoxAligned<true> (), un);
+        else
+            rows (BoxAligned<false> (), un);
+    }
     else
-        rows (BoxAligned<false> ());
+    {
+    /* 128bpp class: the conversion's flavour is fixed here, once per wave (smol_kernels.hip.h WideUnpack) */
+    int uk = wide_unpack_kind (J);
+    if (uk == WU_ANY && !J.p16 && !J.linear && !J.unassoc_in && J.bpp_in == 4)
+        uk = WU_FLAT_P;
+    auto go = [&] (const auto &un)
+    {
+        if (J.in_dword_ok)
+            rows (BoxAligned<true> (), un);
+        else
+            rows (BoxAligned<false> (), un);
+    };
+    switch (uk)
+    {
+        case WU_LIN_P:  go (WideUnpack<WU_LIN_P> (J, lut)); break;
+        case WU_LIN_U:  go (WideUnpack<WU_LIN_U> (J, lut)); break;
+        case WU_LIN_O:  go (WideUnpack<WU_LIN_O> (J, lut)); break;
+        case WU_FLAT_P: go (WideUnpack<WU_FLAT_P> (J, lut)); break;
+        default:        go (WideUnpack<WU_ANY> (J, lut)); break;
+    }
+    }
 }
 
 /* LPC = lanes per output pixel: 1, or 8 for tall boxes (the lanes take every 8th row of the

@@ -491,8 +491,10 @@ enum : int { WU_ANY = 0,       /* run-time flags (unpack_word<true>): compressed
              WU_P16L,          /* premul16 + linear: from_srgb (c) * a                               :627-660    */
              WU_LIN_P,         /* linear, premultiplied 32-bit input: unpremul8 -> from_srgb -> premul8l :481-535 */
              WU_LIN_U,         /* linear, unassociated 32-bit input: from_srgb -> premul8l           :588-614    */
-             WU_LIN_O };       /* linear, every pixel opaque (24-bit input; or the caller saw alpha = 255 on the
+             WU_LIN_O,         /* linear, every pixel opaque (24-bit input; or the caller saw alpha = 255 on the
                                 * whole wave): one fused look-up per channel                                     */
+             WU_FLAT_P };      /* compressed 128bpp (boxes wider than 255 pixels), premultiplied 32-bit input: the bytes
+                                * as they are (:470-479); chosen by the box kernels only                           */
 enum : int { WP_ANY = 0, WP_P16, WP_P16L,
              WP_LIN_P,         /* linear -> premultiplied 32-bit: unpremul8l -> to_srgb -> premul8   :1096-1109  */
              WP_LIN_U,         /* linear -> unassociated 32-bit, or 24-bit through the `321' packer  :1122-1134, :1010-1023 */
@@ -525,6 +527,7 @@ __device__ __forceinline__ int wide_pack_kind (const JobDev &J)
 template <int K>
 struct WideUnpack
 {
+    static constexpr int KIND = K;
     const JobDev &J;
     const LutLds &lut;
     uint32_t sr, sg, sb, sa;
@@ -542,6 +545,12 @@ struct WideUnpack
             return;
         }
         const uint32_t r = (w >> sr) & 0xffu, g = (w >> sg) & 0xffu, b = (w >> sb) & 0xffu;
+        if (K == WU_FLAT_P)
+        {
+            c [0] = r; c [1] = g; c [2] = b;
+            c [3] = (w >> sa) & 0xffu;
+            return;
+        }
         if (K == WU_LIN_O)
         {
             c [0] = lut.opaque_lin (r);
