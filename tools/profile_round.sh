@@ -33,6 +33,8 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" 
   i=$((i+1))
   rocprofv3 --pmc $set -d $O/sq_box/p$i -o p --output-format csv -- python3 tools/bench_configs.py --configs BOX --iters 3 --warmup 1 --settle 0.05 > $O/sq_box_log$i.txt 2>&1 || echo "SQ set $i failed"
 done
+# SQ counters of the gamma-correct rows (128bpp class: vector issue against table look-ups)
+for c in SRGB SRGBUP SRGBHALF; do bash tools/sq_counters.sh $TAG $c > /dev/null 2>&1; done
 # (gpurun merges gpurun_out/ back, not profiles/: run the two lines below again in the build container afterwards)
 python3 tools/profile_summary.py $TAG
 python3 tools/roofline_check.py $TAG | tee $O/roofline_check.txt
