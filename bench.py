@@ -42,6 +42,8 @@ import torch  # noqa: E402
 
 import smolscale_amd as sm  # noqa: E402
 
+sm.harden_host_memory()      # the e2e leg and the verification hand pageable numpy memory to the host entry points
+
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 W_IN = H_IN = 4096
 W_OUT = H_OUT = 1024

@@ -131,6 +131,26 @@ EXPORTS = {
 _lib = None
 
 
+def harden_host_memory():
+    """For processes that hand PAGEABLE heap memory to the host entry points (tests, bench.py's e2e leg, smoke()).
+
+    The ROCm runtime serves a large copy from / to pageable memory by pinning the caller's pages in place and letting
+    the GPU access them. On this pool that faults now and then when the pages are glibc's brk heap backed by
+    transparent huge pages -- "Memory access fault by GPU ... Write access to a read-only page / Reason: Unknown" at an
+    address inside the caller's buffer, 3-8 % of the runs of tests/test_hip_multi.py, 27 % with every array forced into
+    the brk heap, 0 of 60 with THP off for the process or with large arrays mmap-backed
+    (profiles/r03k_pageable_heap_fault.txt). Nothing in the library is involved (the fault is in the runtime's copy),
+    but a test process must not die of it: THP off for this process (prctl PR_SET_THP_DISABLE) and arrays from 64 KiB
+    up in their own mmap (mallopt M_MMAP_THRESHOLD; glibc otherwise raises the threshold to 32 MiB as arrays are
+    freed). Applications should hand over page-locked memory (smol_hip_host_register) or mmap-backed buffers."""
+    try:
+        libc = ctypes.CDLL(None)
+        libc.prctl(41, 1, 0, 0, 0)              # PR_SET_THP_DISABLE
+        libc.mallopt(-3, 1 << 16)               # M_MMAP_THRESHOLD = 64 KiB (and no dynamic adjustment)
+    except (OSError, AttributeError):
+        pass
+
+
 def build():
     """Compile libsmolscale_amd.so in-tree (hipcc --offload-arch=gfx950)."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])

@@ -12,6 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# The tests hand pageable numpy memory to the host entry points; see harden_host_memory() for the runtime / THP
+# hazard this keeps out of the test process (before any large array exists).
+import smolscale_amd as _sm  # noqa: E402
+_sm.harden_host_memory()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
