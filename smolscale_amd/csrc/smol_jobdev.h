@@ -535,6 +535,12 @@ pow2x_tiles_y (const JobDev &d)
 constexpr uint32_t DOWN_LUT_BYTES_FWD = (SMOL_LUT_LDS_BYTES + 15) & ~15u;   /* LDS copy of the tables */
 constexpr uint32_t UP_NSRC_HOST = 10;
 constexpr uint32_t UP_NSRC_W_HOST = 8;      /* premul16 flavour */
+#ifndef SMOL_UPG_NSRC
+#define SMOL_UPG_NSRC 8
+#endif
+constexpr uint32_t UPG_NSRC_HOST = SMOL_UPG_NSRC;      /* table-driven flavours (k_upg): source rows a tile keeps in registers
+                                                        * (6 or 5 rows -- fewer registers, flatter tiles -- measured within +-3 % and
+                                                        * -8 %: profiles/r03l_upg_nsrc_ab.txt) */
 
 inline bool
 up_setup (JobDev &d)
@@ -567,7 +573,7 @@ up_setup (JobDev &d)
 
     d.up_wide = (uint8_t) flavour;
     d.tile_band = tune_env ("SMOL_NO_UP_BAND") ? 0 : 1;     /* tiles dealt out in XCD bands */
-    uint64_t tr = (((uint64_t) ((flavour ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
+    uint64_t tr = (((uint64_t) ((flavour >= 2 ? UPG_NSRC_HOST : flavour ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
     if (tr > 64)
         tr = 64;
     /* 64bpp class: the kernel is bound by its stores, and those want the chip to sweep the output in
@@ -604,7 +610,7 @@ inline uint32_t
 up_lds_bytes (const JobDev &d)
 {
     if (d.up_wide >= 2)
-        return DOWN_LUT_BYTES_FWD + 4u * ((UP_NSRC_W_HOST * d.span_px * (d.up_wide == 3 ? 16u : 8u) + 15u) & ~15u) + 16u;
+        return DOWN_LUT_BYTES_FWD + 4u * ((UPG_NSRC_HOST * d.span_px * (d.up_wide == 3 ? 16u : 8u) + 15u) & ~15u) + 16u;
     if (d.up_wide)
         return UP_NSRC_W_HOST * d.span_px * 8u + 1024u + 16u;       /* + the inverse table */
     return UP_NSRC_HOST * d.span_px * 8u + 16u;

@@ -467,6 +467,8 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
  * flavour chosen per batch (smolscale-generic.c:470-752, 912-1164); 4 waves per workgroup share one    *
  * LDS copy of the six tables, each wave works on its own tile.                *
  * ------------------------------------------------------------------------- */
+constexpr int UPG_NSRC = SMOL_UPG_NSRC;     /* source rows per tile of the table-driven flavours (smol_jobdev.h) */
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void up_static_for (F &&f)
 {
@@ -522,8 +524,8 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
     const uint32_t oy_last = smol_readlane (my_oy, nrows - 1);
     const uint32_t sched = (my_oy - oy_first) | (my_f << 16);
     uint32_t n_src = oy_last - oy_first + 2;
-    if (n_src > (uint32_t) UP_NSRC_W)
-        n_src = UP_NSRC_W;                              /* cannot happen: up_setup sizes tile_rows */
+    if (n_src > (uint32_t) UPG_NSRC)
+        n_src = UPG_NSRC;                              /* cannot happen: up_setup sizes tile_rows */
 
     /* ---- stage: every source pixel of the tile once, as internal channels ------------------ */
     const uint32_t span = J.span_px;
@@ -594,9 +596,9 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
     smol_wave_sync ();
 
     /* ---- H ---------------------------------------------------------------------------- */
-    uint32_t h [UP_NSRC_W][CPL][NCH];
+    uint32_t h [UPG_NSRC][CPL][NCH];
 #pragma unroll
-    for (int s = 0; s < UP_NSRC_W; s++)
+    for (int s = 0; s < UPG_NSRC; s++)
     {
 #pragma unroll
         for (int c = 0; c < CPL; c++)
@@ -638,7 +640,7 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
 
     /* compile-time loop over the source-row pairs: h [] must be indexed by constants (a loop the
      * optimiser declines to unroll would put it in scratch memory) */
-    up_static_for<0, UP_NSRC_W - 1> ([&] (auto s_const)
+    up_static_for<0, UPG_NSRC - 1> ([&] (auto s_const)
     {
         constexpr int s = decltype (s_const)::value;
         while (r < nrows && (e & 0xffffu) == (uint32_t) s)
@@ -731,7 +733,7 @@ __device__ __forceinline__ void upg_entry (const JobDev &J, uint8_t *lds)
     const uint32_t wave = threadIdx.x >> 6;
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
-    const uint32_t region = (UP_NSRC_W * J.span_px * (W32 ? 16u : 8u) + 15u) & ~15u;
+    const uint32_t region = (UPG_NSRC * J.span_px * (W32 ? 16u : 8u) + 15u) & ~15u;
     upg_body<W32> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * region, lds,
                    threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
