@@ -291,6 +291,35 @@ def test_down_kernel_srgb_linear_flavours():
             assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
 
 
+def test_gamma_correct_kernels_on_opaque_images_and_on_a_translucent_block():
+    """with_srgb = 1 on what gamma-correct scaling is used for -- photographs with an alpha channel. Every wave of an
+    all-opaque image takes the fused one-look-up conversions (WU_LIN_O / WP_LIN_O, chosen per wave by a ballot: per row
+    in k_downg, per batch in k_upg / k_pow2x, per group with hysteresis in k_boxh); with one translucent block in the
+    image the waves over its border decide batch by batch. 4:1 (k_pow2x), x3 (k_upg), ratios 1.5 and 2.5 (k_downg), box
+    ratios 9 and 20 (k_boxh + k_boxv); premultiplied, unassociated and 24-bit destinations; host and device entries."""
+    shapes = [(1024, 256, 256, 64), (200, 60, 600, 180), (900, 300, 600, 200), (1000, 250, 400, 100),
+              (1800, 180, 200, 20), (2000, 400, 100, 20)]
+    pairs = [(0, 0), (2, 5), (4, 3), (5, 4), (7, 8), (1, 9), (6, 6)]
+    k = 0
+    for (w_in, h_in, w_out, h_out) in shapes:
+        for (t_in, t_out) in pairs[k % 2::2] if (w_in * h_in > 500_000) else pairs:
+            for block in (False, True):
+                k += 1
+                src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, pad=0)
+                px = src[:w_in * h_in * 4].reshape(h_in, w_in, 4)
+                apos = 3 if (t_in & 3) < 2 else 0
+                keep = px[:, :, apos].copy()
+                px[:, :, apos] = 255
+                if block:
+                    y0, x0 = h_in // 3, w_in // 4
+                    px[y0:y0 + h_in // 4 + 1, x0:x0 + w_in // 3 + 1, apos] = keep[y0:y0 + h_in // 4 + 1, x0:x0 + w_in // 3 + 1]
+                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1)
+                got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1)
+                assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, block, "host")
+                got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 1)
+                assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, block, "device")
+
+
 def test_two_pass_box_thumbnails_single_and_batched():
     """k_boxh + k_boxv (strong minification; every 128bpp-class box): host API, device API
     (temporary intermediate image), one batch with its own scratch, and the same batch as a hipGraph."""

@@ -144,6 +144,8 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
     slot_out = ((h_out * w_out * 4 + 64 + 255) // 256) * 256
     if use_arena:
         arena_in, arena_out = sm.DeviceBuffer(n_images * slot_in), sm.DeviceBuffer(n_images * slot_out)
+        if os.environ.get("SMOL_BENCH_PRINT_ARENA"):
+            print("arena %s in %x out %x" % (name, arena_in.ptr, arena_out.ptr), file=sys.stderr)
     off_in = off_out = 0
 
     # one shared pool of random bytes uploaded once per distinct input size
