@@ -42,8 +42,6 @@ import torch  # noqa: E402
 
 import smolscale_amd as sm  # noqa: E402
 
-sm.harden_host_memory()      # the e2e leg and the verification hand pageable numpy memory to the host entry points
-
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 W_IN = H_IN = 4096
 W_OUT = H_OUT = 1024
@@ -177,7 +175,8 @@ def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out
     src = torch.randint(0, 256, (n_frames, slot_in), dtype=torch.uint8, device=dev, generator=gen)
     dst = torch.zeros((n_frames, slot_out), dtype=torch.uint8, device=dev)
     frame0 = seed0_frame()
-    src[0, :slab_rows * s_in].copy_(torch.from_numpy(frame0[r0 * s_in:(r1 + 1) * s_in]))
+    torch.cuda.synchronize()
+    sm.upload(src[0].data_ptr(), frame0[r0 * s_in:(r1 + 1) * s_in], local_rank)
     images = [_image(job, src[f].data_ptr() - r0 * s_in, dst[f].data_ptr(), s_in, s_out, first_row, n_rows)
               for f in range(n_frames)]
     torch.cuda.synchronize()
@@ -190,7 +189,8 @@ def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out
     def check(n_check=None):
         n = n_rows if n_check is None else min(n_rows, n_check)
         want = H.oracle_scale(frame0, t_in, w_in, h_in, t_out, w_out, h_out, stride_in=s_in, first=first_row, n=n)
-        got = dst[0, :n * s_out].cpu().numpy()
+        torch.cuda.synchronize()
+        got = sm.download(dst[0].data_ptr(), n * s_out, local_rank)
         return bool(np.array_equal(got, want))
     w.check = check
     return w, job
@@ -260,7 +260,8 @@ def work_c5mix(rank, world, dev, local_rank, n_total=10000):
         bi, bo = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
         if k < n_check:
             f = H.make_input(t_in, 256, 256, seed=i, valid=True, pad=0)
-            src[k, :f.size].copy_(torch.from_numpy(f))
+            torch.cuda.synchronize()
+            sm.upload(src[k].data_ptr(), f, local_rank)
             seeded.append((k, t_in, t_out, f))
         images.append(_image(jobs[(t_in, t_out)], src[k].data_ptr(), dst[k].data_ptr(), 256 * bi, 64 * bo, 0, 64))
         algo += 256 * 256 * bi + 64 * 64 * bo
@@ -280,7 +281,7 @@ def work_c5mix(rank, world, dev, local_rank, n_total=10000):
         ok = True
         for k, t_in, t_out, f in seeded:
             want = H.oracle_scale(f, t_in, 256, 256, t_out, 64, 64)
-            ok = ok and bool(np.array_equal(dst[k, :want.size].cpu().numpy(), want))
+            ok = ok and bool(np.array_equal(sm.download(dst[k].data_ptr(), want.size, local_rank), want))
         return ok if seeded else None
     w.check = check
     return w
@@ -363,7 +364,7 @@ def kernel_source_digest(all_kernels=False):
     names = ("smol_kernels.hip.h", "smol_k_stream.hip", "smol_jobdev.h")
     if all_kernels:
         names = sorted(f for f in os.listdir(os.path.join(ROOT, "smolscale_amd", "csrc"))
-                       if f.endswith((".hip.h", ".hip", "smol_jobdev.h", ".inc.h")))
+                       if f.endswith((".hip.h", ".hip", "smol_jobdev.h", ".inc.h")) and not f.startswith("smol_rt_"))
     for f in names:
         with open(os.path.join(ROOT, "smolscale_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
@@ -398,6 +399,21 @@ def recorded_traffic(bytes_per_launch):
         t.get("source", "?"), t.get("commit", "?"))
 
 
+def recorded_profiled_launch(bytes_per_launch):
+    """(average launch duration in us by rocprofv3 --kernel-trace, file) from the last end-of-round capture
+    (profiles/traffic_latest.json, written by tools/profile_summary.py from <tag>_kernel_by_grid.csv), quoted only for
+    the same kernel sources and launch size. The line carries BOTH fractions: `frac` from this run's own hipEvents,
+    `frac_profiled` from the tracked trace of another process on another box (they differ by the +-3-5 % that two
+    processes differ by)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    except Exception:                               # noqa: BLE001
+        return None, "no capture on file"
+    if t.get("kernel_source_digest") != kernel_source_digest() or t.get("algorithmic_bytes_per_launch") != bytes_per_launch:
+        return None, "capture on file predates the current kernel sources or launch size"
+    return t.get("profiled_launch_us"), t.get("profiled_source", "?")
+
+
 def e2e_c4(w, local_rank, reps=3):
     """The strip of --config c4 from HOST memory through smol_hip_scale_rows_host(): PCIe inclusive,
     page-locked and pageable, checked against the device-resident result."""
@@ -407,19 +423,20 @@ def e2e_c4(w, local_rank, reps=3):
     frame = w.host_frame()
     plan = sm.HipPlan(w.job, local_rank)
     out = {}
-    ref = w.keep[1][0, :n_rows * w_out * 4].cpu().numpy()
+    torch.cuda.synchronize()
+    ref = sm.download(w.keep[1][0].data_ptr(), n_rows * w_out * 4, local_rank)
     bytes_moved = n_rows * (w_in * 3 + w_out * 4)
     for mode in ("pinned", "pinned_hostalloc", "pageable"):
         if mode == "pinned":                        # caller's memory page-locked in place (hipHostRegister)
+            hsrc = sm.PinnedArray(frame.size, register=True)
+            hsrc.array[:] = frame
+            hdst = sm.PinnedArray(n_rows * w_out * 4, register=True)
+            a_src, a_dst = hsrc.array, hdst.array
+        elif mode == "pinned_hostalloc":            # memory that was allocated page-locked (smol_hip_host_alloc = hipHostMalloc)
             hsrc = sm.PinnedArray(frame.size)
             hsrc.array[:] = frame
             hdst = sm.PinnedArray(n_rows * w_out * 4)
             a_src, a_dst = hsrc.array, hdst.array
-        elif mode == "pinned_hostalloc":            # memory that was allocated page-locked (hipHostMalloc)
-            tsrc = torch.empty(frame.size, dtype=torch.uint8, pin_memory=True)
-            tdst = torch.empty(n_rows * w_out * 4, dtype=torch.uint8, pin_memory=True)
-            a_src, a_dst = tsrc.numpy(), tdst.numpy()
-            a_src[:] = frame
         else:
             a_src, a_dst = frame, np.zeros(n_rows * w_out * 4, np.uint8)
         plan.scale_rows_host(a_src, s_in, a_dst, w_out * 4, rank_first, n_rows)        # warm-up: lanes, slabs
@@ -432,7 +449,8 @@ def e2e_c4(w, local_rank, reps=3):
         best = min(ts)
         out[mode] = {"ms": round(best * 1e3, 3), "GBps_over_pcie": round(bytes_moved / best / 1e9, 1),
                      "Mpix_out_per_s": round(n_rows * w_out / best / 1e6, 1), "equal_to_device_resident": ok}
-        if mode == "pinned":
+        if mode != "pageable":
+            a_src = a_dst = None
             hsrc.free()
             hdst.free()
     plan.destroy()
@@ -555,6 +573,16 @@ def e2e_c2(local_rank, frame0, want0, reps=3, n_callers=16):
             out[mode] = {"error": repr(e)}
         for k in keep:
             k.free()
+    # a caller that asks for its rows a few at a time (the reference's own outer loop is one row per step,
+    # smolscale.c:507-546): ONE context, smol_scale_batch() for 1 / 8 / 64 / all rows per call
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_rows_per_call
+        out["rows_per_call"] = bench_rows_per_call.table(reps=2)
+        out["rows_per_call"]["what"] = ("ms per image when ONE context is asked for its rows n at a time; x_whole = relative to "
+                                        "one call for the whole image; calls moving <= 256 KiB take the zero-copy road")
+    except Exception as e:                                          # noqa: BLE001
+        out["rows_per_call"] = {"error": repr(e)}
     if old_aff is not None:
         try:
             os.sched_setaffinity(0, old_aff)
@@ -685,6 +713,8 @@ def main():
         launch_ms = kernel_ms / args.steps / max(1, n_launches)
         achieved = w.bytes_per_launch / max(1, n_launches) / (launch_ms * 1e-3) / 1e9 if launch_ms else 0.0
         traffic, traffic_source = recorded_traffic(w.bytes_per_launch) if args.config == "c2" else (None, "not captured for this config")
+        prof_us, prof_src = (recorded_profiled_launch(w.bytes_per_launch) if args.config == "c2"
+                             else (None, "not captured for this config"))
         metric = {"c2": "Mpixels/sec 4K->1K RGBA8 downscale (output pixels)",
                   "c4": "Mpixels/sec 65535x4096 RGB8 -> 8192x4096 RGBA8 (output pixels)",
                   "c5mix": "Mpixels/sec 10000 mixed-type 256->64 thumbnails (output pixels)"}[args.config]
@@ -712,6 +742,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_profiled": (round(w.bytes_per_launch / max(1, n_launches) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                  if prof_us else None),
+                "frac_profiled_source": prof_src,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "bytes_per_launch": w.bytes_per_launch // max(1, n_launches),
@@ -742,7 +775,8 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if ref_want is not None:
-            got = w.keep[1][0, :W_OUT * H_OUT * 4].cpu().numpy()
+            torch.cuda.synchronize()
+            got = sm.download(w.keep[1][0].data_ptr(), W_OUT * H_OUT * 4, local_rank)
             line["bit_exact_vs_reference"] = bool(np.array_equal(got, ref_want))
         print(json.dumps(line), flush=True)
 

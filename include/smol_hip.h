@@ -109,17 +109,29 @@ void smol_hip_plan_destroy (SmolHipPlan *plan);
 /* Allocates whatever smol_hip_scale_rows_device() could need for this plan now, so that
  * later calls are purely asynchronous launches (legal under stream capture). Optional. */
 int smol_hip_plan_prepare (SmolHipPlan *plan);
+/* The same for callers that keep several source images in flight on one plan (frame N and N+1 on
+ * alternating streams): allocates the intermediate images and ordering events for `images_in_flight'
+ * (1..4) images now. Without it the second to fourth buffer are allocated on first use, and an
+ * allocation synchronises the device and must not run while another thread captures a stream in
+ * global capture mode. */
+int smol_hip_plan_reserve (SmolHipPlan *plan, uint32_t images_in_flight);
 
 /* Host-pointer entry (what smol_scale_batch() calls): copies the needed input
  * rows to the device, runs the kernels, copies rows [first_row, first_row+n_rows)
  * back to dest_host (row first_row at offset 0, rowstride_out apart; bytes
  * between rows are left untouched). Thread-safe on one plan. Synchronous.
  *
- * The strip is cut into chunks of output rows that flow through three side streams of
- * a staging lane -- H2D of chunk k+1, the kernels of chunk k and D2H of chunk k-1 run
- * concurrently (events order them; nothing else synchronises until the end). With
- * page-locked host memory (smol_hip_host_register / hipHostMalloc) every copy is a true
- * asynchronous DMA; pageable memory works too, the runtime then stages the copies. */
+ * ANY host memory works, as with the reference (smolscale-generic.c:1613-1642 reads and writes
+ * the caller's rows with plain loads and stores). The strip is cut into chunks of output rows
+ * that flow through three side streams of a staging lane -- H2D of chunk k+1, the kernels of
+ * chunk k and D2H of chunk k-1 run concurrently (events order them; nothing else synchronises
+ * until the end). Page-locked memory (smol_hip_host_alloc, smol_hip_host_register, hipHostMalloc)
+ * is handed to the DMA engines in place. PAGEABLE memory is never shown to the HIP runtime: the
+ * library's copy threads move it through a ring of page-locked buffers owned by the lane (in and
+ * out), so no page of the caller's heap is ever pinned or touched by the GPU. A call that moves
+ * at most SMOL_HIP_ZEROCOPY_KB (default 256) KiB skips the DMA engines altogether: the kernel
+ * reads and writes the ring across PCIe -- one launch and one wait per call, for callers that
+ * ask for their rows a few at a time (the reference's own outer loop, smolscale.c:507-546). */
 int smol_hip_scale_rows_host (SmolHipPlan *plan,
                               const void *pixels_in_host, uint32_t rowstride_in,
                               void *dest_host, uint32_t rowstride_out,
@@ -152,6 +164,10 @@ int smol_hip_scale_rows_peer (SmolHipPlan *plan, int src_device,
  * transfer of the range. */
 int smol_hip_host_register (void *host_ptr, uint64_t n_bytes);
 int smol_hip_host_unregister (void *host_ptr);
+/* Page-locked host memory from the runtime's own allocator (hipHostMalloc): the preferred way to
+ * get buffers that take the zero-copy road. */
+int smol_hip_host_alloc (uint64_t n_bytes, void **host_ptr_out);
+int smol_hip_host_free (void *host_ptr);
 
 /* Device-pointer entry: input image and output strip already live in device
  * memory. Asynchronous on `hip_stream' (a hipStream_t, NULL = default stream): no
@@ -216,7 +232,8 @@ void smol_hip_batch_multi_destroy (SmolHipBatchMulti *batch);
 void smol_hip_shutdown (void);
 
 /* Device memory helpers so that hosts without a HIP binding (ctypes, cgo...)
- * can stage buffers. */
+ * can stage buffers. The copies are synchronous and ordered like hipMemcpy (behind what the
+ * caller queued on blocking streams); pageable host memory travels through a bounce ring. */
 int smol_hip_malloc (int device, uint64_t n_bytes, void **dev_ptr_out);
 int smol_hip_free (int device, void *dev_ptr);
 int smol_hip_memcpy_h2d (int device, void *dst_dev, const void *src_host, uint64_t n_bytes);

@@ -95,11 +95,14 @@ EXPORTS = {
     "smol_hip_plan_create": (_int, [ctypes.POINTER(SmolHipJob), _int, ctypes.POINTER(_vp)]),
     "smol_hip_plan_destroy": (None, [_vp]),
     "smol_hip_plan_prepare": (_int, [_vp]),
+    "smol_hip_plan_reserve": (_int, [_vp, _u32]),
     "smol_hip_scale_rows_host": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32]),
     "smol_hip_scale_rows_host_multi": (_int, [ctypes.POINTER(_vp), _u32, _vp, _u32, _vp, _u32, _u32, _u32]),
     "smol_hip_scale_rows_peer": (_int, [_vp, _int, _vp, _u32, _vp, _u32, _u32, _u32]),
     "smol_hip_host_register": (_int, [_vp, _u64]),
     "smol_hip_host_unregister": (_int, [_vp]),
+    "smol_hip_host_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
+    "smol_hip_host_free": (_int, [_vp]),
     "smol_hip_scale_rows_device": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp]),
     "smol_hip_batch_create": (_int, [ctypes.POINTER(SmolHipImage), _u32, _int, ctypes.POINTER(_vp)]),
     "smol_hip_batch_launch": (_int, [_vp, _vp]),
@@ -129,26 +132,6 @@ EXPORTS = {
 }
 
 _lib = None
-
-
-def harden_host_memory():
-    """For processes that hand PAGEABLE heap memory to the host entry points (tests, bench.py's e2e leg, smoke()).
-
-    The ROCm runtime serves a large copy from / to pageable memory by pinning the caller's pages in place and letting
-    the GPU access them. On this pool that faults now and then when the pages are glibc's brk heap backed by
-    transparent huge pages -- "Memory access fault by GPU ... Write access to a read-only page / Reason: Unknown" at an
-    address inside the caller's buffer, 3-8 % of the runs of tests/test_hip_multi.py, 27 % with every array forced into
-    the brk heap, 0 of 60 with THP off for the process or with large arrays mmap-backed
-    (profiles/r03k_pageable_heap_fault.txt). Nothing in the library is involved (the fault is in the runtime's copy),
-    but a test process must not die of it: THP off for this process (prctl PR_SET_THP_DISABLE) and arrays from 64 KiB
-    up in their own mmap (mallopt M_MMAP_THRESHOLD; glibc otherwise raises the threshold to 32 MiB as arrays are
-    freed). Applications should hand over page-locked memory (smol_hip_host_register) or mmap-backed buffers."""
-    try:
-        libc = ctypes.CDLL(None)
-        libc.prctl(41, 1, 0, 0, 0)              # PR_SET_THP_DISABLE
-        libc.mallopt(-3, 1 << 16)               # M_MMAP_THRESHOLD = 64 KiB (and no dynamic adjustment)
-    except (OSError, AttributeError):
-        pass
 
 
 def build():
@@ -330,6 +313,9 @@ class HipPlan:
     def prepare(self):
         check(lib().smol_hip_plan_prepare(self._h), "smol_hip_plan_prepare")
 
+    def reserve(self, images_in_flight):
+        check(lib().smol_hip_plan_reserve(self._h, images_in_flight), "smol_hip_plan_reserve")
+
     def scale_rows_host(self, src, rowstride_in, dst, rowstride_out, first_row, n_rows):
         check(lib().smol_hip_scale_rows_host(self._h, _as_u8(src).ctypes.data, rowstride_in,
                                              dst.ctypes.data, rowstride_out, first_row, n_rows),
@@ -359,20 +345,35 @@ def scale_rows_host_multi(plans, src, rowstride_in, dst, rowstride_out, first_ro
 
 
 class PinnedArray:
-    """A page-locked numpy uint8 buffer: host memory registered with smol_hip_host_register()."""
+    """A page-locked numpy uint8 buffer: smol_hip_host_alloc() (hipHostMalloc), or -- register=True -- an anonymous
+    mapping of the caller's registered with smol_hip_host_register()."""
 
-    def __init__(self, n_bytes):
-        # page-aligned backing store; registration pins whole pages
-        self._raw = np.zeros(int(n_bytes) + 8192, np.uint8)
-        off = (-self._raw.ctypes.data) % 4096
-        self.array = self._raw[off:off + int(n_bytes)]
-        check(lib().smol_hip_host_register(self.array.ctypes.data, int(n_bytes)), "smol_hip_host_register")
-        self._registered = True
+    def __init__(self, n_bytes, register=False):
+        n = int(n_bytes)
+        self._registered = False
+        self._ptr = None
+        if register:
+            import mmap
+            self._map = mmap.mmap(-1, n + 4096)
+            self.array = np.frombuffer(self._map, np.uint8, n)
+            check(lib().smol_hip_host_register(self.array.ctypes.data, n), "smol_hip_host_register")
+            self._registered = True
+        else:
+            p = _vp()
+            check(lib().smol_hip_host_alloc(n, ctypes.byref(p)), "smol_hip_host_alloc")
+            self._ptr = p.value
+            self.array = np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(p.value))
+            self.array[:] = 0
 
     def free(self):
         if self._registered:
             lib().smol_hip_host_unregister(self.array.ctypes.data)
             self._registered = False
+            self.array = None
+        if self._ptr:
+            self.array = None
+            lib().smol_hip_host_free(self._ptr)
+            self._ptr = None
 
 
 class DeviceBuffer:
@@ -402,6 +403,20 @@ class DeviceBuffer:
         if self.ptr:
             lib().smol_hip_free(self.device, self.ptr)
             self.ptr = None
+
+
+def upload(dev_ptr, host, device=0):
+    """host (numpy) -> device pointer through smol_hip_memcpy_h2d(): pageable memory travels through the library's
+    page-locked bounce ring, never through the runtime's in-place pinning (also for tensors torch allocated)."""
+    h = _as_u8(host)
+    check(lib().smol_hip_memcpy_h2d(device, dev_ptr, h.ctypes.data, h.size), "h2d")
+
+
+def download(dev_ptr, n_bytes, device=0):
+    """device pointer -> a new numpy uint8 array through smol_hip_memcpy_d2h()."""
+    out = np.empty(int(n_bytes), np.uint8)
+    check(lib().smol_hip_memcpy_d2h(device, out.ctypes.data, dev_ptr, int(n_bytes)), "d2h")
+    return out
 
 
 # --------------------------------------------------------------------------- #

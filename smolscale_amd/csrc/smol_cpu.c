@@ -567,6 +567,11 @@ job_valid (const SmolHipJob *j)
         return 0;
     if ((j->filter_h == F_BOX && j->step_x < 0x10000u) || (j->filter_v == F_BOX && j->step_y < 0x10000u))
         return 0;
+    /* the last box must end inside the image: box k ends at (k + 1) * step (16.16). The planner's step,
+     * floor (dim_in * 65536 / dim_out), always does; 64 -> 64 with step 2.0 would read up to pixel 126 */
+    if ((j->filter_h == F_BOX && (((uint64_t) j->width_out * j->step_x) >> 16) > j->width_in)
+        || (j->filter_v == F_BOX && (((uint64_t) j->height_out * j->step_y) >> 16) > j->height_in))
+        return 0;
     return 1;
 }
 

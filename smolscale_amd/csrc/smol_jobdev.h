@@ -1,6 +1,6 @@
 /* smol_jobdev.h -- the device job descriptor and the host-side logic that fills
  * it and picks a kernel class. Plain C++ (no HIP headers) so that the host
- * emulation harness in tests/emu can share it with smol_hip.hip. */
+ * emulation harness in tests/emu can share it with the runtime (smol_rt_*.hip). */
 
 #pragma once
 

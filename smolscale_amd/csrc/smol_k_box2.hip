@@ -1,6 +1,6 @@
 /* smol_k_box2.hip -- kernel instantiations + launch wrappers of k_boxh / k_boxv, the
  * two-pass box filter (gfx950). One translation unit per kernel family so that
- * `make -j' compiles them side by side; smol_hip.hip only sees smol_launch.h. */
+ * `make -j' compiles them side by side; the runtime (smol_rt_*.hip) only sees smol_launch.h. */
 
 #include <hip/hip_runtime.h>
 

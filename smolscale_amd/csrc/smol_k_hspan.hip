@@ -1,7 +1,7 @@
 /* smol_k_hspan.hip -- kernel instantiations + launch wrapper of the k_hspan family (row spans: vertical copy,
  * horizontal bilinear at a nearly power-of-two ratio; BASELINE config 4) for gfx950.
  * One translation unit per kernel family so that `make -j' compiles them side by
- * side; smol_hip.hip (the runtime) only sees smol_launch.h. */
+ * side; the runtime (smol_rt_*.hip) only sees smol_launch.h. */
 
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 /* smol_k_stream.hip -- kernel instantiations + launch wrappers of the k_pow2 / k_pow2x (streaming 2:1, 4:1, 8:1) family (gfx950).
  * One translation unit per kernel family so that `make -j' compiles them side by
- * side; smol_hip.hip (the runtime) only sees smol_launch.h. */
+ * side; the runtime (smol_rt_*.hip) only sees smol_launch.h. */
 
 #include <hip/hip_runtime.h>
 

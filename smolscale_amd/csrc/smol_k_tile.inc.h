@@ -1,6 +1,6 @@
 /* smol_k_tile.inc.h -- kernel instantiations + launch wrappers of the k_tile (arbitrary ratios, box, copy; 64bpp class) family (gfx950).
  * One translation unit per kernel family so that `make -j' compiles them side by
- * side; smol_hip.hip (the runtime) only sees smol_launch.h. */
+ * side; the runtime (smol_rt_*.hip) only sees smol_launch.h. */
 
 #include <hip/hip_runtime.h>
 

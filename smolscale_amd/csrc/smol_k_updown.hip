@@ -1,6 +1,6 @@
 /* smol_k_updown.hip -- kernel instantiations + launch wrappers of the k_up / k_down (magnification; 128bpp-class minification) family (gfx950).
  * One translation unit per kernel family so that `make -j' compiles them side by
- * side; smol_hip.hip (the runtime) only sees smol_launch.h. */
+ * side; the runtime (smol_rt_*.hip) only sees smol_launch.h. */
 
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 /* smol_kernels.hip.h -- device code of the HIP backend (gfx950 / CDNA4 only).
  *
- * Included by smol_hip.hip. Everything here is new code; the arithmetic it has
+ * Included by the kernel translation units (smol_k_*.hip). Everything here is new code; the arithmetic it has
  * to reproduce is the reference's integer fixed-point path (citations per
  * function, paths relative to the reference tree).
  *

@@ -12,10 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# The tests hand pageable numpy memory to the host entry points; see harden_host_memory() for the runtime / THP
-# hazard this keeps out of the test process (before any large array exists).
-import smolscale_amd as _sm  # noqa: E402
-_sm.harden_host_memory()
+# No process-level memory hardening here (rounds 1-3 switched THP off for the test process): the tests hand ordinary
+# pageable numpy memory to the host entry points, which is exactly what the library's bounce rings are for.
 
 
 def pytest_configure(config):

@@ -178,3 +178,11 @@ def test_cpu_plan_handle_row_batches_and_hand_built_jobs():
         assert lib.smol_cpu_plan_create(ctypes.byref(bad), ctypes.byref(plan)) < 0, field
         buf = np.zeros(64 * 64 * 4, np.uint8)
         assert lib.smol_cpu_scale_rows(ctypes.byref(bad), buf.ctypes.data, 256, buf.ctypes.data, 128, 0, 1) < 0, field
+    # a box whose last span would end outside the image (64 -> 64 with a step of 2 pixels reads up to pixel 126)
+    box = H.plan_job(0, 640, 64, 0, 64, 64, 0)
+    assert box.filter_h == sm.SMOL_HIP_FILTER_BOX
+    for field, value in (("width_in", 64), ("width_out", 641)):
+        bad = sm.SmolHipJob.from_buffer_copy(bytes(box))
+        setattr(bad, field, value)
+        plan = ctypes.c_void_p()
+        assert lib.smol_cpu_plan_create(ctypes.byref(bad), ctypes.byref(plan)) < 0, field

@@ -52,14 +52,15 @@ def test_rows_over_several_device_entries_pageable(n_dev_entries):
 def test_rows_over_several_device_entries_pinned_and_odd_strides():
     """Page-locked host memory: one thread drives every strip asynchronously (more strips than a
     device has lanes included); odd strides and a row range that is not the whole image."""
-    for spec in JOBS:
+    for k, spec in enumerate(JOBS):
         t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
         stride_in = w_in * H.bpp(t_in) + 7
         stride_out = w_out * H.bpp(t_out) + 5
         raw = H.make_input(t_in, w_in, h_in, seed=4, stride=stride_in, pad=16)
-        pin_src = sm.PinnedArray(raw.size)
+        # both kinds of page-locked memory: allocated that way, and the caller's own mapping registered in place
+        pin_src = sm.PinnedArray(raw.size, register=bool(k & 1))
         pin_src.array[:] = raw
-        pin_dst = sm.PinnedArray(h_out * stride_out)
+        pin_dst = sm.PinnedArray(h_out * stride_out, register=bool(k & 1))
         want = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, srgb,
                               stride_in=stride_in, stride_out=stride_out)
         job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
@@ -166,7 +167,9 @@ def test_device_pointer_box_path_is_asynchronous_and_capturable():
     src = H.make_input(t_in, w_in, h_in, seed=8, pad=16)
     want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out)
     dev = torch.device("cuda", 0)
-    dsrc = torch.from_numpy(src).to(dev)
+    dsrc = torch.empty(src.size, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    sm.upload(dsrc.data_ptr(), src)
     ddst = torch.zeros(h_out * w_out * 4, dtype=torch.uint8, device=dev)
     plan = sm.HipPlan(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0), 0)
     plan.prepare()
@@ -177,7 +180,7 @@ def test_device_pointer_box_path_is_asynchronous_and_capturable():
         plan.scale_rows_device(dsrc.data_ptr(), w_in * 4, ddst.data_ptr() + first * w_out * 4, w_out * 4,
                                first, n, stream=stream.cuda_stream)
     stream.synchronize()
-    assert np.array_equal(ddst.cpu().numpy(), want)
+    assert np.array_equal(sm.download(ddst.data_ptr(), ddst.numel()), want)
     # under capture
     ddst.zero_()
     torch.cuda.synchronize()
@@ -187,7 +190,7 @@ def test_device_pointer_box_path_is_asynchronous_and_capturable():
                                stream=torch.cuda.current_stream().cuda_stream)
     g.replay()
     torch.cuda.synchronize()
-    assert np.array_equal(ddst.cpu().numpy(), want)
+    assert np.array_equal(sm.download(ddst.data_ptr(), ddst.numel()), want)
     plan.destroy()
 
 
@@ -205,7 +208,9 @@ def test_one_box_plan_many_images_on_alternating_streams():
         src = H.make_input(t_in, w_in, h_in, seed=100 + f, pad=16)
         frames.append(src)
         wants.append(H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out))
-        dsrcs.append(torch.from_numpy(src).to(dev))
+        dsrcs.append(torch.empty(src.size, dtype=torch.uint8, device=dev))
+        torch.cuda.synchronize()
+        sm.upload(dsrcs[-1].data_ptr(), src)
         ddsts.append(torch.zeros(h_out * w_out * 4, dtype=torch.uint8, device=dev))
     plan = sm.HipPlan(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0), 0)
     plan.prepare()
@@ -224,7 +229,7 @@ def test_one_box_plan_many_images_on_alternating_streams():
                                    half, h_out - half, stream=st)
         torch.cuda.synchronize()
         for f in range(n_frames):
-            assert np.array_equal(ddsts[f].cpu().numpy(), wants[f]), (rnd, f)
+            assert np.array_equal(sm.download(ddsts[f].data_ptr(), ddsts[f].numel()), wants[f]), (rnd, f)
     # the same from threads, two strips of one frame on two different streams
     errs = []
 
@@ -250,7 +255,7 @@ def test_one_box_plan_many_images_on_alternating_streams():
     torch.cuda.synchronize()
     assert not errs, errs
     for f in range(n_frames):
-        assert np.array_equal(ddsts[f].cpu().numpy(), wants[f]), f
+        assert np.array_equal(sm.download(ddsts[f].data_ptr(), ddsts[f].numel()), wants[f]), f
     plan.destroy()
 
 
@@ -299,4 +304,64 @@ def test_row_range_arguments_that_wrap_are_rejected():
     a, b = ctypes.c_uint32(), ctypes.c_uint32()
     rc = lib.smol_hip_input_row_range(ctypes.byref(job), 0xFFFFFFFF, 2, ctypes.byref(a), ctypes.byref(b))
     assert rc == -10001
+    plan.destroy()
+
+
+@pytest.mark.parametrize("rows_per_call", [1, 3, 64])
+def test_rows_a_few_at_a_time_through_the_public_api(rows_per_call):
+    """The reference's own outer loop is one output row per step (smolscale.c:507-546): a context asked for its rows
+    1, 3 or 64 at a time -- pageable and page-locked memory, odd strides, a post-row callback that must see every row
+    once and in ascending order -- equals the oracle's whole image. Small calls take the zero-copy road (the kernel
+    reads and writes the page-locked ring across PCIe), larger ones the DMA road; every kernel family is met: exact
+    halving, magnification, 24-bit source with vertical COPY, two-pass box, gamma-correct, vertical ONE."""
+    for k, spec in enumerate(JOBS):
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+        stride_in = w_in * H.bpp(t_in) + (9 if k & 1 else 0)
+        stride_out = w_out * H.bpp(t_out) + (4 if k & 1 else 0)
+        raw = H.make_input(t_in, w_in, h_in, seed=11 + k, stride=stride_in, pad=16)
+        want = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, srgb, stride_in=stride_in, stride_out=stride_out)
+        for pinned in (False, True):
+            keep = []
+            if pinned:
+                a, b = sm.PinnedArray(raw.size), sm.PinnedArray(h_out * stride_out)
+                keep = [a, b]
+                a.array[:] = raw
+                src, dst = a.array, b.array
+            else:
+                src, dst = raw, np.empty(h_out * stride_out, np.uint8)
+            dst[:] = 0xA5
+            seen = []
+
+            def cb(row, width, user):
+                seen.append(ctypes.addressof(row.contents))
+
+            ctx = sm.SmolScaleCtx(src, t_in, w_in, h_in, stride_in, dst, t_out, w_out, h_out, stride_out, srgb,
+                                  post_row_func=cb if t_out < 8 else None)
+            for y in range(0, h_out, rows_per_call):
+                ctx.batch(y, min(rows_per_call, h_out - y))
+            ctx.destroy()
+            got = H.rows_view(dst, h_out, w_out * H.bpp(t_out), stride_out)
+            ref = H.rows_view(want, h_out, w_out * H.bpp(t_out), stride_out)
+            assert np.array_equal(got, ref), (spec, rows_per_call, pinned)
+            if stride_out != w_out * H.bpp(t_out):
+                gaps = np.lib.stride_tricks.as_strided(dst[w_out * H.bpp(t_out):], (h_out - 1, 4), (stride_out, 1))
+                assert np.all(gaps == 0xA5), (spec, "bytes between rows were touched")
+            if t_out < 8:
+                base = dst.ctypes.data
+                assert seen == [base + y * stride_out for y in range(h_out)], (spec, "callback order")
+            got = ref = gaps = dst = src = None
+            for p in keep:
+                p.free()
+
+
+def test_plan_reserve_allocates_the_box_ring_up_front():
+    """smol_hip_plan_reserve(): the intermediate images of up to four frames in flight exist before the first call."""
+    job = H.plan_job(0, 2600, 1900, 1, 130, 100, 0)
+    plan = sm.HipPlan(job, 0)
+    plan.reserve(4)
+    with pytest.raises(sm.HipError):
+        plan.reserve(5)
+    plan.destroy()
+    plan = sm.HipPlan(H.plan_job(0, 640, 480, 0, 320, 240, 0), 0)
+    plan.reserve(3)                     # nothing to allocate for a job without the two-pass box filter
     plan.destroy()

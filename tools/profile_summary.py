@@ -137,6 +137,11 @@ try:
         if "k_pow2" in k:
             v["ratio_traffic_over_algorithmic"] = v["hbm_bytes_per_launch"] / algo
             latest = dict(v)
+            prof = [r for r in rows if r["run"] == "bench_c2" and "k_pow2" in r["kernel"]]
+            if prof:
+                latest["profiled_launch_us"] = prof[0]["mean_us"]
+                latest["profiled_source"] = ("profiles/%s_kernel_by_grid.csv: mean of the last %d of %d dispatches, rocprofv3 "
+                                             "--kernel-trace of bench.py alone" % (tag, prof[0]["timed"], prof[0]["dispatches"]))
             latest.update({"kernel": k, "algorithmic_bytes_per_launch": algo, "source": "profiles/%s_traffic.json" % tag,
                            "commit": commit, "kernel_source_digest": bench.kernel_source_digest(), "correction": CORRECTION})
             json.dump(latest, open(os.path.join(P, "traffic_latest.json"), "w"), indent=1)
