@@ -6,6 +6,7 @@
 
 #include <stdint.h>
 #include <string.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "smol_hip.h"
@@ -632,6 +633,75 @@ up_blocks (const JobDev &d)
  * and alignment and run 4 waves per workgroup around one LDS copy of the tables. */
 constexpr uint32_t DOWN_LUT_BYTES = (SMOL_LUT_LDS_BYTES + 15) & ~15u;
 
+/* k_lind (mode 3): the gamma-correct flavours of mode 1 -- sRGB-linear, 11-bit channels -- on 24-bit rows (any
+ * alignment) and dword-aligned 32-bit rows. Picks the tile width W <= 128 (in group_rows) so that the span of source
+ * pixels a tile reaches just fills whole conversion rounds of 64 pixels: K rounds hold 64 K pixels, a tile of W columns
+ * reaches at most ((W << h) - 1) * step + 3 of them. */
+constexpr uint32_t LIND_KMAX_HOST = 5;
+
+inline uint64_t
+lind_span (const JobDev &d, uint32_t w)
+{
+    return ((((uint64_t) (w << d.halv_h) - 1u) * d.step_x) >> 32) + 3u;
+}
+
+inline bool
+lind_setup (JobDev &d)
+{
+    if (!d.linear || tune_env ("SMOL_NO_LIND"))
+        return false;
+    if (d.bpp_in == 4 && !d.in_dword_ok)
+        return false;
+    if (d.p16 && (d.bpp_in != 4 || d.bpp_out != 4))
+        return false;
+
+    uint32_t best_w = 0;
+    double best = 0.0;
+    for (uint32_t k = 1; k <= LIND_KMAX_HOST; k++)
+    {
+        /* the widest tile whose span fits k rounds */
+        uint32_t lo = 1, hi = 128;
+        if (lind_span (d, lo) > 64u * k)
+            continue;
+        while (lo < hi)
+        {
+            const uint32_t mid = (lo + hi + 1) / 2;
+            if (lind_span (d, mid) <= 64u * k)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        /* slots used in the conversion rounds x lanes used by the filters, both of which scale the tile's cost */
+        const double eff = ((double) lind_span (d, lo) / (64.0 * k)) * ((double) lo / (lo > 64 ? 128.0 : 64.0));
+        if (eff > best + 1e-9)
+        {
+            best = eff;
+            best_w = lo;
+        }
+    }
+    if (const char *e = tune_env ("SMOL_LIND_W"))
+        best_w = (uint32_t) atoi (e);
+    if (best_w < 16 || best_w > 128 || lind_span (d, best_w) > 64u * LIND_KMAX_HOST)
+        return false;
+
+    uint32_t th = d.halv_v ? 4u : 8u;           /* <= 128 vertical samples per tile */
+    if (const char *e = tune_env ("SMOL_DOWN_ROWS"))
+        th = (uint32_t) atoi (e);
+    if (th > (128u >> d.halv_v))
+        th = 128u >> d.halv_v;
+    if (th < 1)
+        th = 1;
+    if (tune_env ("SMOL_LIND_DEBUG"))
+        printf ("lind: %ux%u -> %ux%u bpp %u halv %u W %u span %u eff %.3f\n", d.w_in, d.h_in, d.w_out, d.h_out, d.bpp_in, d.halv_h, best_w, (unsigned) lind_span (d, best_w), best);
+    d.group_rows = (uint16_t) best_w;
+    d.span_px = (uint32_t) lind_span (d, best_w);
+    d.tile_rows = (uint16_t) th;
+    d.tile_cpl = 2;
+    d.up_wide = 1;
+    d.down_mode = 3;
+    return true;
+}
+
 inline bool
 down_setup (JobDev &d)
 {
@@ -652,6 +722,8 @@ down_setup (JobDev &d)
         mode = 1;                               /* channels of at most 11 bits: packed taps */
     if (mode && tune_env ("SMOL_NO_DOWN_GEN"))
         return false;
+    if ((mode == 1 || (mode == 2 && d.linear)) && lind_setup (d))
+        return true;                            /* mode 3: k_lind (smol_kernel_lind.hip.h) */
 
     /* one sample per column and a wide enough image: 4 columns per lane (premul16 fast path). The 11-bit table-driven
      * flavour has the same variant compiled in (SMOL_DOWNG_CPL4 in tuning builds) but keeps one column: with four its
@@ -690,13 +762,15 @@ down_setup (JobDev &d)
 inline uint32_t
 down_blocks (const JobDev &d)
 {
-    const uint32_t tw = 64u * d.tile_cpl;
+    const uint32_t tw = d.down_mode == 3 ? d.group_rows : 64u * d.tile_cpl;
     return ((d.w_out + tw - 1u) / tw) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
 }
 
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
+    if (d.down_mode == 3)                                   /* the tables + a row buffer per wave */
+        return DOWN_LUT_BYTES + 4u * (64u * LIND_KMAX_HOST * (d.p16 ? 16u : 8u)) + 16u;
     const uint32_t pitch = (d.span_px * (d.down_mode == 2 ? 16u : 8u) + 15u) & ~15u;
     if (d.down_mode)
         return DOWN_LUT_BYTES + 4u * 2u * pitch + 16u;      /* the tables + two row buffers per wave */

@@ -53,6 +53,29 @@ launch_downg_m (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t l
     }
 }
 
+/* k_lind: one entry point per (horizontal halvings, input kind: 0 = 32-bit rows, 1 = 24-bit rows, 2 = premul16 + linear) */
+template <int HX, int IN>
+void
+launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN>), grid, dim3 (256), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN>), grid, dim3 (256), lds, s, rep);
+}
+
+template <int IN>
+void
+launch_lind (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (rep.halv_h)
+    {
+        case 0:  launch_lind_k<0, IN> (jobs_dev, rep, grid, lds, s); break;
+        case 1:  launch_lind_k<1, IN> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_lind_k<2, IN> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
 /* k_up: one entry point per (input alignment kind, output kind) */
 template <int INK, int OUT>
 void
@@ -93,7 +116,16 @@ down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStr
     if (rep.down_mode)
     {
         grid.x = (grid.x + 3) / 4;
-        if (rep.down_mode == 2)
+        if (rep.down_mode == 3)
+        {
+            if (rep.p16)
+                launch_lind<2> (jobs_dev, rep, grid, lds, s);
+            else if (rep.bpp_in == 3)
+                launch_lind<1> (jobs_dev, rep, grid, lds, s);
+            else
+                launch_lind<0> (jobs_dev, rep, grid, lds, s);
+        }
+        else if (rep.down_mode == 2)
             launch_downg_m<smolhip::DOWN_GEN32> (jobs_dev, rep, grid, lds, s);
         else
             launch_downg_m<smolhip::DOWN_GEN16> (jobs_dev, rep, grid, lds, s);

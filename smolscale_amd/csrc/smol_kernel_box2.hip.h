@@ -421,7 +421,7 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     else
         boxh_body<WIDE, 1> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
 #else
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = smol_wave_index ();       /* a SCALAR: everything derived from the tile index stays wave-uniform */
     /* the workgroup's 4 waves: 4 column tiles of one row group, or 4 row groups of one column tile (box2_setup) */
     const uint32_t tx = J.box2_ygroup ? blockIdx.x : blockIdx.x * 4u + wave;
     const uint32_t tr = J.box2_ygroup ? blockIdx.y * 4u + wave : blockIdx.y;
@@ -456,9 +456,9 @@ __device__ __forceinline__ void boxv_entry (const JobDev &J, uint8_t *lds)
         __syncthreads ();
     }
     if (J.box2_vlpc == 8)
-        boxv_body<WIDE, 8> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6));
+        boxv_body<WIDE, 8> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + smol_wave_index ());
     else
-        boxv_body<WIDE, 1> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6));
+        boxv_body<WIDE, 1> (J, lds, threadIdx.x & 63u, blockIdx.x * 4u + smol_wave_index ());
 #endif
 }
 

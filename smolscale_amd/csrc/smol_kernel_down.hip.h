@@ -25,6 +25,8 @@
 
 #pragma once
 
+#include "smol_kernel_lind.hip.h"
+
 namespace smolhip {
 
 constexpr int DOWN_NL = 3;          /* 16-byte loads per lane per source row, at most (span <= 768 pixels) */
@@ -513,7 +515,7 @@ __device__ __forceinline__ void down_gen_entry (const JobDev &J, uint8_t *lds)
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
     down_body<HX, CPL, MODE> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = smol_wave_index ();       /* a SCALAR: everything derived from the tile index stays wave-uniform */
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     const uint32_t pitch = (J.span_px * (MODE == DOWN_GEN32 ? 16u : 8u) + 15u) & ~15u;
@@ -526,6 +528,23 @@ __device__ __forceinline__ void down_gen_entry (const JobDev &J, uint8_t *lds)
 /* host emulation: one entry that switches at run time */
 __global__ void k_down_one (const JobDev J)
 {
+    if (J.down_mode == 3)
+    {
+        const int in = J.p16 ? 2 : J.bpp_in == 3 ? 1 : 0;
+        switch (J.halv_h * 3 + in)
+        {
+            case 0: lind_entry<0, false, false> (J, smol_dyn_lds); break;
+            case 1: lind_entry<0, true, false> (J, smol_dyn_lds); break;
+            case 2: lind_entry<0, false, true> (J, smol_dyn_lds); break;
+            case 3: lind_entry<1, false, false> (J, smol_dyn_lds); break;
+            case 4: lind_entry<1, true, false> (J, smol_dyn_lds); break;
+            case 5: lind_entry<1, false, true> (J, smol_dyn_lds); break;
+            case 6: lind_entry<2, false, false> (J, smol_dyn_lds); break;
+            case 7: lind_entry<2, true, false> (J, smol_dyn_lds); break;
+            default: lind_entry<2, false, true> (J, smol_dyn_lds); break;
+        }
+        return;
+    }
     if (J.down_mode == DOWN_GEN16 || J.down_mode == DOWN_GEN32)
     {
         const bool w32 = J.down_mode == DOWN_GEN32;

@@ -1,0 +1,380 @@
+/* smol_kernel_lind.hip.h -- k_lind: gamma-correct (sRGB-linear, 11-bit channels) bilinear MINIFICATION on both axes,
+ * 0-2 halvings each: the with_srgb photo / PNG downscale (unpack smolscale-generic.c:481-535, 588-614; horizontal
+ * :1290-1425; vertical :1648-2007; pack :922-935, 1010-1023, 1096-1134). Round 4's successor of k_downg<*, DOWN_GEN16>
+ * (smol_kernel_down.hip.h), which stays for 32-bit rows that are not dword aligned.
+ *
+ * What the old kernel's counters said (profiles/r03final_sq_srgbhalf.txt): 102 vector lane-operations per SOURCE pixel
+ * where the arithmetic needs about 50, and 0.59 scalar instructions per vector one. The lanes were there, idle: a tile
+ * of 64 output columns spans 97 source pixels at ratio 1.5, converted in three rounds of 64 (51 % of the slots used),
+ * every round and every store behind its own exec-mask branch. Here:
+ *
+ *   tile    W output columns x tile_rows rows per wave, W <= 128 chosen on the HOST (lind_setup) so that the tile's span
+ *           of source pixels just fills K whole rounds of 64 (ratio 1.5: W = 126, span 191 of 192 slots). A lane owns
+ *           columns x0 + lane and x0 + 64 + lane: a wave's stores and LDS reads are runs of neighbouring addresses.
+ *   stage   per source row and round: one raw pixel per lane (index clamped into the span, so that every slot holds a
+ *           real pixel and nothing needs a mask), converted ONCE (WideUnpack, flavour fixed per row: opaque rows take
+ *           the fused table) and written to the wave's single LDS row buffer as four 16-bit channels. Row r + 1 is in
+ *           flight in registers while row r is filtered. A 24-bit pixel is ONE dword load at its own byte address
+ *           (global loads need no alignment on gfx950; the row's last pixel is read one byte early and shifted, so
+ *           that nothing past the row is touched).
+ *   H, V    packed 16-bit taps (lerp11_pk), the vertical schedule read back with v_readlane, as in k_down.
+ *   pack    WidePack, flavour fixed per output row (opaque rows skip the inverse-alpha look-up).
+ *
+ * No branch depends on a lane: the only masks are on the stores of a tile's partial last columns. */
+
+#pragma once
+
+namespace smolhip {
+
+constexpr int LIND_KMAX = 5;            /* conversion rounds per source row: spans of at most 320 pixels */
+typedef uint32_t u32a1 __attribute__ ((aligned (1)));
+
+/* one tap on a 32-bit channel of at most 19 bits: (p * F + q * (256 - F)) >> 8, below 2^28 before the shift */
+__device__ __forceinline__ uint32_t tap32 (uint32_t p, uint32_t q, uint32_t F, uint32_t G)
+{
+    return ((uint32_t) __umul24 (p, F) + (uint32_t) __umul24 (q, G)) >> 8;
+}
+
+/* W32: premul16 + sRGB-linear (unassociated in AND out with with_srgb: 19-bit channels, :627-660 and :1135-1158):
+ * four 32-bit channels per staged pixel, taps as 24-bit multiplies (p * F + q * (256 - F)) >> 8 */
+template <int HX, bool IN24, bool W32>
+__device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
+                                           const uint32_t lane, const uint32_t tile)
+{
+    static_assert (!(IN24 && W32), "premul16 means 32-bit pixels on both sides");
+    constexpr uint32_t NSX = 1u << HX;
+    constexpr int CPL = 2;
+    constexpr uint32_t PXB = W32 ? 16u : 8u;                        /* LDS bytes per staged pixel */
+    constexpr int NCH = W32 ? 4 : 2;                                /* registers per filtered pixel */
+    const uint32_t W = J.group_rows;                                /* output columns per tile (host) */
+
+    const uint32_t tiles_x = (J.w_out + W - 1) / W;
+    const uint32_t tx = tile % tiles_x;
+    const uint32_t ty = tile / tiles_x;
+    const uint32_t yrel0 = ty * J.tile_rows;
+
+    if (yrel0 >= J.n_rows)
+        return;
+
+    const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
+    const uint32_t x0 = tx * W;
+    const uint32_t xn = (x0 + W < J.w_out) ? x0 + W : J.w_out;
+
+    /* ---- horizontal samples of this lane's two columns ---------------------------- */
+    uint32_t xc [CPL];
+    bool ok [CPL];
+    uint32_t tap_ofs [CPL][NSX], tap_f [CPL][NSX];
+    Lerp11W tap_w [CPL][NSX];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+    {
+        xc [c] = x0 + 64u * c + lane;
+        ok [c] = xc [c] < xn;
+        const uint32_t x = ok [c] ? xc [c] : xn - 1;
+        uint64_t pos = J.frac0_x + (uint64_t) (x << HX) * J.step_x;
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+        {
+            bilin_tap (pos, J.w_in, tap_ofs [c][s], tap_f [c][s]);
+            tap_w [c][s] = lerp11_weights (tap_f [c][s]);
+            pos += J.step_x;
+        }
+    }
+    const uint32_t sx0 = smol_readlane (tap_ofs [0][0], 0);         /* first source pixel of the tile */
+    uint32_t sx1, f_unused;
+    bilin_tap (J.frac0_x + (uint64_t) ((xn << HX) - 1) * J.step_x, J.w_in, sx1, f_unused);
+    sx1 += 1;                                                       /* last source pixel of the tile  */
+    const uint32_t npx = sx1 - sx0 + 1;                             /* pixels per staged row: <= 64 * LIND_KMAX (host) */
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+            tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * PXB;          /* byte offset in the LDS row */
+
+    /* ---- vertical schedule: sample k of the tile in lane k & 63 of sched [k >> 6] --- */
+    const uint32_t hv = J.halv_v;
+    const uint32_t nsy = 1u << hv;
+    const uint32_t jy0 = (J.first_row + yrel0) << hv;
+    const uint32_t n_samples = (yrel1 - yrel0) << hv;               /* <= 128 (lind_setup) */
+    uint32_t sched [2];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++)
+    {
+        uint32_t k = q * 64u + lane;
+        if (k >= n_samples)
+            k = n_samples - 1;
+        uint32_t o, f;
+        bilin_tap (J.frac0_y + (uint64_t) (jy0 + k) * J.step_y, J.h_in, o, f);
+        sched [q] = o | (f << 16);
+    }
+    uint32_t e = smol_readlane (sched [0], 0);
+    uint32_t oy = e & 0xffffu, Fy = e >> 16;
+    const uint32_t row_first = oy;
+    const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
+    const uint32_t row_last = (e_last & 0xffffu) + 1;
+
+    /* ---- staging -------------------------------------------------------------------- */
+    const LutLds lut (lut_lds);
+    const int uk = wide_unpack_kind (J), pk = wide_pack_kind (J);
+    const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;   /* row being loaded */
+    /* slot k * 64 + lane holds pixel min (slot, npx - 1) of the span; px_off: its byte offset in a source row */
+    uint32_t px_off [LIND_KMAX], px_sh [IN24 ? LIND_KMAX : 1];
+#pragma unroll
+    for (int k = 0; k < LIND_KMAX; k++)
+    {
+        const uint32_t i = (uint32_t) k * 64u + lane;
+        const uint32_t x = sx0 + (i < npx ? i : npx - 1);
+        if (IN24)
+        {
+            /* the dword at the row's last pixel would end one byte past the row: read it one byte early */
+            px_sh [k] = x == J.w_in - 1u ? 1u : 0u;
+            px_off [k] = x * 3u - px_sh [k];
+        }
+        else
+            px_off [k] = x * 4u;
+    }
+    uint32_t rawpx [LIND_KMAX];                                     /* the pixels of the row in flight */
+
+    auto load_row = [&] ()
+    {
+#pragma unroll
+        for (int k = 0; k < LIND_KMAX; k++)
+            if ((uint32_t) k * 64u < npx)                           /* wave-uniform */
+            {
+                if (IN24)
+                {
+#ifdef SMOL_KERNEL_EMU
+                    __builtin_memcpy (&rawpx [k], srow + px_off [k], 4);
+#else
+                    rawpx [k] = *reinterpret_cast<const SMOL_AS_GLOBAL u32a1 *> (srow + px_off [k]);
+#endif
+                }
+                else
+                    rawpx [k] = *reinterpret_cast<const SMOL_AS_GLOBAL uint32_t *> (srow + px_off [k]);
+            }
+        srow += J.src_stride;
+    };
+
+    auto convert_row = [&] ()
+    {
+        if (IN24)
+        {
+#pragma unroll
+            for (int k = 0; k < LIND_KMAX; k++)
+                if ((uint32_t) k * 64u < npx)
+                    rawpx [k] = __builtin_amdgcn_alignbyte (0u, rawpx [k], px_sh [k]);
+        }
+        auto conv = [&] (const auto &un)
+        {
+#pragma unroll
+            for (int k = 0; k < LIND_KMAX; k++)
+                if ((uint32_t) k * 64u < npx)
+                {
+                    uint32_t ch [4];
+                    un (rawpx [k], ch);
+                    if (W32)
+                        *reinterpret_cast<u32x4 *> (buf + ((uint32_t) k * 64u + lane) * 16u) = u32x4 { ch [0], ch [1], ch [2], ch [3] };
+                    else
+                        *reinterpret_cast<u32x2a8 *> (buf + ((uint32_t) k * 64u + lane) * 8u)
+                            = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
+                }
+        };
+        if (W32)
+            conv (WideUnpack<WU_P16L> (J, lut));
+        else if (IN24 || uk == WU_LIN_O)
+            conv (WideUnpack<WU_LIN_O> (J, lut));
+        else
+        {
+            uint32_t all = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < LIND_KMAX; k++)
+                if ((uint32_t) k * 64u < npx)
+                    all &= rawpx [k];
+            if (wide_batch_opaque (J, all))
+                conv (WideUnpack<WU_LIN_O> (J, lut));
+            else if (uk == WU_LIN_P)
+                conv (WideUnpack<WU_LIN_P> (J, lut));
+            else
+                conv (WideUnpack<WU_LIN_U> (J, lut));
+        }
+    };
+
+    /* ---- the row loop ----------------------------------------------------------------- */
+    gbyte *out_row = gptr (J.dst) + (size_t) yrel0 * J.dst_stride;
+    uint32_t ks = 0, s_y = 0;
+    /* previous row's horizontal result and the vertical sums: two packed channel pairs (R | G << 16, B | A << 16),
+     * or four 32-bit channels (W32) */
+    uint32_t hp [CPL][NCH], acc [CPL][NCH];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int i = 0; i < NCH; i++)
+            hp [c][i] = acc [c][i] = 0;
+
+    load_row ();
+
+    for (uint32_t r = row_first; r <= row_last; r++)
+    {
+        smol_wave_sync ();                              /* row r - 1 has been read (a real barrier only in the host emulation) */
+        convert_row ();                                 /* waits for row r's loads */
+        smol_wave_sync ();
+        if (r < row_last)
+            load_row ();                                /* row r + 1 flies while row r is filtered */
+
+        /* ---- H ---------------------------------------------------------------------------------- */
+        uint32_t h [CPL][NCH];
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+        {
+            uint32_t hs [NCH];
+#pragma unroll
+            for (uint32_t s = 0; s < NSX; s++)
+            {
+                if (W32)
+                {
+                    const u32x4 pp = *reinterpret_cast<const u32x4 *> (buf + tap_ofs [c][s]);
+                    const u32x4 qq = *reinterpret_cast<const u32x4 *> (buf + tap_ofs [c][s] + 16);
+                    const uint32_t F = tap_f [c][s], G = 256u - F;
+                    const uint32_t t [4] = { tap32 (pp.x, qq.x, F, G), tap32 (pp.y, qq.y, F, G), tap32 (pp.z, qq.z, F, G), tap32 (pp.w, qq.w, F, G) };
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        hs [i] = s ? hs [i] + t [i] : t [i];
+                }
+                else
+                {
+                    /* both channel pairs stay packed; the sums of 2^HX taps stay below 2^13 per lane */
+                    const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (buf + tap_ofs [c][s]);
+                    const uint32_t t01 = lerp11_pk (pq.x, pq.z, tap_w [c][s]);
+                    const uint32_t t23 = lerp11_pk (pq.y, pq.w, tap_w [c][s]);
+                    hs [0] = s ? hs [0] + t01 : t01;
+                    hs [1] = s ? hs [1] + t23 : t23;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+                h [c][i] = !HX ? hs [i] : W32 ? hs [i] >> HX : (hs [i] >> HX) & (0xffffu >> HX) * 0x00010001u;
+        }
+
+        /* ---- V: every sample whose bottom row is r ---------------------------------------------- */
+        while (ks < n_samples && oy + 1u == r)
+        {
+            const Lerp11W wy = lerp11_weights (Fy);
+            const uint32_t Gy = 256u - Fy;
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+#pragma unroll
+                for (int i = 0; i < NCH; i++)
+                {
+                    const uint32_t t = W32 ? tap32 (hp [c][i], h [c][i], Fy, Gy) : lerp11_pk (hp [c][i], h [c][i], wy);
+                    acc [c][i] = s_y ? acc [c][i] + t : t;
+                }
+            s_y++;
+            ks++;
+            if (s_y == nsy)
+            {
+                uint32_t v [CPL][4], all_a = 255u;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                {
+                    if (W32)
+                    {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            v [c][i] = acc [c][i] >> hv;
+                    }
+                    else
+                    {
+                        v [c][0] = (acc [c][0] & 0xffffu) >> hv; v [c][1] = acc [c][0] >> (16u + hv);
+                        v [c][2] = (acc [c][1] & 0xffffu) >> hv; v [c][3] = acc [c][1] >> (16u + hv);
+                        all_a &= v [c][3] & 0xffu;      /* (columns past the tile's end repeat its last one) */
+                    }
+                }
+                auto put = [&] (const auto &pack)
+                {
+#pragma unroll
+                    for (int c = 0; c < CPL; c++)
+                    {
+                        const uint32_t w = pack (v [c]);
+                        if (ok [c])
+                        {
+                            if (J.bpp_out == 4 && J.out_dword_ok)
+                                __builtin_nontemporal_store (w, reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4));
+                            else
+                                wide_store_word (J, out_row, xc [c], w);
+                        }
+                    }
+                };
+                /* once per output row and wave; all-opaque rows skip the inverse-alpha look-up and multiplies */
+                if (W32)
+                    put (WidePack<WP_P16L> (J, lut));
+                else if ((pk == WP_LIN_P || pk == WP_LIN_U) && smol_wave_all_opaque (all_a))
+                    put (WidePack<WP_LIN_O> (J, lut));
+                else if (pk == WP_LIN_P)
+                    put (WidePack<WP_LIN_P> (J, lut));
+                else if (pk == WP_LIN_U)
+                    put (WidePack<WP_LIN_U> (J, lut));
+                else
+                    put (WidePack<WP_LIN_Q> (J, lut));
+                s_y = 0;
+                out_row += J.dst_stride;
+            }
+            if (ks < n_samples)
+            {
+                e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
+                oy = e & 0xffffu;
+                Fy = e >> 16;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+                hp [c][i] = h [c][i];
+    }
+}
+
+/* LDS of one wave: the row buffer */
+__device__ __forceinline__ uint32_t lind_wave_lds (bool w32)
+{
+    return 64u * LIND_KMAX * (w32 ? 16u : 8u);
+}
+
+/* 4 waves per workgroup share one LDS copy of the tables, each wave works on its own tile in its own LDS region */
+template <int HX, bool IN24, bool W32>
+__device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    static uint8_t lut_lds [LUT_LDS_BYTES];
+    lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
+    lind_body<HX, IN24, W32> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+#else
+    /* (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same on every lane of a wave, and
+     * without it everything derived from the tile index -- every loop bound, every "is this round needed" test --
+     * is computed per lane and branched on with exec masks) */
+    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
+    lut_fill_lds (lds, threadIdx.x, 256);
+    __syncthreads ();
+    lind_body<HX, IN24, W32> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * lind_wave_lds (W32), lds,
+                         threadIdx.x & 63u, blockIdx.x * 4u + wave);
+#endif
+}
+
+#ifndef SMOL_KERNEL_EMU
+/* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels) */
+template <int HX, int IN>
+__global__ void __launch_bounds__ (256)
+k_lind_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = load_job (jobs, blockIdx.y);
+    lind_entry<HX, IN == 1, IN == 2> (J, smol_dyn_lds);
+}
+
+template <int HX, int IN>
+__global__ void __launch_bounds__ (256)
+k_lind_one (const JobDev J)
+{
+    lind_entry<HX, IN == 1, IN == 2> (J, smol_dyn_lds);
+}
+#endif
+
+} /* namespace smolhip */

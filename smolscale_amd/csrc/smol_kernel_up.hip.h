@@ -730,7 +730,7 @@ __device__ __forceinline__ void upg_entry (const JobDev &J, uint8_t *lds)
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
     upg_body<W32> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = smol_wave_index ();       /* a SCALAR: everything derived from the tile index stays wave-uniform */
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     const uint32_t region = (UPG_NSRC * J.span_px * (W32 ? 16u : 8u) + 15u) & ~15u;
