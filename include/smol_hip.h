@@ -95,6 +95,12 @@ void smol_hip_box_span (uint64_t step, uint32_t dim_in, uint32_t k,
 
 const char *smol_hip_strerror (int err);
 
+/* The kernel family the dispatcher gives these rows to (it depends on the job, on the alignment of the pointers
+ * and strides and on the row range): "k_pow2_batch", "k_tile_batch", "k_lind_batch", ... For tools that count
+ * which kernels a workload exercises; nothing is launched. */
+const char *smol_hip_kernel_name (const SmolHipJob *job, const void *src, uint32_t rowstride_in,
+                                  const void *dst, uint32_t rowstride_out, uint32_t first_row, uint32_t n_rows);
+
 /* ---- device side --------------------------------------------------------- */
 
 int smol_hip_device_count (void);

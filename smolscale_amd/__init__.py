@@ -91,6 +91,7 @@ EXPORTS = {
     "smol_hip_bilinear_sample": (None, [_u64, _u64, _u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "smol_hip_box_span": (None, [_u64, _u32, _u32] + [ctypes.POINTER(_u32)] * 4),
     "smol_hip_strerror": (ctypes.c_char_p, [_int]),
+    "smol_hip_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(SmolHipJob), _vp, _u32, _vp, _u32, _u32, _u32]),
     "smol_hip_device_count": (_int, []),
     "smol_hip_plan_create": (_int, [ctypes.POINTER(SmolHipJob), _int, ctypes.POINTER(_vp)]),
     "smol_hip_plan_destroy": (None, [_vp]),
@@ -171,6 +172,19 @@ def plan_job(pixel_type_in, width_in, height_in, pixel_type_out, width_out, heig
                                   width_out, height_out, int(with_srgb), ctypes.byref(job)),
           "smol_hip_plan_job")
     return job
+
+
+def kernel_name(job, src_ptr=256, rowstride_in=None, dst_ptr=256, rowstride_out=None, first_row=0, n_rows=None):
+    """smol_hip_kernel_name(): the kernel family the dispatcher picks for these rows (default: aligned, packed rows,
+    the whole image)."""
+    if rowstride_in is None:
+        rowstride_in = job.width_in * bytes_per_pixel(job.pixel_type_in)
+    if rowstride_out is None:
+        rowstride_out = job.width_out * bytes_per_pixel(job.pixel_type_out)
+    if n_rows is None:
+        n_rows = job.height_out - first_row
+    return lib().smol_hip_kernel_name(ctypes.byref(job), src_ptr, rowstride_in, dst_ptr, rowstride_out,
+                                      first_row, n_rows).decode()
 
 
 def input_row_range(job, first_row, n_rows):

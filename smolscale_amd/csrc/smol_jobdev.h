@@ -805,6 +805,8 @@ box_span_host (uint64_t step, uint32_t dim_in, uint32_t k, uint32_t &o0, uint32_
 #endif
 inline uint32_t boxh_rows (const JobDev &d) { return d.wide ? SMOL_BOXH_ROWS_WIDE : SMOL_BOXH_ROWS; }
 
+inline void boxh_geometry (JobDev &d, uint32_t lpc, uint64_t span_px, uint32_t chunks);
+
 inline bool
 box2_setup (JobDev &d)
 {
@@ -836,8 +838,19 @@ box2_setup (JobDev &d)
     if (chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
         return false;                           /* four waves' row buffers must fit the LDS (nothing of d touched yet) */
 
-    d.tile_lpc = (uint8_t) lpc;
+    boxh_geometry (d, lpc, span_px, chunks);
     d.box2_vlpc = (d.step_y > (lpc8_min << 16)) ? 8 : 1;
+    d.tmp_row0 = y0;
+    d.tmp_row1 = y1;
+    d.box2 = 1;
+    return true;
+}
+
+/* what k_boxh needs to know about its tiles (box2_setup, twopass_setup) */
+inline void
+boxh_geometry (JobDev &d, uint32_t lpc, uint64_t span_px, uint32_t chunks)
+{
+    d.tile_lpc = (uint8_t) lpc;
     {
         /* pass-1 workgroup shape: 4 column tiles side by side (whole rows, contiguous: 4000x3000 -> 200x150
          * 122 us against 128) unless that leaves wave slots empty -- 7 column tiles (4096 -> 448): one below the
@@ -847,14 +860,10 @@ box2_setup (JobDev &d)
         if (tune_env ("SMOL_BOXH_XGROUP")) d.box2_ygroup = 0;
         if (tune_env ("SMOL_BOXH_YGROUP")) d.box2_ygroup = 1;
     }
-    d.tmp_row0 = y0;
-    d.tmp_row1 = y1;
     d.span_px = (uint32_t) span_px;
     d.span_chunks = chunks;
     d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / chunks) + 1;
     d.box_nmax = ((uint32_t) (d.step_x >> 16) + 1 + lpc - 1) / lpc + 1;   /* most interior pixels a lane walks */
-    d.box2 = 1;
-    return true;
 }
 
 inline bool
@@ -870,9 +879,14 @@ box2_tmp_bytes (const JobDev &d)
 }
 
 /* tiles (= waves) of each pass; a workgroup runs 4 of them */
+inline bool twopass_lin_h (const JobDev &d) { return d.box2 == 2 && d.filter_h != F_BOX; }
+inline bool twopass_lin_v (const JobDev &d) { return d.box2 == 2 && d.filter_v != F_BOX; }
+
 inline uint32_t
 box2_h_tiles (const JobDev &d)
 {
+    if (twopass_lin_h (d))
+        return ((d.w_out + d.group_rows - 1u) / d.group_rows) * ((d.tmp_row1 - d.tmp_row0 + d.tile_rows) / d.tile_rows);
     const uint32_t cols = 64u / d.tile_lpc;
     return ((d.w_out + cols - 1u) / cols) * ((d.tmp_row1 - d.tmp_row0 + boxh_rows (d)) / boxh_rows (d));
 }
@@ -883,6 +897,8 @@ box2_h_tiles (const JobDev &d)
 inline uint32_t
 box2_h_grid (const JobDev &d)
 {
+    if (twopass_lin_h (d))      /* k_linh: x = column tiles, y = groups of 4 row tiles (one per wave) */
+        return ((d.w_out + d.group_rows - 1u) / d.group_rows) | ((((d.tmp_row1 - d.tmp_row0 + d.tile_rows) / d.tile_rows + 3u) / 4u) << 16);
     const uint32_t cols = 64u / d.tile_lpc;
     uint32_t gx = (d.w_out + cols - 1u) / cols;
     uint32_t gy = (d.tmp_row1 - d.tmp_row0 + boxh_rows (d)) / boxh_rows (d);
@@ -904,6 +920,8 @@ box2_grid_max (uint32_t a, uint32_t b)
 inline uint32_t
 box2_v_tiles (const JobDev &d)
 {
+    if (twopass_lin_v (d))      /* k_linv: 128 columns x tile_rows output rows per wave */
+        return ((d.w_out + 127u) / 128u) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
     const uint32_t cols = 64u / d.box2_vlpc;
     return ((d.w_out + cols - 1u) / cols) * d.n_rows;
 }
@@ -911,7 +929,114 @@ box2_v_tiles (const JobDev &d)
 inline uint32_t
 box2_h_lds_bytes (const JobDev &d)
 {
+    if (twopass_lin_h (d))
+        return DOWN_LUT_BYTES + 4u * (64u * LIND_KMAX_HOST * 8u) + 16u;
     return (d.wide ? DOWN_LUT_BYTES_FWD : 0u) + 4u * d.span_chunks * 16u + 32u;
+}
+
+/* ---- the generic two-pass road of the 128bpp class (box2 == 2) ------------------------------------------------
+ * Gamma-correct jobs whose axes differ -- one minified and one magnified, a COPY axis, bilinear on one axis and box
+ * on the other -- used to end in the correctness backstops (k_wtile, k_general<true>: 5-14 % of the roofline,
+ * profiles/r04_backstop_rows.txt). No proportional resize lands there, independently scaled axes do. They now take
+ * the intermediate image of the two-pass box filter with one kernel per axis:
+ *   pass 1   horizontal: k_boxh (BOX) or k_linh = the staging + horizontal half of k_lind (BILINEAR up or down, COPY)
+ *   pass 2   vertical:   k_boxv (BOX) or k_linv = the vertical + packing half of k_lind (BILINEAR up or down, COPY)
+ * A horizontal COPY axis is a bilinear axis at step 1 (every weight is 256 or, at the last sample, 0: the tap returns
+ * the pixel itself); a vertical one hands row R of the intermediate image to output row R. sRGB-linear with 8-bit alpha only (11-bit channels, 8 bytes per intermediate pixel); premul16 jobs with
+ * mixed axes stay where they were. */
+inline void
+twopass_v_rows (const JobDev &d, uint32_t &y0, uint32_t &y1)
+{
+    if (d.filter_v == F_BOX)
+    {
+        uint32_t t;
+        box_span_host (d.step_y, d.h_in, d.first_row, y0, t);
+        box_span_host (d.step_y, d.h_in, d.first_row + d.n_rows - 1, t, y1);
+        return;
+    }
+    if (d.filter_v == F_COPY)
+    {
+        y0 = d.first_row;
+        y1 = d.first_row + d.n_rows - 1u;
+        return;
+    }
+    /* bilinear: sample j reads rows o (j) and o (j) + 1 */
+    auto ofs = [&] (uint64_t j) {
+        const uint64_t o = (d.frac0_y + j * d.step_y) >> 32;
+        return (uint32_t) (o >= d.h_in - 1u ? d.h_in - 2u : o);
+    };
+    y0 = ofs ((uint64_t) d.first_row << d.halv_v);
+    y1 = ofs ((((uint64_t) d.first_row + d.n_rows) << d.halv_v) - 1u) + 1u;
+}
+
+inline bool
+twopass_setup (JobDev &d)
+{
+    if (!d.wide || !d.linear || d.p16 || d.n_rows == 0 || tune_env ("SMOL_NO_TWOPASS"))
+        return false;
+    if (d.bpp_in == 4 && !d.in_dword_ok)
+        return false;
+    const auto usable = [] (uint8_t f) { return f == F_BILINEAR || f == F_COPY || f == F_BOX; };
+    if (!usable (d.filter_h) || !usable (d.filter_v) || (d.filter_h == F_BOX && d.filter_v == F_BOX))
+        return false;
+    if ((d.filter_h != F_BOX && d.w_in < 2) || (d.filter_v == F_BILINEAR && d.h_in < 2))
+        return false;
+
+    JobDev t = d;
+    if (t.filter_h == F_COPY) { t.frac0_x = 0; t.step_x = (uint64_t) 1 << 32; t.halv_h = 0; }
+    if (t.filter_v == F_COPY) { t.frac0_y = 0; t.step_y = (uint64_t) 1 << 32; t.halv_v = 0; }
+
+    if (t.filter_h == F_BOX)
+    {
+        /* k_boxh's geometry, as box2_setup makes it */
+        const uint32_t lpc = (t.step_x > ((uint64_t) 48 << 16)) ? 8u : 1u;
+        uint64_t span_px = (((64u / lpc) * t.step_x) >> 16) + 2;
+        if (span_px > t.w_in)
+            span_px = t.w_in;
+        const uint32_t chunks = ((uint32_t) span_px * t.bpp_in + 15 + 8 + 15) / 16;
+        if (chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
+            return false;
+        boxh_geometry (t, lpc, span_px, chunks);
+    }
+    else
+    {
+        /* k_linh: the widest tile whose span of source pixels fits the conversion rounds (lind_setup's search) */
+        uint32_t best_w = 0;
+        double best = 0.0;
+        for (uint32_t k = 1; k <= LIND_KMAX_HOST; k++)
+        {
+            uint32_t lo = 1, hi = 128;
+            if (lind_span (t, lo) > 64u * k)
+                continue;
+            while (lo < hi)
+            {
+                const uint32_t mid = (lo + hi + 1) / 2;
+                if (lind_span (t, mid) <= 64u * k)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            const double eff = ((double) lind_span (t, lo) / (64.0 * k)) * ((double) lo / (lo > 64 ? 128.0 : 64.0));
+            /* (a magnifying axis converts few pixels per tile: the lanes the filters keep busy decide) */
+            const double score = t.step_x < ((uint64_t) 1 << 32) ? (double) lo : eff;
+            if (score > best + 1e-9)
+            {
+                best = score;
+                best_w = lo;
+            }
+        }
+        if (best_w < 16)
+            return false;
+        t.group_rows = (uint16_t) best_w;
+        t.span_px = (uint32_t) lind_span (t, best_w);
+    }
+    t.box2_vlpc = (t.filter_v == F_BOX && t.step_y > ((uint64_t) 48 << 16)) ? 8 : 1;
+    t.tile_rows = 8;                            /* rows per tile of both k_lin* passes: at most 8 << 2 vertical samples */
+    t.tile_cpl = 2;
+    twopass_v_rows (t, t.tmp_row0, t.tmp_row1);
+    t.box2 = 2;
+    d = t;
+    return true;
 }
 
 /* k_hspan (smol_kernel_hspan.hip.h): vertical COPY, horizontal bilinear at (nearly) the power-of-two
@@ -968,6 +1093,8 @@ classify (JobDev &d)
         return KC_DOWN;
     if (box2_setup (d))
         return KC_BOX2;
+    if (twopass_setup (d))
+        return KC_BOX2;
     if (hspan_setup (d))
         return KC_HSPAN;
     if (tile_ok (d))
@@ -988,9 +1115,11 @@ kclass_name (KClass k, const JobDev &d)
     {
         case KC_POW2: return "k_pow2_batch";
         case KC_POW2X: return "k_pow2x_batch";
-        case KC_UP: return "k_up_batch";
-        case KC_DOWN: return "k_down_batch";
-        case KC_BOX2: return "k_boxh_batch + k_boxv_batch";
+        case KC_UP: return d.up_wide >= 2 ? "k_upg_batch" : "k_up_batch";
+        case KC_DOWN: return d.down_mode == 3 ? "k_lind_batch" : d.down_mode ? "k_downg_batch" : "k_down_batch";
+        case KC_BOX2: return d.box2 != 2 ? "k_boxh_batch + k_boxv_batch"
+                             : twopass_lin_h (d) ? (twopass_lin_v (d) ? "k_linh_batch + k_linv_batch" : "k_linh_batch + k_boxv_batch")
+                                                 : "k_boxh_batch + k_linv_batch";
         case KC_HSPAN: return "k_hspan_batch";
         case KC_TILE: return "k_tile_batch";
         case KC_WTILE: return "k_wtile_batch";
@@ -999,7 +1128,6 @@ kclass_name (KClass k, const JobDev &d)
         case KC_GENERAL_WIDE: return "k_general_batch<true>";
         default: return "k_general_batch<false>";
     }
-    (void) d;
 }
 
 } /* namespace dispatch */

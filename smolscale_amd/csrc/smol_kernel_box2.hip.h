@@ -28,7 +28,12 @@
 
 #pragma once
 
+#include "smol_kernel_lind.hip.h"
+
 namespace smolhip {
+
+using dispatch::twopass_lin_h;
+using dispatch::twopass_lin_v;
 
 
 template <bool V> struct BoxAligned { static constexpr bool value = V; };
@@ -465,11 +470,13 @@ __device__ __forceinline__ void boxv_entry (const JobDev &J, uint8_t *lds)
 #ifdef SMOL_KERNEL_EMU
 __global__ void k_boxh_one (const JobDev J)
 {
+    if (twopass_lin_h (J)) { linh_dispatch (J, smol_dyn_lds); return; }
     if (J.wide) boxh_entry<true> (J, smol_dyn_lds); else boxh_entry<false> (J, smol_dyn_lds);
 }
 
 __global__ void k_boxv_one (const JobDev J)
 {
+    if (twopass_lin_v (J)) { linv_entry (J, smol_dyn_lds); return; }
     if (J.wide) boxv_entry<true> (J, smol_dyn_lds); else boxv_entry<false> (J, smol_dyn_lds);
 }
 #else

@@ -37,23 +37,32 @@ __device__ __forceinline__ uint32_t tap32 (uint32_t p, uint32_t q, uint32_t F, u
 
 /* W32: premul16 + sRGB-linear (unassociated in AND out with with_srgb: 19-bit channels, :627-660 and :1135-1158):
  * four 32-bit channels per staged pixel, taps as 24-bit multiplies (p * F + q * (256 - F)) >> 8 */
-template <int HX, bool IN24, bool W32>
+/* PASS: the two halves of the kernel as passes of their own through the intermediate image of the two-pass road
+ * (smol_jobdev.h: twopass_setup), for gamma-correct jobs whose axes differ:
+ *   LIND_FUSED  both axes here (minification on both)
+ *   LIND_H      k_linh: staging + horizontal filter of `tile_rows' SOURCE rows, result (two packed channel pairs, 8 bytes)
+ *               to J.tmp; any horizontal step (a magnifying axis spans few source pixels per tile)
+ *   LIND_V      k_linv: rows of J.tmp (from k_linh or k_boxh) through the vertical filter and the packer; nothing staged */
+enum : int { LIND_FUSED = 0, LIND_H = 1, LIND_V = 2 };
+
+template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
 {
     static_assert (!(IN24 && W32), "premul16 means 32-bit pixels on both sides");
+    static_assert (PASS == LIND_FUSED || !W32, "the intermediate image holds 16-bit channels");
     constexpr uint32_t NSX = 1u << HX;
     constexpr int CPL = 2;
     constexpr uint32_t PXB = W32 ? 16u : 8u;                        /* LDS bytes per staged pixel */
     constexpr int NCH = W32 ? 4 : 2;                                /* registers per filtered pixel */
-    const uint32_t W = J.group_rows;                                /* output columns per tile (host) */
+    const uint32_t W = PASS == LIND_V ? 128u : J.group_rows;        /* output columns per tile (host) */
 
     const uint32_t tiles_x = (J.w_out + W - 1) / W;
     const uint32_t tx = tile % tiles_x;
     const uint32_t ty = tile / tiles_x;
-    const uint32_t yrel0 = ty * J.tile_rows;
+    const uint32_t yrel0 = ty * J.tile_rows;                        /* LIND_H: counted in rows of the intermediate image */
 
-    if (yrel0 >= J.n_rows)
+    if (PASS == LIND_H ? J.tmp_row0 + yrel0 > J.tmp_row1 : yrel0 >= J.n_rows)
         return;
 
     const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
@@ -71,6 +80,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         xc [c] = x0 + 64u * c + lane;
         ok [c] = xc [c] < xn;
         const uint32_t x = ok [c] ? xc [c] : xn - 1;
+        if (PASS == LIND_V)
+            xc [c] = x;                                             /* (the column whose intermediate pixels the lane reads) */
         uint64_t pos = J.frac0_x + (uint64_t) (x << HX) * J.step_x;
 #pragma unroll
         for (uint32_t s = 0; s < NSX; s++)
@@ -80,11 +91,11 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             pos += J.step_x;
         }
     }
-    const uint32_t sx0 = smol_readlane (tap_ofs [0][0], 0);         /* first source pixel of the tile */
+    const uint32_t sx0 = PASS == LIND_V ? 0u : smol_readlane (tap_ofs [0][0], 0);     /* first source pixel of the tile */
     uint32_t sx1, f_unused;
     bilin_tap (J.frac0_x + (uint64_t) ((xn << HX) - 1) * J.step_x, J.w_in, sx1, f_unused);
     sx1 += 1;                                                       /* last source pixel of the tile  */
-    const uint32_t npx = sx1 - sx0 + 1;                             /* pixels per staged row: <= 64 * LIND_KMAX (host) */
+    const uint32_t npx = PASS == LIND_V ? 0u : sx1 - sx0 + 1;       /* pixels per staged row: <= 64 * LIND_KMAX (host) */
 #pragma unroll
     for (int c = 0; c < CPL; c++)
 #pragma unroll
@@ -95,23 +106,37 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     const uint32_t hv = J.halv_v;
     const uint32_t nsy = 1u << hv;
     const uint32_t jy0 = (J.first_row + yrel0) << hv;
-    const uint32_t n_samples = (yrel1 - yrel0) << hv;               /* <= 128 (lind_setup) */
-    uint32_t sched [2];
-#pragma unroll
-    for (uint32_t q = 0; q < 2; q++)
+    const uint32_t n_samples = PASS == LIND_H ? 1u : (yrel1 - yrel0) << hv;     /* <= 128 (lind_setup) */
+    uint32_t sched [2] = { 0, 0 };
+    uint32_t e = 0, e_last = 0;
+    if (PASS != LIND_H)
     {
-        uint32_t k = q * 64u + lane;
-        if (k >= n_samples)
-            k = n_samples - 1;
-        uint32_t o, f;
-        bilin_tap (J.frac0_y + (uint64_t) (jy0 + k) * J.step_y, J.h_in, o, f);
-        sched [q] = o | (f << 16);
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++)
+        {
+            uint32_t k = q * 64u + lane;
+            if (k >= n_samples)
+                k = n_samples - 1;
+            uint32_t o, f;
+            bilin_tap (J.frac0_y + (uint64_t) (jy0 + k) * J.step_y, J.h_in, o, f);
+            if (PASS == LIND_V && J.filter_v == F_COPY)
+            {
+                /* a COPY axis: output row R is intermediate row R and nothing else -- the strip's slab of source rows
+                 * holds no neighbour to give weight 0 to (smol_hip_input_row_range) */
+                o = jy0 + k;
+                f = 0;
+            }
+            sched [q] = o | (f << 16);
+        }
+        e = smol_readlane (sched [0], 0);
+        e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
     }
-    uint32_t e = smol_readlane (sched [0], 0);
+    /* a sample is due when its BOTTOM row has passed: row o + 1 of a bilinear pair, row o itself on a COPY axis */
+    const uint32_t vdue = (PASS == LIND_V && J.filter_v == F_COPY) ? 0u : 1u;
     uint32_t oy = e & 0xffffu, Fy = e >> 16;
-    const uint32_t row_first = oy;
-    const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
-    const uint32_t row_last = (e_last & 0xffffu) + 1;
+    const uint32_t row_first = PASS == LIND_H ? J.tmp_row0 + yrel0 : oy;
+    const uint32_t row_last = PASS == LIND_H ? (row_first + J.tile_rows - 1u < J.tmp_row1 ? row_first + J.tile_rows - 1u : J.tmp_row1)
+                                             : (e_last & 0xffffu) + vdue;
 
     /* ---- staging -------------------------------------------------------------------- */
     const LutLds lut (lut_lds);
@@ -134,9 +159,20 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             px_off [k] = x * 4u;
     }
     uint32_t rawpx [LIND_KMAX];                                     /* the pixels of the row in flight */
+    /* LIND_V: the lane's two intermediate pixels of the row in flight */
+    u32x2a8 tmp_in [CPL] = { u32x2a8 { 0, 0 }, u32x2a8 { 0, 0 } };
+    const gbyte *trow = gptr (J.tmp) + (size_t) (row_first - J.tmp_row0) * J.w_out * 8u;   /* LIND_H: row being written; LIND_V: row being loaded */
 
     auto load_row = [&] ()
     {
+        if (PASS == LIND_V)
+        {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                tmp_in [c] = *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (trow + (size_t) xc [c] * 8u);
+            trow += (size_t) J.w_out * 8u;
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < LIND_KMAX; k++)
             if ((uint32_t) k * 64u < npx)                           /* wave-uniform */
@@ -215,16 +251,28 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
 
     for (uint32_t r = row_first; r <= row_last; r++)
     {
-        smol_wave_sync ();                              /* row r - 1 has been read (a real barrier only in the host emulation) */
-        convert_row ();                                 /* waits for row r's loads */
-        smol_wave_sync ();
+        uint32_t h [CPL][NCH];
+        if (PASS == LIND_V)
+        {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+            {
+                h [c][0] = tmp_in [c].x;
+                h [c][NCH - 1] = tmp_in [c].y;
+            }
+        }
+        else
+        {
+            smol_wave_sync ();                          /* row r - 1 has been read (a real barrier only in the host emulation) */
+            convert_row ();                             /* waits for row r's loads */
+            smol_wave_sync ();
+        }
         if (r < row_last)
             load_row ();                                /* row r + 1 flies while row r is filtered */
 
         /* ---- H ---------------------------------------------------------------------------------- */
-        uint32_t h [CPL][NCH];
 #pragma unroll
-        for (int c = 0; c < CPL; c++)
+        for (int c = 0; c < CPL && PASS != LIND_V; c++)
         {
             uint32_t hs [NCH];
 #pragma unroll
@@ -255,8 +303,19 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                 h [c][i] = !HX ? hs [i] : W32 ? hs [i] >> HX : (hs [i] >> HX) & (0xffffu >> HX) * 0x00010001u;
         }
 
+        if (PASS == LIND_H)
+        {
+            /* the horizontal result of this source row: row r of the intermediate image */
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                if (ok [c])
+                    *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (const_cast<gbyte *> (trow) + (size_t) xc [c] * 8u) = u32x2a8 { h [c][0], h [c][NCH - 1] };
+            trow += (size_t) J.w_out * 8u;
+            continue;
+        }
+
         /* ---- V: every sample whose bottom row is r ---------------------------------------------- */
-        while (ks < n_samples && oy + 1u == r)
+        while (ks < n_samples && oy + vdue == r)
         {
             const Lerp11W wy = lerp11_weights (Fy);
             const uint32_t Gy = 256u - Fy;
@@ -359,6 +418,50 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 #endif
 }
 
+/* k_linh: blockIdx.x = column tile, the 4 waves of a workgroup take 4 row tiles one below the other (smol_jobdev.h:
+ * box2_h_grid); k_linv: 4 tiles per workgroup, numbered row by row */
+template <int HX, bool IN24>
+__device__ __forceinline__ void linh_entry (const JobDev &J, uint8_t *lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    static uint8_t lut_lds [LUT_LDS_BYTES];
+    lut_fill_lds (lut_lds, 0, 1);
+    lind_body<HX, IN24, false, LIND_H> (J, lds, lut_lds, threadIdx.x, blockIdx.x);      /* emulated: blocks numbered tile by tile */
+#else
+    const uint32_t wave = smol_wave_index ();
+    lut_fill_lds (lds, threadIdx.x, 256);
+    __syncthreads ();
+    const uint32_t tiles_x = (J.w_out + J.group_rows - 1u) / J.group_rows;
+    lind_body<HX, IN24, false, LIND_H> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * lind_wave_lds (false), lds,
+                                        threadIdx.x & 63u, (blockIdx.y * 4u + wave) * tiles_x + blockIdx.x);
+#endif
+}
+
+__device__ __forceinline__ void linv_entry (const JobDev &J, uint8_t *lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    static uint8_t lut_lds [LUT_LDS_BYTES];
+    lut_fill_lds (lut_lds, 0, 1);
+    lind_body<0, false, false, LIND_V> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+#else
+    lut_fill_lds (lds, threadIdx.x, 256);
+    __syncthreads ();
+    lind_body<0, false, false, LIND_V> (J, lds, lds, threadIdx.x & 63u, blockIdx.x * 4u + smol_wave_index ());
+#endif
+}
+
+/* pass 1 of the two-pass road for a job's horizontal filter (k_boxh stays with its own entry) */
+__device__ __forceinline__ void linh_dispatch (const JobDev &J, uint8_t *lds)
+{
+    const bool in24 = J.bpp_in == 3;
+    switch (J.halv_h)
+    {
+        case 0: if (in24) linh_entry<0, true> (J, lds); else linh_entry<0, false> (J, lds); break;
+        case 1: if (in24) linh_entry<1, true> (J, lds); else linh_entry<1, false> (J, lds); break;
+        default: if (in24) linh_entry<2, true> (J, lds); else linh_entry<2, false> (J, lds); break;
+    }
+}
+
 #ifndef SMOL_KERNEL_EMU
 /* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels) */
 template <int HX, int IN>
@@ -374,6 +477,37 @@ __global__ void __launch_bounds__ (256)
 k_lind_one (const JobDev J)
 {
     lind_entry<HX, IN == 1, IN == 2> (J, smol_dyn_lds);
+}
+
+/* (pass 1: jobs along blockIdx.z like k_boxh; pass 2: along blockIdx.y like k_boxv) */
+template <int HX, bool IN24>
+__global__ void __launch_bounds__ (256)
+k_linh_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = load_job (jobs, blockIdx.z);
+    linh_entry<HX, IN24> (J, smol_dyn_lds);
+}
+
+template <int HX, bool IN24>
+__global__ void __launch_bounds__ (256)
+k_linh_one (const JobDev J)
+{
+    linh_entry<HX, IN24> (J, smol_dyn_lds);
+}
+
+template <int UNUSED>        /* (a template so that the header may be included by two translation units) */
+__global__ void __launch_bounds__ (256)
+k_linv_batch (const JobDev *__restrict__ jobs)
+{
+    const JobDev J = load_job (jobs, blockIdx.y);
+    linv_entry (J, smol_dyn_lds);
+}
+
+template <int UNUSED>
+__global__ void __launch_bounds__ (256)
+k_linv_one (const JobDev J)
+{
+    linv_entry (J, smol_dyn_lds);
 }
 #endif
 

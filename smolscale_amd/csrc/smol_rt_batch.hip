@@ -4,6 +4,7 @@
 
 #include "smol_rt.h"
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -153,7 +154,9 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4 || jobs [j].up_wide != g.rep.up_wide
                                  || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))
                 continue;
-            if (g.k == KC_BOX2 && (jobs [j].wide != g.rep.wide || jobs [j].box2_ygroup != g.rep.box2_ygroup))
+            if (g.k == KC_BOX2 && (jobs [j].wide != g.rep.wide || jobs [j].box2_ygroup != g.rep.box2_ygroup || jobs [j].box2 != g.rep.box2
+                                   || (g.rep.box2 == 2 && (jobs [j].filter_h != g.rep.filter_h || jobs [j].filter_v != g.rep.filter_v
+                                                           || jobs [j].halv_h != g.rep.halv_h || jobs [j].bpp_in != g.rep.bpp_in))))
                 continue;
             if (g.k == KC_HSPAN && (jobs [j].bpp_in != g.rep.bpp_in || jobs [j].halv_h != g.rep.halv_h))
                 continue;
@@ -195,6 +198,10 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
             units += (uint64_t) jobs [j].w_out * jobs [j].n_rows;
         }
 
+        /* experiment (tuning builds): the images of a mixed-flavour launch ordered by flavour */
+        if (g.k == KC_POW2X && g.rep.px_mixed && smolhip::tune_env ("SMOL_BATCH_SORT_MIXED"))
+            std::stable_sort (sorted.begin () + g.first, sorted.end (),
+                              [] (const JobDev &a, const JobDev &b2) { return a.px_kind < b2.px_kind; });
         if (units > b->dominant_units)
         {
             b->dominant_units = units;

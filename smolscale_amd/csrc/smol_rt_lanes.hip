@@ -639,7 +639,7 @@ strip_issue_locked (Strip &st, Lane &ln)
     {
         JobDev probe;
         fill_jobdev (probe, job, (void *) 16, (uint32_t) src_pitch, (void *) 16, (uint32_t) dst_pitch, st.first, st.n);
-        if (box2_setup (probe))
+        if (classify (probe) == KC_BOX2)
             tmp_need = box2_tmp_bytes (probe) + 64;
     }
     rc = lane_prepare (ln, zero_copy ? 0 : src_bytes + 64 + 16, zero_copy ? 0 : dst_bytes + 64 + 16, tmp_need);

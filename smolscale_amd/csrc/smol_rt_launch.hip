@@ -97,3 +97,17 @@ launch_single (JobDev &jd, hipStream_t s, void *scratch, KClass *k_out)
 }
 
 } /* namespace smolrt */
+
+/* Which kernel family takes these rows: the dispatcher's own decision (fill_jobdev + classify), no GPU involved.
+ * For the histograms of tools/fuzz/gpu_fuzz.py, tests/test_hip_sweep.py and tools/kernel_histogram.py. */
+extern "C" const char *
+smol_hip_kernel_name (const SmolHipJob *job, const void *src, uint32_t rowstride_in,
+                      const void *dst, uint32_t rowstride_out, uint32_t first_row, uint32_t n_rows)
+{
+    if (!job || job->pixel_type_in >= 10 || job->pixel_type_out >= 10 || !n_rows)
+        return "";
+    smolhip::JobDev jd;
+    fill_jobdev (jd, *job, src, rowstride_in, const_cast<void *> (dst), rowstride_out, first_row, n_rows);
+    const KClass k = classify (jd);
+    return kclass_name (k, jd);
+}

@@ -14,6 +14,19 @@ constexpr int BOX_SLOTS = SMOL_BOX_SLOTS;
 
 namespace {
 
+/* could this plan's rows go through an intermediate image (two-pass box filter, or the two-pass road of the
+ * gamma-correct jobs with mixed axes)? Decided as the dispatcher would for aligned rows -- alignment can only take a
+ * job OFF these roads. */
+bool
+plan_may_need_scratch (const SmolHipPlan *plan)
+{
+    const SmolHipJob &j = plan->job;
+    JobDev probe;
+    fill_jobdev (probe, j, reinterpret_cast<const void *> (uintptr_t (256)), j.width_in * k_types [j.pixel_type_in].bpp,
+                 reinterpret_cast<void *> (uintptr_t (256)), j.width_out * k_types [j.pixel_type_out].bpp, 0, j.height_out);
+    return classify (probe) == KC_BOX2;
+}
+
 size_t
 plan_box_bytes (const SmolHipPlan *plan)
 {
@@ -199,8 +212,7 @@ smol_hip_plan_prepare (SmolHipPlan *plan)
 {
     if (!plan)
         return SMOL_HIP_E_INVALID;
-    const SmolHipJob &j = plan->job;
-    if (j.filter_h != SMOL_HIP_FILTER_BOX || j.filter_v != SMOL_HIP_FILTER_BOX)
+    if (!plan_may_need_scratch (plan))
         return 0;
     HIP_TRY (hipSetDevice (plan->device));
     std::lock_guard<std::mutex> guard (plan->mtx);
@@ -212,8 +224,7 @@ smol_hip_plan_reserve (SmolHipPlan *plan, uint32_t images_in_flight)
 {
     if (!plan || images_in_flight > (uint32_t) BOX_SLOTS)
         return SMOL_HIP_E_INVALID;
-    const SmolHipJob &j = plan->job;
-    if (j.filter_h != SMOL_HIP_FILTER_BOX || j.filter_v != SMOL_HIP_FILTER_BOX)
+    if (!plan_may_need_scratch (plan))
         return 0;
     HIP_TRY (hipSetDevice (plan->device));
     std::lock_guard<std::mutex> guard (plan->mtx);

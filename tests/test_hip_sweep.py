@@ -41,6 +41,7 @@ def _sweep(w_in, h_in, smax, every):
     sizes = list(steps_of(w_in, h_in, 0.01, smax, 200))[::every]
     ddst = sm.DeviceBuffer(max(w * h for w, h in sizes) * 4 + 64)
     kernels = set()
+    hist = {}
     for (w_out, h_out) in sizes:
         job = H.plan_job(ARGB_P, w_in, h_in, ARGB_P, w_out, h_out, 0)
         plan = C.c_void_p()
@@ -51,12 +52,18 @@ def _sweep(w_in, h_in, smax, every):
         sm.check(lib.smol_hip_device_synchronize(0), "sync")
         lib.smol_hip_plan_destroy(plan)
         kernels.add((job.filter_h, job.halvings_h, job.filter_v, job.halvings_v))
+        kn = sm.kernel_name(job)
+        hist[kn] = hist.get(kn, 0) + 1
         for first, n in _strips(h_out):
             want = H.oracle_scale(src, ARGB_P, w_in, h_in, ARGB_P, w_out, h_out, 0, None, None, first, n)
             got = ddst.download(n * w_out * 4, offset=first * w_out * 4)
             assert np.array_equal(got, want), (w_in, h_in, w_out, h_out, first, n)
     dsrc.free()
     ddst.free()
+    print("kernel histogram %dx%d:" % (w_in, h_in),
+          ", ".join("%s %d" % kv for kv in sorted(hist.items(), key=lambda kv: -kv[1])))    # pytest -s shows it
+    # the correctness backstops (k_general / k_wavepx / k_wtile) take none of the reference's benchmark matrix
+    assert not any(k.startswith(("k_general", "k_wavepx", "k_wtile")) for k in hist), hist
     return kernels
 
 

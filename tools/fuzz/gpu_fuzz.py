@@ -10,7 +10,7 @@ import smolscale_amd as sm
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 rng = random.Random(seed)
-bad = 0; fam_count = {}
+bad = 0; fam_count = {}; kernels = {}
 t0 = time.time()
 for it in range(N):
     fam = rng.choice(["any", "any", "pow2x", "up", "up", "bigw", "thin", "hspan"])
@@ -48,6 +48,9 @@ for it in range(N):
     first = rng.randint(0, h_out - 1) if it % 3 == 0 else 0
     n = rng.randint(1, h_out - first) if it % 3 == 0 else h_out
     want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+    # which kernel family the dispatcher hands these rows to (packed aligned rows; the run itself also uses odd strides)
+    kn = sm.kernel_name(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb), first_row=first, n_rows=n)
+    kernels[kn] = kernels.get(kn, 0) + 1
     if it & 1:
         got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n,
                                  src_misalign=rng.choice([0, 0, 1, 2, 4, 8]), dst_misalign=rng.choice([0, 0, 1, 3, 4]))
@@ -58,3 +61,4 @@ for it in range(N):
         bad += 1
         print("MISMATCH it=%d" % it, fam, (t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n), "dev" if it & 1 else "host", flush=True)
 print("cases", N, "bad", bad, fam_count, "%.0f s" % (time.time() - t0))
+print("kernel histogram:", ", ".join("%s %d (%.1f %%)" % (k, v, 100.0 * v / N) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1])))
