@@ -114,6 +114,27 @@ def bpp(t):
     return sm.bytes_per_pixel(t)
 
 
+def gpu_state():
+    """sclk / socket power / junction temperature as rocm-smi reports them right after a timing: the boxes of the pool
+    differ by 10-15 % on instruction-bound kernels (C5mix: 396-413 us on some, 456-471 on others, whatever the process,
+    allocation or image order: profiles/r04_c5mix_modes.txt), and this is what tells them apart in a table."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True, timeout=5).stdout
+        d = {}
+        for l in out.splitlines():
+            v = l.split(":", 2)[-1].strip()
+            if "sclk" in l:
+                d["sclk_mhz"] = int("".join(c for c in v.split("(")[-1] if c.isdigit()) or 0)
+            elif "Power (W)" in l:
+                d["power_w"] = float(v)
+            elif "junction" in l.lower():
+                d["temp_c"] = float(v)
+        return d
+    except Exception:       # noqa: BLE001
+        return {}
+
+
 def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False):
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
@@ -206,6 +227,10 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
     algo = total_in + total_out
     # SURVEY 8d asks for min and median too: 20 single-step timings (hipEvents around one step each)
     singles = sorted(batch.time(0, 1) * 1e3 for _ in range(20))
+    state = {}
+    if os.environ.get("SMOL_BENCH_GPU_STATE"):
+        batch.time(0, max(20, iters))           # (the readout samples the clock the GPU runs at under this load)
+        state = gpu_state()
     line = {
         "config": name, "desc": desc, "kernel": kname, "launches_per_step": n_launches,
         "step_us": round(per_step_ms * 1e3, 2),
@@ -216,6 +241,8 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
         "Mpix_out_per_s": round(n_images * w_out * h_out / (per_step_ms * 1e-3) / 1e6, 1),
         "images_per_s": round(n_images / (per_step_ms * 1e-3), 1),
     }
+    if state:
+        line["gpu_state"] = state
     if checker is not None:
         # checker (host_src, type_in, w_in, h_in, stride_in, type_out, w_out, h_out, stride_out, srgb, got) -> bool
         t_in, t_out, s_in, s_out = specs[0]
