@@ -135,7 +135,26 @@ def gpu_state():
         return {}
 
 
-def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False):
+def natural_bytes(n_bytes, bytes_pp, width, rng):
+    """Image-like bytes instead of white noise: every channel a smooth ramp across the row and down the image plus a few
+    grey levels of noise, alpha (32-bit pixels) mostly opaque with soft-edged translucent regions. Neighbouring pixels then
+    hold neighbouring values, as in photographs -- which is what decides how the gamma-correct kernels' table look-ups
+    spread over the LDS banks (white noise is their worst case)."""
+    n_px = n_bytes // bytes_pp + 1
+    i = np.arange(n_px, dtype=np.int64)
+    x, y = i % max(1, width), i // max(1, width)
+    out = np.empty((n_px, bytes_pp), np.uint8)
+    for c in range(bytes_pp):
+        ramp = (x * (3 + 2 * c)) // 16 + (y * (5 + c)) // 24 + 40 * c
+        out[:, c] = ((ramp + rng.integers(-3, 4, n_px)) % 256).astype(np.uint8)
+    if bytes_pp == 4:
+        a = np.clip(255 - np.maximum(0, 96 - np.abs(((x + y) % 512) - 256)) * 2, 0, 255).astype(np.uint8)
+        out[:, 3] = a
+        out[:, 0] = a       # (either end may be the alpha byte: both carry the alpha pattern, colours in between)
+    return out.reshape(-1)[:n_bytes]
+
+
+def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False, natural=False):
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
     srgb = cfg[9] if len(cfg) > 9 else 0
@@ -192,7 +211,7 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
             dsrc = sm.DeviceBuffer(n_in + 64 + src_off)
             ddst = sm.DeviceBuffer(n_out + 64)
         if i < 16 or n_in > (1 << 24):
-            host = rng.integers(0, 256, n_in, dtype=np.uint8)
+            host = natural_bytes(n_in, bpp(t_in), w_in, rng) if natural else rng.integers(0, 256, n_in, dtype=np.uint8)
             pool = host
         else:
             host = pool          # reuse host bytes (device copies are still distinct allocations)
@@ -270,11 +289,12 @@ def main(argv=None, checker=None):
     ap.add_argument("--srgb", type=int, default=None, help="override with_srgb")
     ap.add_argument("--no-arena", action="store_true", help="one allocation per image even for small images")
     ap.add_argument("--opaque", action="store_true", help="set the alpha channel of 32-bit inputs to 255 (like real photographs)")
+    ap.add_argument("--natural", action="store_true", help="image-like source bytes (smooth ramps + a little noise) instead of white noise")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of warm-up load before timing (clock settling)")
     args = ap.parse_args(argv)
     for name in args.configs.split(","):
         print(json.dumps(run_config(name, args.iters, args.warmup, checker, args.graph,
-                                    args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena)), flush=True)
+                                    args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena, args.natural)), flush=True)
 
 
 if __name__ == "__main__":
