@@ -872,10 +872,17 @@ box2_is (const JobDev &d)
     return d.box2 != 0;
 }
 
+/* bytes per pixel of the intermediate image */
+inline uint32_t
+box2_tmp_px (const JobDev &d)
+{
+    return (d.box2 == 2 && d.p16 && d.filter_h != F_BOX && d.filter_v != F_BOX) ? 16u : 8u;
+}
+
 inline size_t
 box2_tmp_bytes (const JobDev &d)
 {
-    return (size_t) (d.tmp_row1 - d.tmp_row0 + 1) * d.w_out * 8;
+    return (size_t) (d.tmp_row1 - d.tmp_row0 + 1) * d.w_out * box2_tmp_px (d);
 }
 
 /* tiles (= waves) of each pass; a workgroup runs 4 of them */
@@ -930,20 +937,22 @@ inline uint32_t
 box2_h_lds_bytes (const JobDev &d)
 {
     if (twopass_lin_h (d))
-        return DOWN_LUT_BYTES + 4u * (64u * LIND_KMAX_HOST * 8u) + 16u;
+        return DOWN_LUT_BYTES + 4u * (64u * LIND_KMAX_HOST * (d.p16 ? 16u : 8u)) + 16u;
     return (d.wide ? DOWN_LUT_BYTES_FWD : 0u) + 4u * d.span_chunks * 16u + 32u;
 }
 
 /* ---- the generic two-pass road of the 128bpp class (box2 == 2) ------------------------------------------------
- * Gamma-correct jobs whose axes differ -- one minified and one magnified, a COPY axis, bilinear on one axis and box
+ * 128bpp-class jobs whose axes differ -- one minified and one magnified, a COPY axis, bilinear on one axis and box
  * on the other -- used to end in the correctness backstops (k_wtile, k_general<true>: 5-14 % of the roofline,
  * profiles/r04_backstop_rows.txt). No proportional resize lands there, independently scaled axes do. They now take
  * the intermediate image of the two-pass box filter with one kernel per axis:
  *   pass 1   horizontal: k_boxh (BOX) or k_linh = the staging + horizontal half of k_lind (BILINEAR up or down, COPY)
  *   pass 2   vertical:   k_boxv (BOX) or k_linv = the vertical + packing half of k_lind (BILINEAR up or down, COPY)
  * A horizontal COPY axis is a bilinear axis at step 1 (every weight is 256 or, at the last sample, 0: the tap returns
- * the pixel itself); a vertical one hands row R of the intermediate image to output row R. sRGB-linear with 8-bit alpha only (11-bit channels, 8 bytes per intermediate pixel); premul16 jobs with
- * mixed axes stay where they were. */
+ * the pixel itself); a vertical one hands row R of the intermediate image to output row R. Intermediate pixels: 8 bytes
+ * (four 16-bit channels) for the 11-bit sRGB-linear flavours and wherever a box pass reads or writes them, 16 bytes
+ * (four 32-bit channels) for the premul16 flavours between two k_lin* passes. Gamma-correct and premul16 jobs alike
+ * (the 128bpp class); compressed 128bpp (boxes wider than 255 pixels without sRGB) stays with its own kernels. */
 inline void
 twopass_v_rows (const JobDev &d, uint32_t &y0, uint32_t &y1)
 {
@@ -972,9 +981,14 @@ twopass_v_rows (const JobDev &d, uint32_t &y0, uint32_t &y1)
 inline bool
 twopass_setup (JobDev &d)
 {
-    if (!d.wide || !d.linear || d.p16 || d.n_rows == 0 || tune_env ("SMOL_NO_TWOPASS"))
+    if (!d.wide || (!d.linear && !d.p16) || d.n_rows == 0 || tune_env ("SMOL_NO_TWOPASS"))
         return false;
     if (d.bpp_in == 4 && !d.in_dword_ok)
+        return false;
+    if (d.p16 && (d.bpp_in != 4 || d.bpp_out != 4))
+        return false;
+    /* premul16 + sRGB leaves 19-bit channels behind a bilinear horizontal pass: more than k_boxv's 16-bit pixels hold */
+    if (d.p16 && d.linear && d.filter_h != F_BOX && d.filter_v == F_BOX)
         return false;
     const auto usable = [] (uint8_t f) { return f == F_BILINEAR || f == F_COPY || f == F_BOX; };
     if (!usable (d.filter_h) || !usable (d.filter_v) || (d.filter_h == F_BOX && d.filter_v == F_BOX))

@@ -14,26 +14,68 @@ using smolhip::JobDev;
 
 namespace {
 
-template <int HX, bool IN24>
+/* the KIND of a two-pass job (device twin: lin_pass_kind) */
+int
+lin_pass_kind (const JobDev &J)
+{
+    if (!J.p16)
+        return J.bpp_in == 3 ? 1 : 0;
+    return (J.filter_h == smolhip::F_BOX || J.filter_v == smolhip::F_BOX) ? 3 : 2;
+}
+
+template <int HX, int KIND>
 void
 launch_linh_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_linh_batch<HX, IN24>), grid, dim3 (256), lds, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_linh_batch<HX, KIND>), grid, dim3 (256), lds, s, jobs_dev);
     else
-        hipLaunchKernelGGL ((smolhip::k_linh_one<HX, IN24>), grid, dim3 (256), lds, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_linh_one<HX, KIND>), grid, dim3 (256), lds, s, rep);
 }
 
-/* k_linh: pass 1 of the generic two-pass road (smol_kernel_lind.hip.h), one entry point per (halvings, 24-bit rows) */
+template <int HX>
+void
+launch_linh_h (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (lin_pass_kind (rep))
+    {
+        case 0:  launch_linh_k<HX, 0> (jobs_dev, rep, grid, lds, s); break;
+        case 1:  launch_linh_k<HX, 1> (jobs_dev, rep, grid, lds, s); break;
+        case 2:  launch_linh_k<HX, 2> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_linh_k<HX, 3> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
+/* k_linh: pass 1 of the generic two-pass road (smol_kernel_lind.hip.h), one entry point per (halvings, kind) */
 void
 launch_linh (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
-    const bool in24 = rep.bpp_in == 3;
     switch (rep.halv_h)
     {
-        case 0:  if (in24) launch_linh_k<0, true> (jobs_dev, rep, grid, lds, s); else launch_linh_k<0, false> (jobs_dev, rep, grid, lds, s); break;
-        case 1:  if (in24) launch_linh_k<1, true> (jobs_dev, rep, grid, lds, s); else launch_linh_k<1, false> (jobs_dev, rep, grid, lds, s); break;
-        default: if (in24) launch_linh_k<2, true> (jobs_dev, rep, grid, lds, s); else launch_linh_k<2, false> (jobs_dev, rep, grid, lds, s); break;
+        case 0:  launch_linh_h<0> (jobs_dev, rep, grid, lds, s); break;
+        case 1:  launch_linh_h<1> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_linh_h<2> (jobs_dev, rep, grid, lds, s); break;
+    }
+}
+
+template <int KIND>
+void
+launch_linv_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    if (jobs_dev)
+        hipLaunchKernelGGL ((smolhip::k_linv_batch<KIND>), grid, dim3 (256), lds, s, jobs_dev);
+    else
+        hipLaunchKernelGGL ((smolhip::k_linv_one<KIND>), grid, dim3 (256), lds, s, rep);
+}
+
+void
+launch_linv (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
+{
+    switch (lin_pass_kind (rep))
+    {
+        case 2:  launch_linv_k<2> (jobs_dev, rep, grid, lds, s); break;
+        case 3:  launch_linv_k<3> (jobs_dev, rep, grid, lds, s); break;
+        default: launch_linv_k<0> (jobs_dev, rep, grid, lds, s); break;
     }
 }
 
@@ -73,12 +115,7 @@ box2 (const JobDev *jobs_dev, const JobDev &rep, uint32_t n_jobs, uint32_t h_gri
 
     /* pass 2: vertical */
     if (twopass_lin_v (rep))
-    {
-        if (jobs_dev)
-            hipLaunchKernelGGL (smolhip::k_linv_batch<0>, gv, dim3 (256), v_lds, s, jobs_dev);
-        else
-            hipLaunchKernelGGL (smolhip::k_linv_one<0>, gv, dim3 (256), v_lds, s, rep);
-    }
+        launch_linv (jobs_dev, rep, gv, v_lds, s);
     else if (rep.wide)
     {
         if (jobs_dev)

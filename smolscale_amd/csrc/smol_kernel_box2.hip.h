@@ -476,7 +476,7 @@ __global__ void k_boxh_one (const JobDev J)
 
 __global__ void k_boxv_one (const JobDev J)
 {
-    if (twopass_lin_v (J)) { linv_entry (J, smol_dyn_lds); return; }
+    if (twopass_lin_v (J)) { linv_dispatch (J, smol_dyn_lds); return; }
     if (J.wide) boxv_entry<true> (J, smol_dyn_lds); else boxv_entry<false> (J, smol_dyn_lds);
 }
 #else

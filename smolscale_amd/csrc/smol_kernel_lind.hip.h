@@ -45,12 +45,14 @@ __device__ __forceinline__ uint32_t tap32 (uint32_t p, uint32_t q, uint32_t F, u
  *   LIND_V      k_linv: rows of J.tmp (from k_linh or k_boxh) through the vertical filter and the packer; nothing staged */
 enum : int { LIND_FUSED = 0, LIND_H = 1, LIND_V = 2 };
 
-template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED>
+/* TMP8 (passes of the W32 flavour only): the intermediate pixel is 8 bytes of 16-bit channels -- what k_boxh writes and
+ * k_boxv reads (premul16 without sRGB: every value fits 16 bits) -- instead of four 32-bit channels (16 bytes) */
+template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
 {
     static_assert (!(IN24 && W32), "premul16 means 32-bit pixels on both sides");
-    static_assert (PASS == LIND_FUSED || !W32, "the intermediate image holds 16-bit channels");
+    constexpr uint32_t TPX = (W32 && !TMP8) ? 16u : 8u;            /* bytes per pixel of the intermediate image */
     constexpr uint32_t NSX = 1u << HX;
     constexpr int CPL = 2;
     constexpr uint32_t PXB = W32 ? 16u : 8u;                        /* LDS bytes per staged pixel */
@@ -160,8 +162,13 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     }
     uint32_t rawpx [LIND_KMAX];                                     /* the pixels of the row in flight */
     /* LIND_V: the lane's two intermediate pixels of the row in flight */
-    u32x2a8 tmp_in [CPL] = { u32x2a8 { 0, 0 }, u32x2a8 { 0, 0 } };
-    const gbyte *trow = gptr (J.tmp) + (size_t) (row_first - J.tmp_row0) * J.w_out * 8u;   /* LIND_H: row being written; LIND_V: row being loaded */
+    uint32_t tmp_in [CPL][NCH];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int i = 0; i < NCH; i++)
+            tmp_in [c][i] = 0;
+    const gbyte *trow = gptr (J.tmp) + (size_t) (row_first - J.tmp_row0) * J.w_out * TPX;  /* LIND_H: row being written; LIND_V: row being loaded */
 
     auto load_row = [&] ()
     {
@@ -169,8 +176,28 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         {
 #pragma unroll
             for (int c = 0; c < CPL; c++)
-                tmp_in [c] = *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (trow + (size_t) xc [c] * 8u);
-            trow += (size_t) J.w_out * 8u;
+            {
+                if (TPX == 16)
+                {
+                    const u32x4 t = *reinterpret_cast<const SMOL_AS_GLOBAL u32x4 *> (trow + (size_t) xc [c] * 16u);
+                    tmp_in [c][0] = t.x; tmp_in [c][1] = t.y; tmp_in [c][NCH - 2] = t.z; tmp_in [c][NCH - 1] = t.w;
+                }
+                else
+                {
+                    const u32x2a8 t = *reinterpret_cast<const SMOL_AS_GLOBAL u32x2a8 *> (trow + (size_t) xc [c] * 8u);
+                    if (W32)
+                    {
+                        tmp_in [c][0] = t.x & 0xffffu; tmp_in [c][1] = t.x >> 16;
+                        tmp_in [c][NCH - 2] = t.y & 0xffffu; tmp_in [c][NCH - 1] = t.y >> 16;
+                    }
+                    else
+                    {
+                        tmp_in [c][0] = t.x;
+                        tmp_in [c][NCH - 1] = t.y;
+                    }
+                }
+            }
+            trow += (size_t) J.w_out * TPX;
             return;
         }
 #pragma unroll
@@ -216,7 +243,12 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                 }
         };
         if (W32)
-            conv (WideUnpack<WU_P16L> (J, lut));
+        {
+            if (J.linear)
+                conv (WideUnpack<WU_P16L> (J, lut));
+            else
+                conv (WideUnpack<WU_P16> (J, lut));
+        }
         else if (IN24 || uk == WU_LIN_O)
             conv (WideUnpack<WU_LIN_O> (J, lut));
         else
@@ -256,10 +288,9 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         {
 #pragma unroll
             for (int c = 0; c < CPL; c++)
-            {
-                h [c][0] = tmp_in [c].x;
-                h [c][NCH - 1] = tmp_in [c].y;
-            }
+#pragma unroll
+                for (int i = 0; i < NCH; i++)
+                    h [c][i] = tmp_in [c][i];
         }
         else
         {
@@ -309,8 +340,16 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
 #pragma unroll
             for (int c = 0; c < CPL; c++)
                 if (ok [c])
-                    *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (const_cast<gbyte *> (trow) + (size_t) xc [c] * 8u) = u32x2a8 { h [c][0], h [c][NCH - 1] };
-            trow += (size_t) J.w_out * 8u;
+                {
+                    gbyte *tp = const_cast<gbyte *> (trow) + (size_t) xc [c] * TPX;
+                    if (TPX == 16)
+                        *reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (tp) = u32x4 { h [c][0], h [c][1], h [c][NCH - 2], h [c][NCH - 1] };
+                    else if (W32)
+                        *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (tp) = u32x2a8 { h [c][0] | (h [c][1] << 16), h [c][NCH - 2] | (h [c][NCH - 1] << 16) };
+                    else
+                        *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (tp) = u32x2a8 { h [c][0], h [c][NCH - 1] };
+                }
+            trow += (size_t) J.w_out * TPX;
             continue;
         }
 
@@ -365,7 +404,12 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                 };
                 /* once per output row and wave; all-opaque rows skip the inverse-alpha look-up and multiplies */
                 if (W32)
-                    put (WidePack<WP_P16L> (J, lut));
+                {
+                    if (J.linear)
+                        put (WidePack<WP_P16L> (J, lut));
+                    else
+                        put (WidePack<WP_P16> (J, lut));
+                }
                 else if ((pk == WP_LIN_P || pk == WP_LIN_U) && smol_wave_all_opaque (all_a))
                     put (WidePack<WP_LIN_O> (J, lut));
                 else if (pk == WP_LIN_P)
@@ -419,46 +463,75 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 }
 
 /* k_linh: blockIdx.x = column tile, the 4 waves of a workgroup take 4 row tiles one below the other (smol_jobdev.h:
- * box2_h_grid); k_linv: 4 tiles per workgroup, numbered row by row */
-template <int HX, bool IN24>
+ * box2_h_grid); k_linv: 4 tiles per workgroup, numbered row by row.
+ * KIND: 0 = 11-bit channels, 32-bit rows; 1 = 11-bit channels, 24-bit rows; 2 = premul16 flavours, 16-byte intermediate
+ * pixels; 3 = premul16 without sRGB next to a box pass (8-byte intermediate pixels) */
+template <int HX, int KIND>
 __device__ __forceinline__ void linh_entry (const JobDev &J, uint8_t *lds)
 {
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);
-    lind_body<HX, IN24, false, LIND_H> (J, lds, lut_lds, threadIdx.x, blockIdx.x);      /* emulated: blocks numbered tile by tile */
+    lind_body<HX, KIND == 1, KIND >= 2, LIND_H, KIND == 3> (J, lds, lut_lds, threadIdx.x, blockIdx.x);     /* emulated: blocks numbered tile by tile */
 #else
     const uint32_t wave = smol_wave_index ();
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     const uint32_t tiles_x = (J.w_out + J.group_rows - 1u) / J.group_rows;
-    lind_body<HX, IN24, false, LIND_H> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * lind_wave_lds (false), lds,
-                                        threadIdx.x & 63u, (blockIdx.y * 4u + wave) * tiles_x + blockIdx.x);
+    lind_body<HX, KIND == 1, KIND >= 2, LIND_H, KIND == 3> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * lind_wave_lds (KIND >= 2), lds,
+                                                            threadIdx.x & 63u, (blockIdx.y * 4u + wave) * tiles_x + blockIdx.x);
 #endif
 }
 
+template <int KIND>
 __device__ __forceinline__ void linv_entry (const JobDev &J, uint8_t *lds)
 {
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);
-    lind_body<0, false, false, LIND_V> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    lind_body<0, false, KIND >= 2, LIND_V, KIND == 3> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
-    lind_body<0, false, false, LIND_V> (J, lds, lds, threadIdx.x & 63u, blockIdx.x * 4u + smol_wave_index ());
+    lind_body<0, false, KIND >= 2, LIND_V, KIND == 3> (J, lds, lds, threadIdx.x & 63u, blockIdx.x * 4u + smol_wave_index ());
 #endif
 }
 
-/* pass 1 of the two-pass road for a job's horizontal filter (k_boxh stays with its own entry) */
+/* the KIND of a two-pass job (host twin: smol_k_box2.hip) */
+__device__ __forceinline__ int lin_pass_kind (const JobDev &J)
+{
+    if (!J.p16)
+        return J.bpp_in == 3 ? 1 : 0;
+    return (J.filter_h == F_BOX || J.filter_v == F_BOX) ? 3 : 2;
+}
+
+/* pass 1 / pass 2 of the two-pass road for a job's filters (k_boxh / k_boxv stay with their own entries) */
 __device__ __forceinline__ void linh_dispatch (const JobDev &J, uint8_t *lds)
 {
-    const bool in24 = J.bpp_in == 3;
-    switch (J.halv_h)
+    switch (J.halv_h * 4 + lin_pass_kind (J))
     {
-        case 0: if (in24) linh_entry<0, true> (J, lds); else linh_entry<0, false> (J, lds); break;
-        case 1: if (in24) linh_entry<1, true> (J, lds); else linh_entry<1, false> (J, lds); break;
-        default: if (in24) linh_entry<2, true> (J, lds); else linh_entry<2, false> (J, lds); break;
+        case 0: linh_entry<0, 0> (J, lds); break;
+        case 1: linh_entry<0, 1> (J, lds); break;
+        case 2: linh_entry<0, 2> (J, lds); break;
+        case 3: linh_entry<0, 3> (J, lds); break;
+        case 4: linh_entry<1, 0> (J, lds); break;
+        case 5: linh_entry<1, 1> (J, lds); break;
+        case 6: linh_entry<1, 2> (J, lds); break;
+        case 7: linh_entry<1, 3> (J, lds); break;
+        case 8: linh_entry<2, 0> (J, lds); break;
+        case 9: linh_entry<2, 1> (J, lds); break;
+        case 10: linh_entry<2, 2> (J, lds); break;
+        default: linh_entry<2, 3> (J, lds); break;
+    }
+}
+
+__device__ __forceinline__ void linv_dispatch (const JobDev &J, uint8_t *lds)
+{
+    switch (lin_pass_kind (J))
+    {
+        case 2: linv_entry<2> (J, lds); break;
+        case 3: linv_entry<3> (J, lds); break;
+        default: linv_entry<0> (J, lds); break;
     }
 }
 
@@ -480,34 +553,34 @@ k_lind_one (const JobDev J)
 }
 
 /* (pass 1: jobs along blockIdx.z like k_boxh; pass 2: along blockIdx.y like k_boxv) */
-template <int HX, bool IN24>
+template <int HX, int KIND>
 __global__ void __launch_bounds__ (256)
 k_linh_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.z);
-    linh_entry<HX, IN24> (J, smol_dyn_lds);
+    linh_entry<HX, KIND> (J, smol_dyn_lds);
 }
 
-template <int HX, bool IN24>
+template <int HX, int KIND>
 __global__ void __launch_bounds__ (256)
 k_linh_one (const JobDev J)
 {
-    linh_entry<HX, IN24> (J, smol_dyn_lds);
+    linh_entry<HX, KIND> (J, smol_dyn_lds);
 }
 
-template <int UNUSED>        /* (a template so that the header may be included by two translation units) */
+template <int KIND>
 __global__ void __launch_bounds__ (256)
 k_linv_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    linv_entry (J, smol_dyn_lds);
+    linv_entry<KIND> (J, smol_dyn_lds);
 }
 
-template <int UNUSED>
+template <int KIND>
 __global__ void __launch_bounds__ (256)
 k_linv_one (const JobDev J)
 {
-    linv_entry (J, smol_dyn_lds);
+    linv_entry<KIND> (J, smol_dyn_lds);
 }
 #endif
 

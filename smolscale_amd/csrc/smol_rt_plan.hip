@@ -30,7 +30,8 @@ plan_may_need_scratch (const SmolHipPlan *plan)
 size_t
 plan_box_bytes (const SmolHipPlan *plan)
 {
-    return (size_t) plan->job.height_in * plan->job.width_out * 8 + 64;
+    /* (16 bytes per pixel between the two k_lin* passes of a premul16 job, 8 everywhere else) */
+    return (size_t) plan->job.height_in * plan->job.width_out * (plan->job.premul16 ? 16u : 8u) + 64;
 }
 
 int
@@ -277,7 +278,7 @@ smol_hip_scale_rows_device (SmolHipPlan *plan,
         return rc;
     /* the kernels index the intermediate image from the job's first source row:
      * shift the base so that row r of the image always lands at r * w_out * 8 */
-    void *scratch = static_cast<uint8_t *> (sl->buf) + (size_t) probe.tmp_row0 * probe.w_out * 8;
+    void *scratch = static_cast<uint8_t *> (sl->buf) + (size_t) probe.tmp_row0 * probe.w_out * box2_tmp_px (probe);
     HIP_TRY (launch_single (jd, stream, scratch));
     if (use)
     {

@@ -1,5 +1,6 @@
-"""Emulated two-pass road of the gamma-correct class (k_linh / k_boxh + k_linv / k_boxv) vs oracle: axes scaled
-independently -- one minified and one magnified, a COPY axis, bilinear x box -- every type pair that is not premul16."""
+"""Emulated two-pass road of the 128bpp class (k_linh / k_boxh + k_linv / k_boxv) vs oracle: axes scaled independently --
+one minified and one magnified, a COPY axis, bilinear x box -- gamma-correct jobs of every type pair and premul16 jobs
+(unassociated in and out) with and without sRGB."""
 import sys, random
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
@@ -19,18 +20,22 @@ for it in range(N):
     w_in, h_in = axis(kh, w_out), axis(kv, h_out)
     if (kh != "copy" and w_in == w_out) or (kv != "copy" and h_in == h_out): continue
     if w_in < 2 or h_in < 2: continue
-    t_in=random.randrange(10); t_out=random.randrange(10)
+    srgb=random.choice([1,1,0])
+    if srgb: t_in=random.randrange(10); t_out=random.randrange(10)
+    else: t_in=random.choice([4,5,6,7]); t_out=random.choice([4,5,6,7])     # premul16: the 128bpp class without sRGB
     sin=w_in*bpp(t_in)+random.choice([0,0,4,16,1,3]); sout=w_out*bpp(t_out)+random.choice([0,0,1,4,16])
     src=make_input(t_in,w_in,h_in,seed=it,valid=random.choice([True,False]),stride=sin,pad=0)
-    job=plan_job(t_in,w_in,h_in,t_out,w_out,h_out,1)
+    job=plan_job(t_in,w_in,h_in,t_out,w_out,h_out,srgb)
     if not job.wide: continue
     first=random.randint(0,h_out-1); nr=random.randint(1,h_out-first)
-    a=oracle_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,1,sin,sout,first,nr)
-    b,k=emu_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,1,sin,sout,first,nr)
-    key=(kh,kv,k,job.premul16)
+    a=oracle_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,srgb,sin,sout,first,nr)
+    b,k=emu_scale(src,t_in,w_in,h_in,t_out,w_out,h_out,srgb,sin,sout,first,nr)
+    key=(kh,kv,k,job.premul16,srgb)
     seen[key]=seen.get(key,0)+1
     n+=1
     if not np.array_equal(a,b):
-        bad+=1; print("MISMATCH",kh,kv,"types",t_in,t_out,(w_in,h_in),(w_out,h_out),sin,sout,first,nr,"class",k,"p16",job.premul16,"halv",job.halvings_h,job.halvings_v)
+        bad+=1; print("MISMATCH",kh,kv,"types",t_in,t_out,"srgb",srgb,(w_in,h_in),(w_out,h_out),sin,sout,first,nr,"class",k,"p16",job.premul16,"halv",job.halvings_h,job.halvings_v)
 print("cases",n,"bad",bad)
-for k,v in sorted(seen.items()): print("  ",k,v)
+tp = sum(v for k,v in seen.items() if k[2]==10); print("two-pass (class 10):", tp, " p16:", sum(v for k,v in seen.items() if k[2]==10 and k[3]))
+for k,v in sorted(seen.items()):
+    if k[2] != 10: print("  not two-pass:",k,v)
