@@ -341,3 +341,71 @@ def test_emulated_tile_kernel_box_filters():
         o = rng.randint(1, 60)
         return rng.randint(2 * o + 1, 4 * o), o
     _fuzz_tile(random.Random(77), dims, 60)
+
+
+def test_emulated_mixed_axis_two_pass_road():
+    """k_linh / k_boxh + k_linv / k_boxv (smol_jobdev.h: twopass_setup): 128bpp-class jobs whose axes differ -- one
+    minified and one magnified, a COPY axis, bilinear x box -- gamma-correct (every type pair) and premul16 with and
+    without sRGB, odd strides, row strips. Every (horizontal, vertical) pairing must have gone through the road."""
+    rng = random.Random(1357)
+    seen = set()
+
+    def axis(kind, d_out):
+        if kind == "copy":
+            return d_out
+        if kind == "up":
+            return max(2, int(d_out / rng.uniform(1.05, 9)))
+        if kind == "down":
+            return max(d_out + 1, int(d_out * rng.uniform(1.01, 7.99)))
+        return int(d_out * rng.uniform(8.5, 30)) + 1
+
+    pairs = [("down", "up"), ("up", "down"), ("copy", "down"), ("down", "copy"), ("copy", "up"), ("up", "copy"),
+             ("box", "down"), ("box", "up"), ("box", "copy"), ("down", "box"), ("up", "box"), ("copy", "box")]
+    for it in range(144):
+        kh, kv = pairs[it % len(pairs)]
+        w_out, h_out = rng.choice([2, 3, 7, 40, 65, 130]), rng.choice([2, 5, 17, 33])
+        w_in, h_in = axis(kh, w_out), axis(kv, h_out)
+        if w_in < 2 or h_in < 2 or (kh != "copy" and w_in == w_out) or (kv != "copy" and h_in == h_out):
+            continue
+        srgb = 0 if it % 4 == 3 else 1
+        if srgb:
+            t_in, t_out = rng.randrange(10), rng.randrange(10)
+        else:
+            t_in, t_out = rng.choice([4, 5, 6, 7]), rng.choice([4, 5, 6, 7])
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 4, 16]) * (1 if H.bpp(t_in) == 4 else rng.choice([1, 1, 3]))
+        sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4])
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
+        assert np.array_equal(got, want), (kh, kv, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n, k)
+        if k == 10:
+            seen.add((kh, kv, int(job.premul16)))
+    assert {(a, b) for (a, b, _) in seen} == set(pairs)
+    assert {p for (_, _, p) in seen} == {0, 1}
+
+
+def test_dispatcher_keeps_proportional_resizes_off_the_backstops():
+    """smol_hip_kernel_name(): no size of the reference's proportional benchmark matrix (bench.sh:39-71) -- as it is run,
+    with sRGB, with 24-bit and with unassociated types -- ends in k_general / k_wavepx / k_wtile, bar the one 1:1 copy of
+    the gamma-correct class; jobs with mixed axes in the 128bpp class take the two-pass road."""
+    import smolscale_amd as sm
+
+    def steps_of(w_in, h_in, smin, smax, n):
+        w0, w1, h0, h1 = int(w_in * smin), int(w_in * smax), int(h_in * smin), int(h_in * smax)
+        for s in range(n):
+            yield (min(max(int(w0 + s * (w1 - w0) / (n - 1.0)), 1), 65535), min(max(int(h0 + s * (h1 - h0) / (n - 1.0)), 1), 65535))
+
+    backstops = ("k_general", "k_wavepx", "k_wtile")
+    for (t_in, t_out, srgb) in ((2, 2, 0), (2, 2, 1), (8, 8, 0), (8, 8, 1), (4, 0, 0), (4, 4, 0), (4, 4, 1)):
+        for (w, h, smax) in ((1920, 1080, 2.0), (7680, 4320, 1.0)):
+            bad = [(wo, ho) for (wo, ho) in steps_of(w, h, 0.01, smax, 200)
+                   if (wo, ho) != (w, h) and sm.kernel_name(sm.plan_job(t_in, w, h, t_out, wo, ho, srgb)).startswith(backstops)]
+            assert not bad, (t_in, t_out, srgb, w, h, bad[:3])
+    assert sm.kernel_name(sm.plan_job(0, 4096, 2048, 0, 2731, 3000, 1)) == "k_linh_batch + k_linv_batch"
+    assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 300, 2000, 1)) == "k_boxh_batch + k_linv_batch"
+    assert sm.kernel_name(sm.plan_job(4, 300, 4000, 4, 900, 200, 0)) == "k_linh_batch + k_boxv_batch"
+    assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 2731, 2731, 1)) == "k_lind_batch"
+    assert sm.kernel_name(sm.plan_job(8, 4000, 3000, 8, 1600, 1200, 1)) == "k_lind_batch"
