@@ -198,6 +198,17 @@ __device__ __forceinline__ uint32_t pair_dot (uint32_t hi, uint32_t lo, uint32_t
 #endif
 }
 
+/* the same with the pair already side by side in one register (lo | hi << 16) */
+__device__ __forceinline__ uint32_t pair_word_dot (uint32_t pr, uint32_t w)
+{
+#ifdef SMOL_KERNEL_EMU
+    return (pr & 0xffffu) * (w & 0xffffu) + (pr >> 16) * (w >> 16);
+#else
+    typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+    return __builtin_amdgcn_udot2 (__builtin_bit_cast (us2, pr), __builtin_bit_cast (us2, w), 0u, false);
+#endif
+}
+
 /* unassociated -> premultiplied on a whole pixel word; ain = alpha byte index */
 __device__ __forceinline__ uint32_t premul_word (uint32_t w, uint32_t ain)
 {

@@ -643,10 +643,27 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
     up_static_for<0, UPG_NSRC - 1> ([&] (auto s_const)
     {
         constexpr int s = decltype (s_const)::value;
+        /* 11-bit channels: the rows s and s + 1 of every column side by side, channel by channel -- (top | bottom << 16),
+         * four v_perm per column and row pair -- so that an output pixel's vertical tap is ONE v_dot2_u32_u16 per channel
+         * against the packed weights (F, 256 - F), (top * F + bottom * (256 - F)) >> 8, and comes out unpacked, as the
+         * packer wants it: 4 dot products + 4 shifts per pixel where two packed taps and their unpacking took 16
+         * instructions (gamma-correct x4: 102 -> see profiles/r04_upg_dot2_ab.txt) */
+        uint32_t pr [CPL][4];
+        if (!W32 && r < nrows && (e & 0xffffu) == (uint32_t) s)
+        {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+            {
+                pr [c][0] = __builtin_amdgcn_perm (h [s + 1][c][0], h [s][c][0], PAIR_LO);
+                pr [c][1] = __builtin_amdgcn_perm (h [s + 1][c][0], h [s][c][0], PAIR_HI);
+                pr [c][2] = __builtin_amdgcn_perm (h [s + 1][c][1 % NCH], h [s][c][1 % NCH], PAIR_LO);
+                pr [c][3] = __builtin_amdgcn_perm (h [s + 1][c][1 % NCH], h [s][c][1 % NCH], PAIR_HI);
+            }
+        }
         while (r < nrows && (e & 0xffffu) == (uint32_t) s)
         {
             const uint32_t F = e >> 16, G = 256u - F;
-            const Lerp11W wy = lerp11_weights (F);
+            const uint32_t FG = F | (G << 16);
             uint32_t wv [CPL], vv [CPL][4];
 #pragma unroll
             for (int c = 0; c < CPL; c++)
@@ -659,9 +676,9 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                 }
                 else
                 {
-                    const uint32_t rg = lerp11_pk (h [s][c][0], h [s + 1][c][0], wy);
-                    const uint32_t ba = lerp11_pk (h [s][c][1], h [s + 1][c][1], wy);
-                    vv [c][0] = rg & 0xffffu; vv [c][1] = rg >> 16; vv [c][2] = ba & 0xffffu; vv [c][3] = ba >> 16;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        vv [c][i] = pair_word_dot (pr [c][i], FG) >> 8;
                 }
             }
             /* pack: flavour chosen once per output row and wave (WidePack: the row's 2-4 pixels per lane convert in one

@@ -11,13 +11,13 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 LINE_CFGS="C1 C3 C4 C5 C5mix BOX C2CROP4"
-TABLE=C1,C2,C3,C4,C5,C5mix,BOX,C2CROP4,C2ODD,R1.2,R1.5,R1.7,R1.9,R2.5,R3,R3.5,R5,R6,R7,PHOTO,PNG,R1.5RGB,R1.5U,HDOWNVUP,THUMB,P16,SRGB,P16UP,P16HALF,SRGBUP,SRGBPNGUP,SRGBHALF,SRGBPHOTO,SRGBPNG,SRGBTHUMB,SRGBBOX,BOX128,WIDEBOX
+TABLE=C1,C2,C3,C4,C5,C5mix,BOX,C2CROP4,C2ODD,R1.03,R1.1,R1.2,R1.35,R1.5,R1.7,R1.9,R2.5,R3,R3.5,R5,R6,R7,U1.1,U1.37,U1.5,U2,U2.6,U3,PHOTO,PHOTOODD,PNG,R1.5RGB,R1.5U,HDOWNVUP,THUMB,P16,SRGB,P16UP,P16HALF,SRGBUP,SRGBPNGUP,SRGBHALF,SRGBPHOTO,SRGBPNG,SRGBTHUMB,SRGBBOX,BOX128,WIDEBOX,SRGBHDVU,SRGBVCOPY,SRGBBOXBIL,P16BOXBIL,P16HDVU
 python3 bench.py --steps 50 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt
 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o b --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-e2e > $O/kt_bench.log 2>&1
 for c in $LINE_CFGS; do
   rocprofv3 --kernel-trace --stats -d $O/kt_cfg_$c -o c --output-format csv -- python3 tools/bench_configs.py --iters 20 --warmup 3 --configs $c > $O/kt_cfg_$c.log 2>&1
 done
-python3 tests/bench_configs_checked.py --iters 50 --warmup 3 --configs $TABLE > $O/configs.jsonl 2> $O/configs_err.txt
+SMOL_BENCH_GPU_STATE=1 python3 tests/bench_configs_checked.py --iters 50 --warmup 3 --configs $TABLE > $O/configs.jsonl 2> $O/configs_err.txt
 python3 tests/bench_configs_checked.py --iters 50 --warmup 3 --opaque --configs SRGB,SRGBUP,SRGBHALF,SRGBPNG,SRGBBOX,C5mix > $O/configs_opaque.jsonl 2>> $O/configs_err.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $O/pmc_bench_$c -o p --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --no-e2e > $O/pmc_bench_$c.log 2>&1
@@ -34,7 +34,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" 
   rocprofv3 --pmc $set -d $O/sq_box/p$i -o p --output-format csv -- python3 tools/bench_configs.py --configs BOX --iters 3 --warmup 1 --settle 0.05 > $O/sq_box_log$i.txt 2>&1 || echo "SQ set $i failed"
 done
 # SQ counters of the gamma-correct rows (128bpp class: vector issue against table look-ups)
-for c in SRGB SRGBUP SRGBHALF; do bash tools/sq_counters.sh $TAG $c > /dev/null 2>&1; done
+for c in SRGB SRGBUP SRGBHALF SRGBPHOTO SRGBBOX; do bash tools/sq_counters.sh $TAG $c > /dev/null 2>&1; done
 # (gpurun merges gpurun_out/ back, not profiles/: run the two lines below again in the build container afterwards)
 python3 tools/profile_summary.py $TAG
 python3 tools/roofline_check.py $TAG | tee $O/roofline_check.txt

@@ -188,7 +188,7 @@ with open(os.path.join(P, tag + "_sq_box.txt"), "w") as fh:
         bc, ia = v.get("SQ_LDS_BANK_CONFLICT"), v.get("SQ_LDS_IDX_ACTIVE")
         if bc and ia:
             fh.write("   LDS bank-conflict cycles / LDS active cycles = %.3f\n" % ((sum(bc) / len(bc)) / (sum(ia) / len(ia))))
-for c in ("SRGB", "SRGBUP", "SRGBHALF"):
+for c in ("SRGB", "SRGBUP", "SRGBHALF", "SRGBPHOTO", "SRGBBOX"):
     src = os.path.join(O, "sq_%s.txt" % c)
     if os.path.exists(src):
         open(os.path.join(P, "%s_sq_%s.txt" % (tag, c.lower())), "w").write(open(src).read())
