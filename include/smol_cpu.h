@@ -1,6 +1,7 @@
-/* smol_cpu.h -- C-ABI of the library's CPU backend (a from-scratch AVX2 / AVX-512
- * implementation of the same resampling path, bit-exact with the reference's generic code,
- * smolscale-generic.c:185-2318). It is what smol_scale_*() runs on when the caller selects it with
+/* smol_cpu.h -- C-ABI of the library's CPU backend: a from-scratch implementation of the same
+ * resampling path, bit-exact with the reference's generic code (smolscale-generic.c:185-2318), kept as a CORRECTNESS
+ * fallback -- scalar for every class but 32-bit premultiplied bilinear (packed 16-bit lanes, AVX2 / AVX-512BW chosen
+ * at run time), one thread per call, about half the reference's AVX2 speed per thread. Not a performance path. It is what smol_scale_*() runs on when the caller selects it with
  * SMOL_BACKEND=cpu (or SMOL_BACKEND=auto on a machine without a usable GPU); the default backend
  * stays HIP, and a missing GPU then stays a loud failure. */
 
