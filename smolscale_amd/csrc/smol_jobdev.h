@@ -650,8 +650,6 @@ lind_setup (JobDev &d)
 {
     if (!d.linear || tune_env ("SMOL_NO_LIND"))
         return false;
-    if (d.bpp_in == 4 && !d.in_dword_ok)
-        return false;
     if (d.p16 && (d.bpp_in != 4 || d.bpp_out != 4))
         return false;
 
@@ -876,7 +874,7 @@ box2_is (const JobDev &d)
 inline uint32_t
 box2_tmp_px (const JobDev &d)
 {
-    return (d.box2 == 2 && d.p16 && d.filter_h != F_BOX && d.filter_v != F_BOX) ? 16u : 8u;
+    return (d.box2 == 2 && d.p16 && d.linear && d.filter_h != F_BOX && d.filter_v != F_BOX) ? 16u : 8u;
 }
 
 inline size_t
@@ -950,8 +948,7 @@ box2_h_lds_bytes (const JobDev &d)
  *   pass 2   vertical:   k_boxv (BOX) or k_linv = the vertical + packing half of k_lind (BILINEAR up or down, COPY)
  * A horizontal COPY axis is a bilinear axis at step 1 (every weight is 256 or, at the last sample, 0: the tap returns
  * the pixel itself); a vertical one hands row R of the intermediate image to output row R. Intermediate pixels: 8 bytes
- * (four 16-bit channels) for the 11-bit sRGB-linear flavours and wherever a box pass reads or writes them, 16 bytes
- * (four 32-bit channels) for the premul16 flavours between two k_lin* passes. Gamma-correct and premul16 jobs alike
+ * (four 16-bit channels) everywhere but for premul16 + sRGB between two k_lin* passes (19-bit channels: 16 bytes). Gamma-correct and premul16 jobs alike
  * (the 128bpp class); compressed 128bpp (boxes wider than 255 pixels without sRGB) stays with its own kernels. */
 inline void
 twopass_v_rows (const JobDev &d, uint32_t &y0, uint32_t &y1)
@@ -969,6 +966,11 @@ twopass_v_rows (const JobDev &d, uint32_t &y0, uint32_t &y1)
         y1 = d.first_row + d.n_rows - 1u;
         return;
     }
+    if (d.filter_v == F_ONE)
+    {
+        y0 = y1 = 0;
+        return;
+    }
     /* bilinear: sample j reads rows o (j) and o (j) + 1 */
     auto ofs = [&] (uint64_t j) {
         const uint64_t o = (d.frac0_y + j * d.step_y) >> 32;
@@ -983,22 +985,25 @@ twopass_setup (JobDev &d)
 {
     if (!d.wide || (!d.linear && !d.p16) || d.n_rows == 0 || tune_env ("SMOL_NO_TWOPASS"))
         return false;
-    if (d.bpp_in == 4 && !d.in_dword_ok)
-        return false;
     if (d.p16 && (d.bpp_in != 4 || d.bpp_out != 4))
         return false;
     /* premul16 + sRGB leaves 19-bit channels behind a bilinear horizontal pass: more than k_boxv's 16-bit pixels hold */
     if (d.p16 && d.linear && d.filter_h != F_BOX && d.filter_v == F_BOX)
         return false;
-    const auto usable = [] (uint8_t f) { return f == F_BILINEAR || f == F_COPY || f == F_BOX; };
-    if (!usable (d.filter_h) || !usable (d.filter_v) || (d.filter_h == F_BOX && d.filter_v == F_BOX))
+    if (d.filter_h == F_BOX && d.filter_v == F_BOX)
+        return false;                           /* box2_setup's */
+    if ((d.filter_h == F_BILINEAR && d.w_in < 2) || (d.filter_v == F_BILINEAR && d.h_in < 2))
         return false;
-    if ((d.filter_h != F_BOX && d.w_in < 2) || (d.filter_v == F_BILINEAR && d.h_in < 2))
+    if ((d.filter_h == F_COPY && d.w_in < 2))
         return false;
+    if (d.filter_h == F_ONE && d.bpp_in == 3)
+        return false;                           /* (a row of three bytes: no dword to load a 24-bit pixel with) */
 
     JobDev t = d;
+    /* COPY and ONE axes have no positions of their own: a step of one pixel (COPY), of nothing (ONE) */
     if (t.filter_h == F_COPY) { t.frac0_x = 0; t.step_x = (uint64_t) 1 << 32; t.halv_h = 0; }
-    if (t.filter_v == F_COPY) { t.frac0_y = 0; t.step_y = (uint64_t) 1 << 32; t.halv_v = 0; }
+    if (t.filter_h == F_ONE) { t.frac0_x = 0; t.step_x = 0; t.halv_h = 0; }
+    if (t.filter_v == F_COPY || t.filter_v == F_ONE) { t.frac0_y = 0; t.step_y = (uint64_t) 1 << 32; t.halv_v = 0; }
 
     if (t.filter_h == F_BOX)
     {

@@ -20,7 +20,7 @@ lin_pass_kind (const JobDev &J)
 {
     if (!J.p16)
         return J.bpp_in == 3 ? 1 : 0;
-    return (J.filter_h == smolhip::F_BOX || J.filter_v == smolhip::F_BOX) ? 3 : 2;
+    return (!J.linear || J.filter_h == smolhip::F_BOX || J.filter_v == smolhip::F_BOX) ? 3 : 2;
 }
 
 template <int HX, int KIND>

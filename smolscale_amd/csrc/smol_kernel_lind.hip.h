@@ -89,6 +89,13 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         for (uint32_t s = 0; s < NSX; s++)
         {
             bilin_tap (pos, J.w_in, tap_ofs [c][s], tap_f [c][s]);
+            if (PASS == LIND_H && J.filter_h == F_ONE)
+            {
+                /* an axis of ONE pixel (:1563-1611): every column is pixel 0 -- weight 256 on it, and the neighbour the
+                 * tap also reads is the clamped copy of it in the next slot */
+                tap_ofs [c][s] = 0;
+                tap_f [c][s] = 256;
+            }
             tap_w [c][s] = lerp11_weights (tap_f [c][s]);
             pos += J.step_x;
         }
@@ -97,6 +104,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     uint32_t sx1, f_unused;
     bilin_tap (J.frac0_x + (uint64_t) ((xn << HX) - 1) * J.step_x, J.w_in, sx1, f_unused);
     sx1 += 1;                                                       /* last source pixel of the tile  */
+    if (PASS == LIND_H && J.filter_h == F_ONE)
+        sx1 = 0;
     const uint32_t npx = PASS == LIND_V ? 0u : sx1 - sx0 + 1;       /* pixels per staged row: <= 64 * LIND_KMAX (host) */
 #pragma unroll
     for (int c = 0; c < CPL; c++)
@@ -121,11 +130,11 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                 k = n_samples - 1;
             uint32_t o, f;
             bilin_tap (J.frac0_y + (uint64_t) (jy0 + k) * J.step_y, J.h_in, o, f);
-            if (PASS == LIND_V && J.filter_v == F_COPY)
+            if (PASS == LIND_V && (J.filter_v == F_COPY || J.filter_v == F_ONE))
             {
                 /* a COPY axis: output row R is intermediate row R and nothing else -- the strip's slab of source rows
-                 * holds no neighbour to give weight 0 to (smol_hip_input_row_range) */
-                o = jy0 + k;
+                 * holds no neighbour to give weight 0 to (smol_hip_input_row_range); an axis of ONE row: always row 0 */
+                o = J.filter_v == F_ONE ? 0u : jy0 + k;
                 f = 0;
             }
             sched [q] = o | (f << 16);
@@ -134,7 +143,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
     }
     /* a sample is due when its BOTTOM row has passed: row o + 1 of a bilinear pair, row o itself on a COPY axis */
-    const uint32_t vdue = (PASS == LIND_V && J.filter_v == F_COPY) ? 0u : 1u;
+    const uint32_t vdue = (PASS == LIND_V && (J.filter_v == F_COPY || J.filter_v == F_ONE)) ? 0u : 1u;
     uint32_t oy = e & 0xffffu, Fy = e >> 16;
     const uint32_t row_first = PASS == LIND_H ? J.tmp_row0 + yrel0 : oy;
     const uint32_t row_last = PASS == LIND_H ? (row_first + J.tile_rows - 1u < J.tmp_row1 ? row_first + J.tile_rows - 1u : J.tmp_row1)
@@ -212,8 +221,17 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                     rawpx [k] = *reinterpret_cast<const SMOL_AS_GLOBAL u32a1 *> (srow + px_off [k]);
 #endif
                 }
-                else
+                else if (J.in_dword_ok)
                     rawpx [k] = *reinterpret_cast<const SMOL_AS_GLOBAL uint32_t *> (srow + px_off [k]);
+                else
+                {
+                    /* 32-bit pixels at any byte address (wave-uniform choice): the same unaligned dword load */
+#ifdef SMOL_KERNEL_EMU
+                    __builtin_memcpy (&rawpx [k], srow + px_off [k], 4);
+#else
+                    rawpx [k] = *reinterpret_cast<const SMOL_AS_GLOBAL u32a1 *> (srow + px_off [k]);
+#endif
+                }
             }
         srow += J.src_stride;
     };
@@ -464,8 +482,8 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 
 /* k_linh: blockIdx.x = column tile, the 4 waves of a workgroup take 4 row tiles one below the other (smol_jobdev.h:
  * box2_h_grid); k_linv: 4 tiles per workgroup, numbered row by row.
- * KIND: 0 = 11-bit channels, 32-bit rows; 1 = 11-bit channels, 24-bit rows; 2 = premul16 flavours, 16-byte intermediate
- * pixels; 3 = premul16 without sRGB next to a box pass (8-byte intermediate pixels) */
+ * KIND: 0 = 11-bit channels, 32-bit rows; 1 = 11-bit channels, 24-bit rows; 2 = premul16 + sRGB between two k_lin* passes
+ * (19-bit channels, 16-byte intermediate pixels); 3 = every other premul16 job (8-byte intermediate pixels) */
 template <int HX, int KIND>
 __device__ __forceinline__ void linh_entry (const JobDev &J, uint8_t *lds)
 {
@@ -502,7 +520,9 @@ __device__ __forceinline__ int lin_pass_kind (const JobDev &J)
 {
     if (!J.p16)
         return J.bpp_in == 3 ? 1 : 0;
-    return (J.filter_h == F_BOX || J.filter_v == F_BOX) ? 3 : 2;
+    /* premul16 without sRGB: every value fits 16 bits, whatever the passes; with sRGB (19 bits) only next to a box pass
+     * (whose results the reference masks to 16 bits: smolscale-generic.c:1231-1261) */
+    return (!J.linear || J.filter_h == F_BOX || J.filter_v == F_BOX) ? 3 : 2;
 }
 
 /* pass 1 / pass 2 of the two-pass road for a job's filters (k_boxh / k_boxv stay with their own entries) */

@@ -9,6 +9,7 @@ import smolscale_amd as sm
 random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 3); bad=0; n=0; seen={}
 N=int(sys.argv[2]) if len(sys.argv) > 2 else 150
 def axis(kind, d_out):
+    if kind == "one": return 1
     if kind == "copy": return d_out
     if kind == "up": return max(2, int(d_out / random.uniform(1.05, 9)))
     if kind == "down": return min(65535, max(d_out + 1, int(d_out * random.uniform(1.01, 7.99))))
@@ -16,10 +17,12 @@ def axis(kind, d_out):
 for it in range(N):
     w_out=random.choice([1,2,3,7,40,64,65,130,256,300]); h_out=random.choice([1,2,5,17,33,70])
     kh, kv = random.choice([("down","up"),("up","down"),("copy","down"),("down","copy"),("copy","up"),("up","copy"),
-                            ("box","down"),("box","up"),("box","copy"),("down","box"),("up","box"),("copy","box"),("copy","copy")])
+                            ("box","down"),("box","up"),("box","copy"),("down","box"),("up","box"),("copy","box"),("copy","copy"),
+                            ("one","down"),("one","up"),("down","one"),("up","one"),("one","box"),("box","one"),("one","copy"),("copy","one")])
     w_in, h_in = axis(kh, w_out), axis(kv, h_out)
     if (kh != "copy" and w_in == w_out) or (kv != "copy" and h_in == h_out): continue
-    if w_in < 2 or h_in < 2: continue
+    if (w_in < 2 and kh != "one") or (h_in < 2 and kv != "one"): continue
+    if (kh == "one" and w_out == 1) or (kv == "one" and h_out == 1): continue
     srgb=random.choice([1,1,0])
     if srgb: t_in=random.randrange(10); t_out=random.randrange(10)
     else: t_in=random.choice([4,5,6,7]); t_out=random.choice([4,5,6,7])     # premul16: the 128bpp class without sRGB
