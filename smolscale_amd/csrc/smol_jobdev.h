@@ -75,7 +75,7 @@ struct JobDev
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
     uint8_t box2_vlpc;             /* k_boxv: lanes per output pixel (1 or 8)           */
     uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
-    uint8_t reserved0;             /* (keeps the 16-bit fields below on even offsets)     */
+    uint8_t out_wt;                /* output rows start on 64-byte boundaries: k_tile's stores go out write-through; else write-back (see fill_jobdev) */
     uint8_t dbg;                   /* -DSMOL_TUNING builds only (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores; else 0 */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
@@ -404,6 +404,13 @@ fill_jobdev (JobDev &d, const SmolHipJob &j, const void *src, uint32_t src_strid
     d.wide = j.wide; d.p16 = j.premul16; d.linear = j.linear; d.quirk24 = j.quirk24;
     d.in_dword_ok = (ti.bpp == 4 && (((uintptr_t) src | src_stride) & 3) == 0);
     d.out_dword_ok = (to.bpp == 4 && (((uintptr_t) dst | dst_stride) & 3) == 0);
+    /* Write-through stores keep the output stream out of the L2 -- worth 1-2 % when a wave's kilobyte of output is whole
+     * 128-byte lines. When rows start anywhere (every output width that is not a multiple of 16 pixels: nearly every size
+     * of the reference's sweep) the first and last line of each kilobyte are partial, a write-through of a partial line is
+     * a read-modify-write in memory, and the neighbouring tile does the same to the other part later: 3840x2160 ->
+     * 4185x2354 180 us write-through, 156 us write-back; -> 3724x2094 253 / 221 (profiles/r04_store_policy_ab.txt).
+     * Write-back lets the two parts meet in the L2. */
+    d.out_wt = ((((uintptr_t) dst | dst_stride) & 63) == 0 && !tune_env ("SMOL_TILE_NO_WT")) || tune_env ("SMOL_TILE_WT");
 
     /* byte shuffle from the internal pixel word (bytes in INPUT memory order; a
      * 24bpp input gets alpha = 0xff as byte 3) to the output memory order */

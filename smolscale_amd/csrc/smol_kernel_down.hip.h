@@ -425,7 +425,7 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
                             wide_store_word (J, out_row, xl + c, w [c]);
                     }
                     if (vec)
-                        store_nt128 (out_row + (size_t) xl * 4, u32x4 { w [0], w [1 % CPL], w [2 % CPL], w [3 % CPL] });
+                        store_row128 (out_row + (size_t) xl * 4, u32x4 { w [0], w [1 % CPL], w [2 % CPL], w [3 % CPL] }, J.out_wt);
                 };
                 /* once per output row and wave; all-opaque rows skip the inverse-alpha look-up and multiplies */
                 if ((pk == WP_LIN_P || pk == WP_LIN_U) && smol_wave_all_opaque (all_a))
@@ -462,7 +462,7 @@ __device__ __forceinline__ void down_body (const JobDev &J, uint8_t *lds, const 
                     const u32x4 v = { w [0], w [1 % CPL], w [2 % CPL], w [3 % CPL] };
                     /* non-temporal (this kernel is bound by arithmetic: the write-through asm store and its compiler
                      * barrier cost 66 -> 88 us on the premul16 ratio-1.5 case) */
-                    store_nt128 (out_row + (size_t) xl * 4, v);
+                    store_row128 (out_row + (size_t) xl * 4, v, J.out_wt);
                 }
                 else
                 {

@@ -413,8 +413,10 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                         const uint32_t w = pack (v [c]);
                         if (ok [c])
                         {
-                            if (J.bpp_out == 4 && J.out_dword_ok)
+                            if (J.bpp_out == 4 && J.out_dword_ok && J.out_wt)
                                 __builtin_nontemporal_store (w, reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4));
+                            else if (J.bpp_out == 4 && J.out_dword_ok)
+                                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;    /* rows that start anywhere: write-back (fill_jobdev) */
                             else
                                 wide_store_word (J, out_row, xc [c], w);
                         }

@@ -393,7 +393,7 @@ __device__ __forceinline__ void tile_store (const JobDev &J, uint8_t *rowp, uint
          * non-temporal (C4 189 -> 184 us; the copy-only skeleton of tools/microbench/stagebw.hip shows
          * the same 183 -> 175 us). Strided dword stores (edge tiles of the 4-columns-per-lane
          * variants) must NOT be: partial lines written around the L2 cost ratio 1.5 127 -> 211 us. */
-        if (NT)
+        if (NT && J.out_wt)
             store_out32 (reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4), w);
         else
             *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (gptr (rowp) + (size_t) x * 4) = w;
@@ -493,7 +493,17 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c], inv_tab);
             u32x4 v = { w [0], w [1], w [2], w [3] };
-            store_out128 (gptr (rowp) + (size_t) xl * 4, v);
+            if (J.out_wt)
+                store_out128 (gptr (rowp) + (size_t) xl * 4, v);
+            else
+            {
+                /* rows that start anywhere: write-back, so that the two parts of a shared line meet in the L2 (fill_jobdev) */
+#ifdef SMOL_KERNEL_EMU
+                __builtin_memcpy (gptr (rowp) + (size_t) xl * 4, &v, 16);
+#else
+                *reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (gptr (rowp) + (size_t) xl * 4) = v;
+#endif
+            }
             return;
         }
     }

@@ -1108,6 +1108,21 @@ __device__ __forceinline__ void store_nt128 (gbyte *p, u32x4 v)
 #endif
 }
 
+/* the same, streaming only when the rows start on 64-byte boundaries (`lines': JobDev::out_wt, wave-uniform): rows that
+ * start anywhere share their first and last line with the neighbouring tile, and the two parts should meet in the L2
+ * (write-back) instead of each costing a partial-line write to memory (smol_jobdev.h: fill_jobdev) */
+__device__ __forceinline__ void store_row128 (gbyte *p, u32x4 v, bool lines)
+{
+#if defined (SMOL_KERNEL_EMU)
+    __builtin_memcpy (p, &v, 16);
+#else
+    if (lines)
+        __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p));
+    else
+        *reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p) = v;
+#endif
+}
+
 /* 16-byte write-through output store (see store_out32) */
 __device__ __forceinline__ void store_out128 (gbyte *p, u32x4 v)
 {

@@ -54,6 +54,8 @@ CONFIGS = {
     "S4K65": (2, 3840, 2160, None, 2, 2496, 1404, 19, "sweep point 3840x2160->2496x1404 ARGB8 premul (ratio 1.54), 19 frames"),
     "S4K57": (2, 3840, 2160, None, 2, 2188, 1231, 19, "sweep point 3840x2160->2188x1231 ARGB8 premul (ratio 1.755), 19 frames"),
     "S4K110": (2, 3840, 2160, None, 2, 4224, 2376, 12, "sweep point 3840x2160->4224x2376 ARGB8 premul (magnify x1.1), 12 frames"),
+    "S4K109ODD": (2, 3840, 2160, None, 2, 4185, 2354, 12, "sweep point 3840x2160->4185x2354 ARGB8 premul (magnify x1.09, odd width: rows start on 4-byte boundaries only), 12 frames"),
+    "S4K91ODD": (2, 3840, 2160, None, 2, 3494, 1965, 12, "sweep point 3840x2160->3494x1965 ARGB8 premul (ratio 1.099, rows of 13976 bytes), 12 frames"),
     "S4K140": (2, 3840, 2160, None, 2, 5376, 3024, 12, "sweep point 3840x2160->5376x3024 ARGB8 premul (magnify x1.4), 12 frames"),
     "S4K176": (2, 3840, 2160, None, 2, 6758, 3801, 19, "sweep point 3840x2160->6758x3801 ARGB8 premul (magnify x1.76), 19 frames"),
     "S4K193": (2, 3840, 2160, None, 2, 7411, 4168, 19, "sweep point 3840x2160->7411x4168 ARGB8 premul (magnify x1.93), 19 frames"),
@@ -91,6 +93,9 @@ CONFIGS = {
     "SRGB": (0, 4096, 4096, None, 0, 1024, 1024, 4, "4096^2->1024^2 RGBA8 premul with_srgb=1 (linear, 128bpp class), 4 frames", 1),
     "P16UP": (4, 1920, 1080, None, 4, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 unassociated->unassociated (premul16 magnify), 2 frames"),
     "SRGBUP": (0, 1920, 1080, None, 0, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 premul with_srgb=1 (linear magnify), 2 frames", 1),
+    "SRGBUPODD": (0, 1920, 1080, None, 0, 4993, 2809, 4, "1920x1080->4993x2809 RGBA8 premul with_srgb=1 (linear magnify x2.6, output rows start on 4-byte boundaries only), 4 frames", 1),
+    "P16UPODD": (4, 1920, 1080, None, 4, 4993, 2809, 4, "1920x1080->4993x2809 rgbA->rgbA (premul16 magnify x2.6, odd width), 4 frames"),
+    "P16HALFODD": (4, 4096, 4096, None, 4, 2733, 2733, 2, "4096^2->2733^2 unassociated->unassociated (premul16, ratio 1.5, odd width), 2 frames"),
     "P16HALF": (4, 4096, 4096, None, 4, 2731, 2731, 2, "4096^2->2731^2 unassociated->unassociated (premul16, ratio 1.5), 2 frames"),
     "SRGBPNGUP": (4, 1920, 1080, None, 4, 7680, 4320, 2, "1920x1080->7680x4320 rgbA->rgbA with_srgb=1 (premul16 + linear magnify), 2 frames", 1),
     "THUMB": (8, 4000, 3000, None, 8, 200, 150, 16, "4000x3000 RGB8 -> 200x150 RGB8 (BOX ratio 20, 64bpp class), 16 frames"),
