@@ -130,6 +130,46 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                     acc [i] += ((c [i] * fr) >> 8) & 0x00ffffffu;
             }
             off = int_ofs + mis;
+            constexpr int UK0 = std::remove_reference_t<decltype (un)>::KIND;
+            if (UK0 == WU_LIN_O && bpp == 3)
+            {
+                /* Gamma-correct 24-bit rows (photographs -> thumbnails): every byte of the span goes through the SAME
+                 * 256-entry table (opaque pixels: one fused look-up per channel), so the interior is a stream of bytes.
+                 * Groups of 4 pixels = 12 bytes = 3 dwords, realigned to the lane's first interior byte with three
+                 * v_alignbyte (as the 64bpp class does for its dot products): 12 x (v_bfe, address, look-up, add) per
+                 * group, no per-pixel extraction, no per-pixel select; the 0-3 pixels left over are one more group with
+                 * the bytes past the span masked to 0, which the table maps to 0. The sums are kept per byte POSITION
+                 * (0, 1, 2 of a pixel) and handed to the channels at the end. Gamma-correct photo thumbnails
+                 * 192 -> see profiles/r04_boxh24_ab.txt. */
+                const uint32_t ngrp = n_int >> 2;
+                uint32_t s0 = 0, s1 = 0, s2 = 0;
+                const uint32_t sh = off & 3u;
+                const uint32_t *pp = reinterpret_cast<const uint32_t *> (rowb + (off & ~3u));
+                for (uint32_t g = 0; g <= J.box_nmax; g += 4, pp += 3)
+                {
+                    if ((g >> 2) <= ngrp)
+                    {
+                        const uint32_t q0 = pp [0], q1 = pp [1], q2 = pp [2], q3 = pp [3];
+                        uint32_t d0 = __builtin_amdgcn_alignbyte (q1, q0, sh);
+                        uint32_t d1 = __builtin_amdgcn_alignbyte (q2, q1, sh);
+                        uint32_t d2 = __builtin_amdgcn_alignbyte (q3, q2, sh);
+                        if ((g >> 2) == ngrp)
+                        {
+                            d0 &= rem_mask0; d1 &= rem_mask1; d2 &= rem_mask2;
+                        }
+                        /* bytes 0 .. 11 of the group: positions 0 1 2 0 | 1 2 0 1 | 2 0 1 2 */
+                        s0 += lut.opaque_lin (d0 & 0xffu) + lut.opaque_lin (d0 >> 24) + lut.opaque_lin ((d1 >> 16) & 0xffu) + lut.opaque_lin ((d2 >> 8) & 0xffu);
+                        s1 += lut.opaque_lin ((d0 >> 8) & 0xffu) + lut.opaque_lin (d1 & 0xffu) + lut.opaque_lin (d1 >> 24) + lut.opaque_lin ((d2 >> 16) & 0xffu);
+                        s2 += lut.opaque_lin ((d0 >> 16) & 0xffu) + lut.opaque_lin ((d1 >> 8) & 0xffu) + lut.opaque_lin (d2 & 0xffu) + lut.opaque_lin (d2 >> 24);
+                    }
+                }
+                auto at_pos = [&] (uint32_t pos) { return pos == 0 ? s0 : pos == 1 ? s1 : s2; };       /* (pos is wave-uniform) */
+                acc [0] += at_pos (J.pos_in [0]);
+                acc [1] += at_pos (J.pos_in [1]);
+                acc [2] += at_pos (J.pos_in [2]);
+                acc [3] += 255u * n_int;
+            }
+            else
             /* interior pixels four at a time, converted in one branch-free block (`un': the conversion's flavour, fixed
              * per wave); a pixel past the lane's share is a zero word with its channels masked off */
             for (uint32_t k = 0; k < J.box_nmax; k += 4)
