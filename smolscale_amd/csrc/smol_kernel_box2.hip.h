@@ -175,9 +175,11 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
             for (uint32_t k = 0; k < J.box_nmax; k += 4)
             {
                 uint32_t w4 [4], c4 [4][4];
+                /* (a pixel past the lane's share is the neighbouring column's: staged bytes, converted for nothing and
+                 * masked off below -- cheaper than a select per pixel in front of the read) */
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++)
-                    w4 [u] = (k + u < n_int) ? box2_px_word<AL> (J, rowb, off + u * bpp) : 0u;
+                    w4 [u] = box2_px_word<AL> (J, rowb, off + u * bpp);
                 constexpr int UK = std::remove_reference_t<decltype (un)>::KIND;
                 bool opaque = false;
                 if constexpr (UK == WU_LIN_P || UK == WU_LIN_U)
@@ -207,13 +209,25 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                     for (uint32_t u = 0; u < 4; u++)
                         un (w4 [u], c4 [u]);
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < 4; u++)
+                if (k + 4u <= n_int)
                 {
-                    const uint32_t m = (k + u < n_int) ? 0xffffffffu : 0u;
+                    /* a whole group of the lane's share: no masks */
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        acc [i] += c4 [u][i] & m;
+                    for (uint32_t u = 0; u < 4; u++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            acc [i] += c4 [u][i];
+                }
+                else
+                {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                    {
+                        const uint32_t m = (k + u < n_int) ? 0xffffffffu : 0u;
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            acc [i] += c4 [u][i] & m;
+                    }
                 }
                 off += 4u * bpp;
             }
