@@ -6,7 +6,6 @@
 
 #include <stdint.h>
 #include <string.h>
-#include <stdio.h>
 #include <stdlib.h>
 
 #include "smol_hip.h"
@@ -74,7 +73,7 @@ struct JobDev
     uint8_t up_wide;               /* k_up: 0 64bpp class, 1 premul16 fast path, 2 table-driven 16-bit channels, 3 table-driven 32-bit */
     uint8_t box2;                  /* this job runs as k_boxh + k_boxv (two passes)     */
     uint8_t box2_vlpc;             /* k_boxv: lanes per output pixel (1 or 8)           */
-    uint8_t down_mode;             /* k_down: 0 premul16 fast path, 1 table-driven 16-bit channels, 2 table-driven 32-bit */
+    uint8_t down_mode;             /* KC_DOWN: 3 = k_lind (the only kernel of the class since round 4) */
     uint8_t out_wt;                /* output rows start on 64-byte boundaries: k_tile's stores go out write-through; else write-back (see fill_jobdev) */
     uint8_t dbg;                   /* -DSMOL_TUNING builds only (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores; else 0 */
     uint16_t tile_rows;            /* output rows per tile                               */
@@ -633,11 +632,9 @@ up_blocks (const JobDev &d)
     return (n + 7u) & ~7u;
 }
 
-/* k_down: bilinear minification on both axes (0-2 halvings) for the 128bpp class.
- * Mode 0: premul16 without sRGB on 4-byte aligned 32-bit rows (table-free unpack);
- * mode 1: any other job whose channels fit 16 bits (sRGB-linear with 8-bit alpha);
- * mode 2: premul16 + sRGB-linear (19-bit channels). Modes 1-2 take any input type
- * and alignment and run 4 waves per workgroup around one LDS copy of the tables. */
+/* KC_DOWN: bilinear minification on both axes (0-2 halvings) for the 128bpp class = k_lind (smol_kernel_lind.hip.h):
+ * premul16 with and without sRGB, the sRGB-linear flavours, 32- and 24-bit rows at any byte alignment. 4 waves per
+ * workgroup around one LDS copy of the tables. */
 constexpr uint32_t DOWN_LUT_BYTES = (SMOL_LUT_LDS_BYTES + 15) & ~15u;
 
 /* k_lind (mode 3): the gamma-correct flavours of mode 1 -- sRGB-linear, 11-bit channels -- on 24-bit rows (any
@@ -655,10 +652,10 @@ lind_span (const JobDev &d, uint32_t w)
 inline bool
 lind_setup (JobDev &d)
 {
-    if (!d.linear || tune_env ("SMOL_NO_LIND"))
-        return false;
-    if (d.p16 && (d.bpp_in != 4 || d.bpp_out != 4))
-        return false;
+    if (!d.linear && !d.p16)
+        return false;                           /* (compressed 128bpp never meets a bilinear axis) */
+    if (d.p16 && d.bpp_in != 4)
+        return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */
 
     uint32_t best_w = 0;
     double best = 0.0;
@@ -696,8 +693,6 @@ lind_setup (JobDev &d)
         th = 128u >> d.halv_v;
     if (th < 1)
         th = 1;
-    if (tune_env ("SMOL_LIND_DEBUG"))
-        printf ("lind: %ux%u -> %ux%u bpp %u halv %u W %u span %u eff %.3f\n", d.w_in, d.h_in, d.w_out, d.h_out, d.bpp_in, d.halv_h, best_w, (unsigned) lind_span (d, best_w), best);
     d.group_rows = (uint16_t) best_w;
     d.span_px = (uint32_t) lind_span (d, best_w);
     d.tile_rows = (uint16_t) th;
@@ -716,70 +711,20 @@ down_setup (JobDev &d)
         return false;
     if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_DOWN"))
         return false;
-
-    const bool aligned32 = d.bpp_in == 4 && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0;
-    uint32_t mode;
-    if (d.p16 && !d.linear && aligned32)
-        mode = 0;
-    else if (d.p16)
-        mode = 2;                               /* 16- to 19-bit channels (premul16 + sRGB; premul16 on unaligned rows) */
-    else
-        mode = 1;                               /* channels of at most 11 bits: packed taps */
-    if (mode && tune_env ("SMOL_NO_DOWN_GEN"))
-        return false;
-    if ((mode == 1 || (mode == 2 && d.linear)) && lind_setup (d))
-        return true;                            /* mode 3: k_lind (smol_kernel_lind.hip.h) */
-
-    /* one sample per column and a wide enough image: 4 columns per lane (premul16 fast path). The 11-bit table-driven
-     * flavour has the same variant compiled in (SMOL_DOWNG_CPL4 in tuning builds) but keeps one column: with four its
-     * two row buffers take 8 KiB per wave, 4 waves per SIMD instead of 8 stay resident and the gamma-correct ratio-1.5
-     * row goes 97 -> 116 us (profiles/r03h_downg_cpl4_ab.txt) -- the kernel lives on covering its table look-ups'
-     * latency with other waves */
-    const uint32_t cpl = (d.halv_h == 0 && d.w_out >= 256 && !tune_env ("SMOL_DOWN_CPL1")
-                          && (mode == 0 || (mode == 1 && tune_env ("SMOL_DOWNG_CPL4")))) ? 4 : 1;
-
-    /* source pixels a tile can reach, rounded up to whole 4-pixel chunks */
-    uint64_t span = ((((uint64_t) (64u * cpl) << d.halv_h) * d.step_x) >> 32) + 3;
-    if (span > d.w_in)
-        span = d.w_in;
-    span = (span + 3 + 4) & ~(uint64_t) 3;
-    if (span > 64u * 4u * 3u)
-        return false;                           /* more than DOWN_NL loads per lane and row */
-    d.span_px = (uint32_t) span;
-
-    /* flat tiles again (profiles/r02o_down_tile_rows.txt): 8 rows without vertical halvings, 4 with --
-     * premul16 ratio 1.5 65 -> 60 us, sRGB-linear ratio 1.5 120 -> 111, gamma-correct photo 133 -> 126 */
-    uint32_t th = d.halv_v ? 4u : 8u;           /* <= 128 vertical samples per tile */
-    if (const char *e = tune_env ("SMOL_DOWN_ROWS"))
-        th = (uint32_t) atoi (e);
-    if (th > (128u >> d.halv_v))
-        th = 128u >> d.halv_v;
-    if (th < 1)
-        th = 1;
-    d.tile_rows = (uint16_t) th;
-    d.tile_cpl = (uint8_t) cpl;
-    d.up_wide = 1;
-    d.down_mode = (uint8_t) mode;
-    return true;
+    return lind_setup (d);
 }
 
-/* tiles of the job (modes 1-2 launch one workgroup per 4 tiles) */
+/* tiles of the job (a workgroup takes 4) */
 inline uint32_t
 down_blocks (const JobDev &d)
 {
-    const uint32_t tw = d.down_mode == 3 ? d.group_rows : 64u * d.tile_cpl;
-    return ((d.w_out + tw - 1u) / tw) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
+    return ((d.w_out + d.group_rows - 1u) / d.group_rows) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
 }
 
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
-    if (d.down_mode == 3)                                   /* the tables + a row buffer per wave */
-        return DOWN_LUT_BYTES + 4u * (64u * LIND_KMAX_HOST * (d.p16 ? 16u : 8u)) + 16u;
-    const uint32_t pitch = (d.span_px * (d.down_mode == 2 ? 16u : 8u) + 15u) & ~15u;
-    if (d.down_mode)
-        return DOWN_LUT_BYTES + 4u * 2u * pitch + 16u;      /* the tables + two row buffers per wave */
-    return 2u * pitch + 1024u + 16u;                        /* two row buffers + the inverse table */
+    return DOWN_LUT_BYTES + 4u * (64u * LIND_KMAX_HOST * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
 }
 
 /* host twin of the device box_span (smol_kernels.hip.h; closed form of smolscale.c's box precalc) */
@@ -992,8 +937,8 @@ twopass_setup (JobDev &d)
 {
     if (!d.wide || (!d.linear && !d.p16) || d.n_rows == 0 || tune_env ("SMOL_NO_TWOPASS"))
         return false;
-    if (d.p16 && (d.bpp_in != 4 || d.bpp_out != 4))
-        return false;
+    if (d.p16 && d.bpp_in != 4)
+        return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */
     /* premul16 + sRGB leaves 19-bit channels behind a bilinear horizontal pass: more than k_boxv's 16-bit pixels hold */
     if (d.p16 && d.linear && d.filter_h != F_BOX && d.filter_v == F_BOX)
         return false;
@@ -1142,7 +1087,7 @@ kclass_name (KClass k, const JobDev &d)
         case KC_POW2: return "k_pow2_batch";
         case KC_POW2X: return "k_pow2x_batch";
         case KC_UP: return d.up_wide >= 2 ? "k_upg_batch" : "k_up_batch";
-        case KC_DOWN: return d.down_mode == 3 ? "k_lind_batch" : d.down_mode ? "k_downg_batch" : "k_down_batch";
+        case KC_DOWN: return "k_lind_batch";
         case KC_BOX2: return d.box2 != 2 ? "k_boxh_batch + k_boxv_batch"
                              : twopass_lin_h (d) ? (twopass_lin_v (d) ? "k_linh_batch + k_linv_batch" : "k_linh_batch + k_boxv_batch")
                                                  : "k_boxh_batch + k_linv_batch";

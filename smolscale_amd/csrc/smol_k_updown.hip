@@ -1,4 +1,4 @@
-/* smol_k_updown.hip -- kernel instantiations + launch wrappers of the k_up / k_down (magnification; 128bpp-class minification) family (gfx950).
+/* smol_k_updown.hip -- kernel instantiations + launch wrappers of the k_up / k_lind (magnification; 128bpp-class minification) family (gfx950).
  * One translation unit per kernel family so that `make -j' compiles them side by
  * side; the runtime (smol_rt_*.hip) only sees smol_launch.h. */
 
@@ -13,45 +13,6 @@
 using smolhip::JobDev;
 
 namespace {
-
-/* k_down: one entry point per horizontal mode (halvings 0-2 | 3 = four columns per lane) */
-template <int HC>
-void
-launch_down_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_down_batch<HC>), grid, dim3 (64), lds, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_down_one<HC>), grid, dim3 (64), lds, s, rep);
-}
-
-/* table-driven k_down flavours: one entry point per (horizontal halvings, mode) */
-template <int HX, int MODE>
-void
-launch_downg_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_downg_batch<HX, MODE>), grid, dim3 (256), lds, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_downg_one<HX, MODE>), grid, dim3 (256), lds, s, rep);
-}
-
-template <int MODE>
-void
-launch_downg_m (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    if (MODE == smolhip::DOWN_GEN16 && rep.tile_cpl == 4)
-    {
-        launch_downg_k<MODE == smolhip::DOWN_GEN16 ? 3 : 0, MODE> (jobs_dev, rep, grid, lds, s);
-        return;
-    }
-    switch (rep.halv_h)
-    {
-        case 0:  launch_downg_k<0, MODE> (jobs_dev, rep, grid, lds, s); break;
-        case 1:  launch_downg_k<1, MODE> (jobs_dev, rep, grid, lds, s); break;
-        default: launch_downg_k<2, MODE> (jobs_dev, rep, grid, lds, s); break;
-    }
-}
 
 /* k_lind: one entry point per (horizontal halvings, input kind: 0 = 32-bit rows, 1 = 24-bit rows, 2 = premul16 + linear) */
 template <int HX, int IN>
@@ -109,36 +70,17 @@ launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds
 namespace smolhip {
 namespace launch {
 
-/* grid.x counts tiles; the table-driven flavours run 4 tiles (4 waves) per workgroup */
+/* grid.x counts tiles; a workgroup runs 4 of them (4 waves) */
 void
 down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
-    if (rep.down_mode)
-    {
-        grid.x = (grid.x + 3) / 4;
-        if (rep.down_mode == 3)
-        {
-            if (rep.p16)
-                launch_lind<2> (jobs_dev, rep, grid, lds, s);
-            else if (rep.bpp_in == 3)
-                launch_lind<1> (jobs_dev, rep, grid, lds, s);
-            else
-                launch_lind<0> (jobs_dev, rep, grid, lds, s);
-        }
-        else if (rep.down_mode == 2)
-            launch_downg_m<smolhip::DOWN_GEN32> (jobs_dev, rep, grid, lds, s);
-        else
-            launch_downg_m<smolhip::DOWN_GEN16> (jobs_dev, rep, grid, lds, s);
-        return;
-    }
-    if (rep.tile_cpl == 4)
-        launch_down_k<3> (jobs_dev, rep, grid, lds, s);
-    else if (rep.halv_h == 0)
-        launch_down_k<0> (jobs_dev, rep, grid, lds, s);
-    else if (rep.halv_h == 1)
-        launch_down_k<1> (jobs_dev, rep, grid, lds, s);
+    grid.x = (grid.x + 3) / 4;
+    if (rep.p16)
+        launch_lind<2> (jobs_dev, rep, grid, lds, s);
+    else if (rep.bpp_in == 3)
+        launch_lind<1> (jobs_dev, rep, grid, lds, s);
     else
-        launch_down_k<2> (jobs_dev, rep, grid, lds, s);
+        launch_lind<0> (jobs_dev, rep, grid, lds, s);
 }
 
 void

@@ -1,7 +1,8 @@
-/* smol_kernel_lind.hip.h -- k_lind: gamma-correct (sRGB-linear, 11-bit channels) bilinear MINIFICATION on both axes,
- * 0-2 halvings each: the with_srgb photo / PNG downscale (unpack smolscale-generic.c:481-535, 588-614; horizontal
- * :1290-1425; vertical :1648-2007; pack :922-935, 1010-1023, 1096-1134). Round 4's successor of k_downg<*, DOWN_GEN16>
- * (smol_kernel_down.hip.h), which stays for 32-bit rows that are not dword aligned.
+/* smol_kernel_lind.hip.h -- k_lind: bilinear MINIFICATION on both axes in the 128bpp class, 0-2 halvings each:
+ * gamma-correct (sRGB-linear, 11-bit channels; the with_srgb photo / PNG downscale), premul16 and premul16 + sRGB
+ * (32-bit channels) (unpack smolscale-generic.c:481-535, 588-614; horizontal :1290-1425; vertical :1648-2007; pack
+ * :922-935, 1010-1023, 1096-1134). Round 4's successor of k_down and k_downg, which it replaced on every row; its three
+ * row passes also serve the mixed-axis roads (k_linh, k_linv below).
  *
  * What the old kernel's counters said (profiles/r03final_sq_srgbhalf.txt): 102 vector lane-operations per SOURCE pixel
  * where the arithmetic needs about 50, and 0.59 scalar instructions per vector one. The lanes were there, idle: a tile
@@ -17,7 +18,7 @@
  *           flight in registers while row r is filtered. A 24-bit pixel is ONE dword load at its own byte address
  *           (global loads need no alignment on gfx950; the row's last pixel is read one byte early and shifted, so
  *           that nothing past the row is touched).
- *   H, V    packed 16-bit taps (lerp11_pk), the vertical schedule read back with v_readlane, as in k_down.
+ *   H, V    packed 16-bit taps (lerp11_pk), the vertical schedule read back with v_readlane.
  *   pack    WidePack, flavour fixed per output row (opaque rows skip the inverse-alpha look-up).
  *
  * No branch depends on a lane: the only masks are on the stores of a tile's partial last columns. */
@@ -177,7 +178,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
 #pragma unroll
         for (int i = 0; i < NCH; i++)
             tmp_in [c][i] = 0;
-    const gbyte *trow = gptr (J.tmp) + (size_t) (row_first - J.tmp_row0) * J.w_out * TPX;  /* LIND_H: row being written; LIND_V: row being loaded */
+    /* LIND_H: row being written; LIND_V: row being loaded (the fused kernel has no intermediate image) */
+    const gbyte *trow = PASS == LIND_FUSED ? nullptr : gptr (J.tmp) + (size_t) (row_first - J.tmp_row0) * J.w_out * TPX;
 
     auto load_row = [&] ()
     {

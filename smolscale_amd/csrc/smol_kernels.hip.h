@@ -20,8 +20,8 @@
  *                     and for the 128bpp class (smol_kernel_pow2x.hip.h).
  *   k_up<IN,OUT>      bilinear magnification on both axes, organised around the
  *                     stores (smol_kernel_up.hip.h).
- *   k_down<W16,HX>    bilinear minification on both axes for 32-bit pixels on aligned
- *                     rows, 64bpp class and premul16 (smol_kernel_down.hip.h).
+ *   k_lind<HX,IN>     bilinear minification on both axes for the 128bpp class
+ *                     (smol_kernel_lind.hip.h).
  *   k_tile / k_wtile  LDS-tiled kernels for arbitrary ratios (smol_kernel_tile.hip.h,
  *                     smol_kernel_wtile.hip.h).
  */
@@ -1098,7 +1098,7 @@ typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 typedef u32x4 u32x4a4 __attribute__ ((aligned (4)));       /* a 16-byte load unit on a 4-byte boundary (cropped images) */
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
 
-/* 16-byte NON-TEMPORAL output store on a dword-aligned address (the store-bound kernels: k_up, k_down) */
+/* 16-byte NON-TEMPORAL output store on a dword-aligned address (the store-bound kernels: k_up, k_lind) */
 __device__ __forceinline__ void store_nt128 (gbyte *p, u32x4 v)
 {
 #if defined (SMOL_KERNEL_EMU)

@@ -148,7 +148,7 @@ def test_emulated_up_kernel_table_driven_flavours():
 
 
 def test_emulated_down_kernel_premul16_minification():
-    """k_down: unassociated -> unassociated (premul16) bilinear minification, ratios
+    """k_lind: unassociated -> unassociated (premul16) bilinear minification, ratios
     1..8 per axis (0-2 halvings), 1 and 4 columns per lane, row slabs, padded strides."""
     rng = random.Random(4242)
     hits = 0
@@ -173,7 +173,7 @@ def test_emulated_down_kernel_premul16_minification():
 
 
 def test_emulated_down_kernel_table_driven_flavours():
-    """k_down modes 1 and 2: sRGB-linear (11-bit channels) and premul16 + sRGB (19-bit),
+    """k_lind: sRGB-linear (11-bit channels) and premul16 + sRGB (19-bit),
     every input/output type incl. 24-bit, byte-aligned rows."""
     rng = random.Random(999)
     kinds = set()

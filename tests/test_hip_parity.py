@@ -235,7 +235,7 @@ def test_up_kernel_magnification_shapes():
 
 
 def test_down_kernel_premul16_minification_shapes():
-    """k_down: unassociated -> unassociated minification at arbitrary ratios (0-2 halvings
+    """k_lind: unassociated -> unassociated minification at arbitrary ratios (0-2 halvings
     per axis, 1 and 4 columns per lane), host pointers and misaligned device buffers."""
     shapes = [
         (4, 4096, 300, 4, 2731, 200), (5, 1000, 700, 6, 333, 100), (7, 2000, 64, 4, 260, 9),
@@ -273,7 +273,7 @@ def test_up_kernel_srgb_linear_flavours():
 
 
 def test_down_kernel_srgb_linear_flavours():
-    """k_down modes 1 and 2 (with_srgb = 1): premultiplied, unassociated
+    """k_lind (with_srgb = 1): premultiplied, unassociated
     and 24-bit types, odd strides, misaligned device buffers."""
     shapes = [
         (0, 4096, 300, 0, 2731, 200), (8, 4000, 90, 8, 1600, 36), (4, 1000, 700, 6, 333, 100),
@@ -294,8 +294,8 @@ def test_down_kernel_srgb_linear_flavours():
 def test_gamma_correct_kernels_on_opaque_images_and_on_a_translucent_block():
     """with_srgb = 1 on what gamma-correct scaling is used for -- photographs with an alpha channel. Every wave of an
     all-opaque image takes the fused one-look-up conversions (WU_LIN_O / WP_LIN_O, chosen per wave by a ballot: per row
-    in k_downg, per batch in k_upg / k_pow2x, per group with hysteresis in k_boxh); with one translucent block in the
-    image the waves over its border decide batch by batch. 4:1 (k_pow2x), x3 (k_upg), ratios 1.5 and 2.5 (k_downg), box
+    in k_lind, per batch in k_upg / k_pow2x, per group with hysteresis in k_boxh); with one translucent block in the
+    image the waves over its border decide batch by batch. 4:1 (k_pow2x), x3 (k_upg), ratios 1.5 and 2.5 (k_lind), box
     ratios 9 and 20 (k_boxh + k_boxv); premultiplied, unassociated and 24-bit destinations; host and device entries."""
     shapes = [(1024, 256, 256, 64), (200, 60, 600, 180), (900, 300, 600, 200), (1000, 250, 400, 100),
               (1800, 180, 200, 20), (2000, 400, 100, 20)]
@@ -368,7 +368,7 @@ def test_workgroups_with_more_than_64k_of_lds():
         (4, 2000, 100, 4, 2050, 110, 1),    # k_upg<32>, mild magnification
         (0, 4000, 600, 0, 64, 10, 0),       # k_boxh, 64bpp class, ratio 62
         (0, 4000, 600, 0, 64, 10, 1),       # k_boxh, 128bpp class, ratio 62
-        (8, 4000, 100, 8, 3990, 99, 1),     # k_downg, mild minification
+        (8, 4000, 100, 8, 3990, 99, 1),     # k_lind, mild minification
     ]
     for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in enumerate(cases):
         src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, pad=0)

@@ -1,4 +1,4 @@
-"""Emulated k_down vs oracle: minification on both axes (ratios 1..8), 32-bit inputs, 64bpp class and premul16."""
+"""Emulated k_tile / k_lind vs oracle: minification on both axes (ratios 1..8), 32-bit inputs, 64bpp class and premul16."""
 import sys, random
 sys.path.insert(0, "tests")
 import numpy as np

@@ -1,4 +1,4 @@
-"""Emulated k_down (all modes) vs oracle: 128bpp-class minification, any types, srgb on/off, any alignment."""
+"""Emulated k_lind vs oracle: 128bpp-class minification, any types, srgb on/off, any alignment."""
 import sys, random
 sys.path.insert(0, "tests")
 import numpy as np
