@@ -637,10 +637,9 @@ up_blocks (const JobDev &d)
  * workgroup around one LDS copy of the tables. */
 constexpr uint32_t DOWN_LUT_BYTES = (SMOL_LUT_LDS_BYTES + 15) & ~15u;
 
-/* k_lind (mode 3): the gamma-correct flavours of mode 1 -- sRGB-linear, 11-bit channels -- on 24-bit rows (any
- * alignment) and dword-aligned 32-bit rows. Picks the tile width W <= 128 (in group_rows) so that the span of source
- * pixels a tile reaches just fills whole conversion rounds of 64 pixels: K rounds hold 64 K pixels, a tile of W columns
- * reaches at most ((W << h) - 1) * step + 3 of them. */
+/* k_lind's tile width W <= 128 (in group_rows): chosen so that the span of source pixels a tile reaches just fills
+ * whole conversion rounds of 64 pixels -- K rounds hold 64 K pixels, a tile of W columns reaches at most
+ * ((W << h) - 1) * step + 3 of them. */
 constexpr uint32_t LIND_KMAX_HOST = 5;
 
 inline uint64_t
@@ -649,14 +648,9 @@ lind_span (const JobDev &d, uint32_t w)
     return ((((uint64_t) (w << d.halv_h) - 1u) * d.step_x) >> 32) + 3u;
 }
 
-inline bool
-lind_setup (JobDev &d)
+inline uint32_t
+lind_pick_width (const JobDev &d)
 {
-    if (!d.linear && !d.p16)
-        return false;                           /* (compressed 128bpp never meets a bilinear axis) */
-    if (d.p16 && d.bpp_in != 4)
-        return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */
-
     uint32_t best_w = 0;
     double best = 0.0;
     for (uint32_t k = 1; k <= LIND_KMAX_HOST; k++)
@@ -673,45 +667,78 @@ lind_setup (JobDev &d)
             else
                 hi = mid - 1;
         }
-        /* slots used in the conversion rounds x lanes used by the filters, both of which scale the tile's cost */
+        /* slots used in the conversion rounds x lanes used by the filters, both of which scale the tile's cost; a
+         * magnifying axis converts few pixels per tile: there the lanes the filters keep busy decide alone */
         const double eff = ((double) lind_span (d, lo) / (64.0 * k)) * ((double) lo / (lo > 64 ? 128.0 : 64.0));
-        if (eff > best + 1e-9)
+        const double score = d.step_x < ((uint64_t) 1 << 32) ? (double) lo : eff;
+        if (score > best + 1e-9)
         {
-            best = eff;
+            best = score;
             best_w = lo;
         }
     }
     if (const char *e = tune_env ("SMOL_LIND_W"))
         best_w = (uint32_t) atoi (e);
     if (best_w < 16 || best_w > 128 || lind_span (d, best_w) > 64u * LIND_KMAX_HOST)
-        return false;
-
-    uint32_t th = d.halv_v ? 4u : 8u;           /* <= 128 vertical samples per tile */
-    if (const char *e = tune_env ("SMOL_DOWN_ROWS"))
-        th = (uint32_t) atoi (e);
-    if (th > (128u >> d.halv_v))
-        th = 128u >> d.halv_v;
-    if (th < 1)
-        th = 1;
-    d.group_rows = (uint16_t) best_w;
-    d.span_px = (uint32_t) lind_span (d, best_w);
-    d.tile_rows = (uint16_t) th;
-    d.tile_cpl = 2;
-    d.up_wide = 1;
-    d.down_mode = 3;
-    return true;
+        return 0;
+    return best_w;
 }
 
+/* KC_DOWN = k_lind, both axes in one kernel: every 128bpp-class job without a box axis that k_up (magnification on
+ * both axes) has not taken -- bilinear minification with 0-2 halvings on both axes (the case the kernel was built for),
+ * and the jobs whose axes differ: one minifying and one magnifying, or one of them COPY / ONE. Round 4 first sent
+ * those through an intermediate image (k_linh + k_linv, below); the kernel's vertical schedule never cared whether
+ * consecutive samples share their source rows, and without the image the mixed rows move 40 % of the bytes. */
 inline bool
 down_setup (JobDev &d)
 {
-    if (!d.wide || d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR)
+    if (!d.wide || (!d.linear && !d.p16) || tune_env ("SMOL_NO_DOWN"))
+        return false;                           /* (compressed 128bpp never meets a bilinear axis) */
+    if (d.p16 && d.bpp_in != 4)
+        return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */
+    if (d.filter_h == F_BOX || d.filter_v == F_BOX)
         return false;
-    if (d.step_x < ((uint64_t) 1 << 32) || d.step_y < ((uint64_t) 1 << 32))
+    if ((d.filter_h != F_ONE && d.w_in < 2) || (d.filter_v == F_BILINEAR && d.h_in < 2))
         return false;
-    if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_DOWN"))
+    if (d.filter_h == F_ONE && d.bpp_in == 3)
+        return false;                           /* (a row of three bytes: no dword to load a 24-bit pixel with) */
+    const bool mixed = d.filter_h != F_BILINEAR || d.filter_v != F_BILINEAR
+                    || d.step_x < ((uint64_t) 1 << 32) || d.step_y < ((uint64_t) 1 << 32);
+    if (mixed && tune_env ("SMOL_NO_LIND_MIXED"))
         return false;
-    return lind_setup (d);
+
+    JobDev t = d;
+    /* COPY and ONE axes have no positions of their own: a step of one pixel (COPY), of nothing (ONE) */
+    if (t.filter_h == F_COPY) { t.frac0_x = 0; t.step_x = (uint64_t) 1 << 32; t.halv_h = 0; }
+    if (t.filter_h == F_ONE) { t.frac0_x = 0; t.step_x = 0; t.halv_h = 0; }
+    if (t.filter_v == F_COPY || t.filter_v == F_ONE) { t.frac0_y = 0; t.step_y = (uint64_t) 1 << 32; t.halv_v = 0; }
+
+    const uint32_t w = lind_pick_width (t);
+    if (!w)
+        return false;
+
+    /* <= 128 vertical samples per tile. A magnifying vertical axis shares its source rows between output rows: tiles
+     * tall enough to reach ~16 of them, so that the two halo rows a tile converts again stay a small share */
+    uint32_t th = t.halv_v ? 4u : 8u;
+    if (t.filter_v == F_BILINEAR && t.step_y < ((uint64_t) 1 << 32))
+    {
+        const uint64_t want = ((uint64_t) 14 << 32) / (t.step_y ? t.step_y : 1u);
+        th = want > 64u ? 64u : want < 8u ? 8u : (uint32_t) want;
+    }
+    if (const char *e = tune_env ("SMOL_DOWN_ROWS"))
+        th = (uint32_t) atoi (e);
+    if (th > (128u >> t.halv_v))
+        th = 128u >> t.halv_v;
+    if (th < 1)
+        th = 1;
+    t.group_rows = (uint16_t) w;
+    t.span_px = (uint32_t) lind_span (t, w);
+    t.tile_rows = (uint16_t) th;
+    t.tile_cpl = 2;
+    t.up_wide = 1;
+    t.down_mode = 3;
+    d = t;
+    return true;
 }
 
 /* tiles of the job (a workgroup takes 4) */
@@ -971,32 +998,9 @@ twopass_setup (JobDev &d)
     }
     else
     {
-        /* k_linh: the widest tile whose span of source pixels fits the conversion rounds (lind_setup's search) */
-        uint32_t best_w = 0;
-        double best = 0.0;
-        for (uint32_t k = 1; k <= LIND_KMAX_HOST; k++)
-        {
-            uint32_t lo = 1, hi = 128;
-            if (lind_span (t, lo) > 64u * k)
-                continue;
-            while (lo < hi)
-            {
-                const uint32_t mid = (lo + hi + 1) / 2;
-                if (lind_span (t, mid) <= 64u * k)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            const double eff = ((double) lind_span (t, lo) / (64.0 * k)) * ((double) lo / (lo > 64 ? 128.0 : 64.0));
-            /* (a magnifying axis converts few pixels per tile: the lanes the filters keep busy decide) */
-            const double score = t.step_x < ((uint64_t) 1 << 32) ? (double) lo : eff;
-            if (score > best + 1e-9)
-            {
-                best = score;
-                best_w = lo;
-            }
-        }
-        if (best_w < 16)
+        /* k_linh: k_lind's tile width */
+        const uint32_t best_w = lind_pick_width (t);
+        if (!best_w)
             return false;
         t.group_rows = (uint16_t) best_w;
         t.span_px = (uint32_t) lind_span (t, best_w);

@@ -90,7 +90,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         for (uint32_t s = 0; s < NSX; s++)
         {
             bilin_tap (pos, J.w_in, tap_ofs [c][s], tap_f [c][s]);
-            if (PASS == LIND_H && J.filter_h == F_ONE)
+            if (PASS != LIND_V && J.filter_h == F_ONE)
             {
                 /* an axis of ONE pixel (:1563-1611): every column is pixel 0 -- weight 256 on it, and the neighbour the
                  * tap also reads is the clamped copy of it in the next slot */
@@ -105,7 +105,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     uint32_t sx1, f_unused;
     bilin_tap (J.frac0_x + (uint64_t) ((xn << HX) - 1) * J.step_x, J.w_in, sx1, f_unused);
     sx1 += 1;                                                       /* last source pixel of the tile  */
-    if (PASS == LIND_H && J.filter_h == F_ONE)
+    if (PASS != LIND_V && J.filter_h == F_ONE)
         sx1 = 0;
     const uint32_t npx = PASS == LIND_V ? 0u : sx1 - sx0 + 1;       /* pixels per staged row: <= 64 * LIND_KMAX (host) */
 #pragma unroll
@@ -131,7 +131,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                 k = n_samples - 1;
             uint32_t o, f;
             bilin_tap (J.frac0_y + (uint64_t) (jy0 + k) * J.step_y, J.h_in, o, f);
-            if (PASS == LIND_V && (J.filter_v == F_COPY || J.filter_v == F_ONE))
+            if (PASS != LIND_H && (J.filter_v == F_COPY || J.filter_v == F_ONE))
             {
                 /* a COPY axis: output row R is intermediate row R and nothing else -- the strip's slab of source rows
                  * holds no neighbour to give weight 0 to (smol_hip_input_row_range); an axis of ONE row: always row 0 */
@@ -144,7 +144,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
     }
     /* a sample is due when its BOTTOM row has passed: row o + 1 of a bilinear pair, row o itself on a COPY axis */
-    const uint32_t vdue = (PASS == LIND_V && (J.filter_v == F_COPY || J.filter_v == F_ONE)) ? 0u : 1u;
+    const uint32_t vdue = (PASS != LIND_H && (J.filter_v == F_COPY || J.filter_v == F_ONE)) ? 0u : 1u;
     uint32_t oy = e & 0xffffu, Fy = e >> 16;
     const uint32_t row_first = PASS == LIND_H ? J.tmp_row0 + yrel0 : oy;
     const uint32_t row_last = PASS == LIND_H ? (row_first + J.tile_rows - 1u < J.tmp_row1 ? row_first + J.tile_rows - 1u : J.tmp_row1)
@@ -415,10 +415,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                         const uint32_t w = pack (v [c]);
                         if (ok [c])
                         {
-                            if (J.bpp_out == 4 && J.out_dword_ok && J.out_wt)
-                                __builtin_nontemporal_store (w, reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4));
-                            else if (J.bpp_out == 4 && J.out_dword_ok)
-                                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;    /* rows that start anywhere: write-back (fill_jobdev) */
+                            if (J.bpp_out == 4 && J.out_dword_ok)
+                                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;     /* (plain: the kernel is bound by its arithmetic) */
                             else
                                 wide_store_word (J, out_row, xc [c], w);
                         }

@@ -477,7 +477,7 @@ __device__ __forceinline__ uint32_t smol_shfl_xor (uint32_t v, uint32_t mask)
  * re-cut into 48 dwords through two in-wave shuffles. `interior'/`full' are
  * wave-uniform. */
 
-template <int OUT, int CPL>
+template <int OUT, int CPL, bool STREAM = false>       /* STREAM: write-through whatever the rows' alignment (k_up) */
 __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp, uint32_t xl, uint32_t xn,
                                                  bool interior, bool full24, const Px2 (&o) [CPL],
                                                  const uint32_t *inv_tab = smol_inv_p8_lut)
@@ -493,7 +493,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             for (int c = 0; c < 4; c++)
                 w [c] = tile_pack<OUT> (J, o [c], inv_tab);
             u32x4 v = { w [0], w [1], w [2], w [3] };
-            if (J.out_wt)
+            if (STREAM || J.out_wt)
                 store_out128 (gptr (rowp) + (size_t) xl * 4, v);
             else
             {

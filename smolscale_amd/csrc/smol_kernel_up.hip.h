@@ -237,7 +237,7 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
                                   __builtin_amdgcn_perm (hi [2], lo [2], J.up_perm), __builtin_amdgcn_perm (hi [3], lo [3], J.up_perm) };
                 /* non-temporal, not write-through: this kernel is bound by its stores, and write-through 16-byte
                  * stores run config 3 at 114 us against 88-93 us (profiles/r02m_store_policy.txt) */
-                store_row128 (gptr (out_row) + (size_t) xl * 4, v, J.out_wt);
+                store_nt128 (gptr (out_row) + (size_t) xl * 4, v);
             }
             else
             {
@@ -248,7 +248,7 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
                     o [c].lo = (lo [c] >> 8) & PAIR_MASK;
                     o [c].hi = (hi [c] >> 8) & PAIR_MASK;
                 }
-                tile_store_cols<OUT, UP_CPL> (J, out_row, xl, xn, interior, full24, o);
+                tile_store_cols<OUT, UP_CPL, true> (J, out_row, xl, xn, interior, full24, o);
             }
             out_row += J.dst_stride;
             r++;
@@ -427,7 +427,7 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
             if (fast)
             {
                 const u32x4 v = { o [0], o [1], o [2], o [3] };
-                store_row128 (out_row + (size_t) xl * 4, v, J.out_wt);
+                store_nt128 (out_row + (size_t) xl * 4, v);
             }
             else
             {
@@ -718,7 +718,7 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                 if (CPL == 4)
                 {
                     const u32x4 v4 = { wv [0], wv [1 % CPL], wv [2 % CPL], wv [3 % CPL] };
-                    store_row128 (gptr (out_row) + (size_t) xl * 4, v4, J.out_wt);
+                    store_nt128 (gptr (out_row) + (size_t) xl * 4, v4);
                 }
                 else
                 {

@@ -1098,28 +1098,16 @@ typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 typedef u32x4 u32x4a4 __attribute__ ((aligned (4)));       /* a 16-byte load unit on a 4-byte boundary (cropped images) */
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
 
-/* 16-byte NON-TEMPORAL output store on a dword-aligned address (the store-bound kernels: k_up, k_lind) */
+/* 16-byte NON-TEMPORAL output store on a dword-aligned address (k_up, bound by its stores: aligned rows 92 us
+ * against 120 us with plain stores on config 3, rows that start anywhere 106 against 111; profiles/r04_store_policy_ab.txt).
+ * Never put this and a plain store on the two sides of a branch: the compiler merges them into ONE plain store (the hint
+ * is metadata, and metadata that differs is dropped). */
 __device__ __forceinline__ void store_nt128 (gbyte *p, u32x4 v)
 {
 #if defined (SMOL_KERNEL_EMU)
     __builtin_memcpy (p, &v, 16);
 #else
     __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p));
-#endif
-}
-
-/* the same, streaming only when the rows start on 64-byte boundaries (`lines': JobDev::out_wt, wave-uniform): rows that
- * start anywhere share their first and last line with the neighbouring tile, and the two parts should meet in the L2
- * (write-back) instead of each costing a partial-line write to memory (smol_jobdev.h: fill_jobdev) */
-__device__ __forceinline__ void store_row128 (gbyte *p, u32x4 v, bool lines)
-{
-#if defined (SMOL_KERNEL_EMU)
-    __builtin_memcpy (p, &v, 16);
-#else
-    if (lines)
-        __builtin_nontemporal_store (v, reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p));
-    else
-        *reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (p) = v;
 #endif
 }
 

@@ -343,10 +343,11 @@ def test_emulated_tile_kernel_box_filters():
     _fuzz_tile(random.Random(77), dims, 60)
 
 
-def test_emulated_mixed_axis_two_pass_road():
-    """k_linh / k_boxh + k_linv / k_boxv (smol_jobdev.h: twopass_setup): 128bpp-class jobs whose axes differ -- one
-    minified and one magnified, a COPY axis, bilinear x box -- gamma-correct (every type pair) and premul16 with and
-    without sRGB, odd strides, row strips. Every (horizontal, vertical) pairing must have gone through the road."""
+def test_emulated_mixed_axis_roads():
+    """128bpp-class jobs whose axes differ -- one minified and one magnified, a COPY axis, bilinear x box -- gamma-correct
+    (every type pair) and premul16 with and without sRGB, odd strides, row strips. Pairings with a box axis must have
+    gone through the two-pass road (k_linh / k_boxh + k_linv / k_boxv, smol_jobdev.h: twopass_setup), the others through
+    k_lind with both axes in one kernel (down_setup)."""
     rng = random.Random(1357)
     seen = set()
 
@@ -381,16 +382,17 @@ def test_emulated_mixed_axis_two_pass_road():
         want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
         got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n)
         assert np.array_equal(got, want), (kh, kv, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout, first, n, k)
-        if k == 10:
+        if k == (10 if "box" in (kh, kv) else 9):
             seen.add((kh, kv, int(job.premul16)))
     assert {(a, b) for (a, b, _) in seen} == set(pairs)
-    assert {p for (_, _, p) in seen} == {0, 1}
+    assert {p for (a, b, p) in seen if "box" in (a, b)} == {0, 1}
+    assert {p for (a, b, p) in seen if "box" not in (a, b)} == {0, 1}
 
 
 def test_dispatcher_keeps_proportional_resizes_off_the_backstops():
     """smol_hip_kernel_name(): no size of the reference's proportional benchmark matrix (bench.sh:39-71) -- as it is run,
     with sRGB, with 24-bit and with unassociated types -- ends in k_general / k_wavepx / k_wtile, bar the one 1:1 copy of
-    the gamma-correct class; jobs with mixed axes in the 128bpp class take the two-pass road."""
+    the gamma-correct class; jobs with mixed axes in the 128bpp class take k_lind, with a box axis the two-pass road."""
     import smolscale_amd as sm
 
     def steps_of(w_in, h_in, smin, smax, n):
@@ -404,7 +406,8 @@ def test_dispatcher_keeps_proportional_resizes_off_the_backstops():
             bad = [(wo, ho) for (wo, ho) in steps_of(w, h, 0.01, smax, 200)
                    if (wo, ho) != (w, h) and sm.kernel_name(sm.plan_job(t_in, w, h, t_out, wo, ho, srgb)).startswith(backstops)]
             assert not bad, (t_in, t_out, srgb, w, h, bad[:3])
-    assert sm.kernel_name(sm.plan_job(0, 4096, 2048, 0, 2731, 3000, 1)) == "k_linh_batch + k_linv_batch"
+    assert sm.kernel_name(sm.plan_job(0, 4096, 2048, 0, 2731, 3000, 1)) == "k_lind_batch"        # H down, V up: one kernel
+    assert sm.kernel_name(sm.plan_job(4, 1000, 3000, 4, 2731, 3000, 0)) == "k_lind_batch"        # H up, V COPY, premul16
     assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 300, 2000, 1)) == "k_boxh_batch + k_linv_batch"
     assert sm.kernel_name(sm.plan_job(4, 300, 4000, 4, 900, 200, 0)) == "k_linh_batch + k_boxv_batch"
     assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 2731, 2731, 1)) == "k_lind_batch"

@@ -106,9 +106,9 @@ CONFIGS = {
     "SRGBPNG": (4, 4000, 3000, None, 4, 1600, 1200, 4, "4000x3000 rgbA -> 1600x1200 rgbA with_srgb=1 (premul16 + linear), 4 frames", 1),
     # the correctness backstops (k_wtile / k_general<true>): 128bpp-class jobs whose axes differ -- no proportional resize lands here
     # (profiles/r04_kernel_histogram.txt), independently scaled axes do
-    "SRGBHDVU": (0, 4096, 2048, None, 0, 2731, 3000, 2, "4096x2048->2731x3000 RGBA8 premul with_srgb=1 (H ratio 1.5 down, V up: k_wtile), 2 frames", 1),
-    "SRGBVCOPY": (0, 4096, 4096, None, 0, 2731, 4096, 2, "4096^2->2731x4096 RGBA8 premul with_srgb=1 (H ratio 1.5, V COPY: k_wtile), 2 frames", 1),
-    "SRGBBOXBIL": (0, 4096, 4096, None, 0, 300, 2000, 2, "4096^2->300x2000 RGBA8 premul with_srgb=1 (H BOX ratio 13.7, V bilinear: k_general<true>), 2 frames", 1),
+    "SRGBHDVU": (0, 4096, 2048, None, 0, 2731, 3000, 2, "4096x2048->2731x3000 RGBA8 premul with_srgb=1 (H ratio 1.5 down, V up), 2 frames", 1),
+    "SRGBVCOPY": (0, 4096, 4096, None, 0, 2731, 4096, 2, "4096^2->2731x4096 RGBA8 premul with_srgb=1 (H ratio 1.5, V COPY), 2 frames", 1),
+    "SRGBBOXBIL": (0, 4096, 4096, None, 0, 300, 2000, 2, "4096^2->300x2000 RGBA8 premul with_srgb=1 (H BOX ratio 13.7, V bilinear), 2 frames", 1),
     "P16BOXBIL": (4, 4096, 4096, None, 4, 300, 2000, 2, "4096^2->300x2000 rgbA->rgbA (premul16; H BOX, V bilinear), 2 frames"),
     "P16HDVU": (4, 4096, 2048, None, 4, 2731, 3000, 2, "4096x2048->2731x3000 rgbA->rgbA (premul16; H ratio 1.5 down, V up), 2 frames"),
     "WIDEBOX": (0, 65535, 512, None, 0, 64, 8, 4, "65535x512->64x8 RGBA8 premul (BOX ratio 1024 x 64, 128bpp class, 32 KB of source per output-column group and row), 4 frames"),
