@@ -840,7 +840,8 @@ boxh_geometry (JobDev &d, uint32_t lpc, uint64_t span_px, uint32_t chunks)
     d.span_px = (uint32_t) span_px;
     d.span_chunks = chunks;
     d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / chunks) + 1;
-    d.box_nmax = ((uint32_t) (d.step_x >> 16) + 1 + lpc - 1) / lpc + 1;   /* most interior pixels a lane walks */
+    /* most interior pixels a lane walks: a column's span o0 .. o1 has o1 - o0 <= floor (step) + 1, its interior one less */
+    d.box_nmax = ((uint32_t) (d.step_x >> 16) + lpc - 1) / lpc;
 }
 
 inline bool

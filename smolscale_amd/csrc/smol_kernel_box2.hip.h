@@ -170,15 +170,20 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                 acc [3] += 255u * n_int;
             }
             else
-            /* interior pixels four at a time, converted in one branch-free block (`un': the conversion's flavour, fixed
-             * per wave); a pixel past the lane's share is a zero word with its channels masked off */
-            for (uint32_t k = 0; k < J.box_nmax; k += 4)
             {
-                uint32_t w4 [4], c4 [4][4];
+            /* interior pixels four at a time, converted in one branch-free block (`un': the conversion's flavour, fixed
+             * per wave); a pixel past the lane's share is a zero word with its channels masked off. The last group holds
+             * the 1-3 pixels the longest column has left (wave-uniform: a job constant) -- a box of 9.14 pixels has 8 or 9
+             * interior ones, and a third group of four converted 12 pixels for them (4096^2 -> 448^2 gamma-correct:
+             * 14 conversions per column and row where 11 do; profiles/r04_boxh_tail_ab.txt) */
+            auto group = [&] (auto n_tag, const uint32_t k)
+            {
+                constexpr uint32_t N = decltype (n_tag)::value;
+                uint32_t w4 [N], c4 [N][4];
                 /* (a pixel past the lane's share is the neighbouring column's: staged bytes, converted for nothing and
                  * masked off below -- cheaper than a select per pixel in front of the read) */
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++)
+                for (uint32_t u = 0; u < N; u++)
                     w4 [u] = box2_px_word<AL> (J, rowb, off + u * bpp);
                 constexpr int UK = std::remove_reference_t<decltype (un)>::KIND;
                 bool opaque = false;
@@ -191,7 +196,7 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                      * table saves 14 % */
                     uint32_t all = 0xffffffffu;
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++)
+                    for (uint32_t u = 0; u < N; u++)
                         all &= (k + u < n_int) ? w4 [u] : 0xffffffffu;
                     opaque = wide_batch_opaque (J, all);
                     try_opaque = opaque;
@@ -200,20 +205,20 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                 {
                     const WideUnpack<WU_LIN_O> uno (J, lut);
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++)
+                    for (uint32_t u = 0; u < N; u++)
                         uno (w4 [u], c4 [u]);
                 }
                 else
                 {
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++)
+                    for (uint32_t u = 0; u < N; u++)
                         un (w4 [u], c4 [u]);
                 }
-                if (k + 4u <= n_int)
+                if (k + N <= n_int)
                 {
                     /* a whole group of the lane's share: no masks */
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++)
+                    for (uint32_t u = 0; u < N; u++)
 #pragma unroll
                         for (int i = 0; i < 4; i++)
                             acc [i] += c4 [u][i];
@@ -221,7 +226,7 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                 else
                 {
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++)
+                    for (uint32_t u = 0; u < N; u++)
                     {
                         const uint32_t m = (k + u < n_int) ? 0xffffffffu : 0u;
 #pragma unroll
@@ -229,7 +234,19 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
                             acc [i] += c4 [u][i] & m;
                     }
                 }
-                off += 4u * bpp;
+                off += N * bpp;
+            };
+            const uint32_t nfull = J.box_nmax & ~3u;
+            uint32_t k = 0;
+            for (; k < nfull; k += 4)
+                group (std::integral_constant<uint32_t, 4> (), k);
+            switch (J.box_nmax & 3u)                /* wave-uniform */
+            {
+                case 1: group (std::integral_constant<uint32_t, 1> (), k); break;
+                case 2: group (std::integral_constant<uint32_t, 2> (), k); break;
+                case 3: group (std::integral_constant<uint32_t, 3> (), k); break;
+                default: break;
+            }
             }
             if (LPC > 1)
             {
