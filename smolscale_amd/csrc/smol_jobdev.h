@@ -60,7 +60,7 @@ struct JobDev
     uint8_t tile_aligned4;         /* every staged pixel sits on a 4-byte LDS boundary   */
     uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
     uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
-    uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8)              */
+    uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8; k_boxh 128bpp class: also 64) */
     uint8_t tile_band;             /* k_tile: deal tiles out in XCD bands (very wide images) */
     uint8_t tile_vm;               /* k_tile: vertical specialisation (TILE_VM_*): 0 decided at run time, 1 copy, 2 bilinear, 3 box */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
@@ -784,6 +784,29 @@ inline uint32_t boxh_rows (const JobDev &d) { return d.wide ? SMOL_BOXH_ROWS_WID
 
 inline void boxh_geometry (JobDev &d, uint32_t lpc, uint64_t span_px, uint32_t chunks);
 
+/* k_boxh's lanes per output column: 64 columns per wave, or 8 columns with 8 lanes each when a column's span is very
+ * wide (then 64 columns' worth of a row would not fit the LDS either), or -- spans of hundreds of pixels, which only the
+ * 128bpp class has (boxes wider than 255 pixels) -- the whole wave on ONE column: eight columns' spans in a wave's row
+ * buffer are 32 KB at a ratio of 1024, one wave per SIMD and nobody to cover its loads (65535 x 512 -> 64 x 8: 295 us) */
+inline uint64_t
+boxh_lpc8_min ()
+{
+    if (const char *e = tune_env ("SMOL_BOX2_LPC8_MIN"))
+        return (uint64_t) atoi (e);
+    return 48;
+}
+
+inline uint32_t
+boxh_lpc (const JobDev &d)
+{
+    uint64_t lpc64_min = 400;
+    if (const char *e = tune_env ("SMOL_BOX2_LPC64_MIN"))
+        lpc64_min = (uint64_t) atoi (e);
+    if (d.wide && d.step_x > (lpc64_min << 16))
+        return 64u;
+    return (d.step_x > (boxh_lpc8_min () << 16)) ? 8u : 1u;
+}
+
 inline bool
 box2_setup (JobDev &d)
 {
@@ -801,10 +824,8 @@ box2_setup (JobDev &d)
 
     /* pass 1: 64 columns per wave, or 8 columns with 8 lanes each when a column's span is very
      * wide (then 64 columns' worth of a row would not fit the LDS either) */
-    uint64_t lpc8_min = 48;
-    if (const char *e = tune_env ("SMOL_BOX2_LPC8_MIN"))
-        lpc8_min = (uint64_t) atoi (e);
-    const uint32_t lpc = (d.step_x > (lpc8_min << 16)) ? 8u : 1u;
+    const uint64_t lpc8_min = boxh_lpc8_min ();
+    const uint32_t lpc = boxh_lpc (d);
 
     /* source bytes a tile can span in one row, as 16-byte chunks (+ misalignment and reader slack) */
     uint64_t span_px = (((64u / lpc) * d.step_x) >> 16) + 2;
@@ -988,7 +1009,7 @@ twopass_setup (JobDev &d)
     if (t.filter_h == F_BOX)
     {
         /* k_boxh's geometry, as box2_setup makes it */
-        const uint32_t lpc = (t.step_x > ((uint64_t) 48 << 16)) ? 8u : 1u;
+        const uint32_t lpc = boxh_lpc (t);
         uint64_t span_px = (((64u / lpc) * t.step_x) >> 16) + 2;
         if (span_px > t.w_in)
             span_px = t.w_in;

@@ -291,6 +291,39 @@ def test_down_kernel_srgb_linear_flavours():
             assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "device", sin_pad, mis)
 
 
+def test_axes_scaled_independently_in_the_128bpp_class():
+    """Jobs whose axes differ (smol_jobdev.h: down_setup, twopass_setup): one minified and one magnified, a COPY axis, an
+    axis of one pixel -> k_lind with both axes in one launch; bilinear on one axis and box on the other -> k_boxh / k_linh
+    + k_linv / k_boxv through the intermediate image. Gamma-correct types of every kind and premul16 with and without
+    sRGB, tiles wider and taller than one wave's, odd strides, row strips, misaligned device buffers."""
+    import smolscale_amd as sm
+    shapes = [
+        # (t_in, w_in, h_in, t_out, w_out, h_out, srgb, kernel)
+        (0, 1500, 300, 0, 1000, 700, 1, "k_lind"),          # H down, V up
+        (8, 300, 1400, 8, 1100, 500, 1, "k_lind"),          # H up, V down, 24-bit both sides
+        (4, 1500, 256, 4, 1000, 256, 1, "k_lind"),          # V COPY, premul16 + sRGB
+        (4, 700, 900, 6, 700, 400, 0, "k_lind"),            # H COPY, premul16
+        (5, 1200, 1, 7, 500, 40, 0, "k_lind"),              # V ONE
+        (2, 1, 600, 3, 300, 250, 1, "k_lind"),              # H ONE
+        (4, 2100, 130, 4, 300, 517, 0, "k_lind"),           # 2 halvings down, x4 up: tall tiles
+        (0, 4096, 300, 0, 300, 200, 1, "k_boxh_batch + k_linv"),
+        (4, 300, 4000, 4, 900, 200, 0, "k_linh_batch + k_boxv"),
+        (9, 3000, 100, 1, 200, 333, 1, "k_boxh_batch + k_linv"),
+    ]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb, kernel) in enumerate(shapes):
+        name = sm.kernel_name(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb))
+        assert name.startswith(kernel), (name, kernel, shapes[k])
+        for (sin_pad, mis, first, n) in ((0, 0, 0, h_out), (3 if H.bpp(t_in) == 3 else 4, 1, h_out // 3, h_out // 2), (16, 4, h_out - 1, 1)):
+            sin = w_in * H.bpp(t_in) + sin_pad
+            src = H.make_input(t_in, w_in, h_in, seed=k, valid=bool(k & 1), stride=sin, pad=0)
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, None, first, n)
+            got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, None, first, n)
+            assert np.array_equal(got, want), (shapes[k], "host", sin_pad, first, n)
+            got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, None, first, n,
+                                     src_misalign=mis, dst_misalign=mis)
+            assert np.array_equal(got, want), (shapes[k], "device", sin_pad, mis, first, n)
+
+
 def test_gamma_correct_kernels_on_opaque_images_and_on_a_translucent_block():
     """with_srgb = 1 on what gamma-correct scaling is used for -- photographs with an alpha channel. Every wave of an
     all-opaque image takes the fused one-look-up conversions (WU_LIN_O / WP_LIN_O, chosen per wave by a ballot: per row
