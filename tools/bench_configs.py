@@ -194,6 +194,9 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
     use_arena = (w_in * h_in * 4 <= (1 << 22)) and not no_arena
     slot_in = ((h_in * (stride_in or w_in * 4) + 64 + 255) // 256) * 256        # sized for 4-byte pixels
     slot_out = ((h_out * w_out * 4 + 64 + 255) // 256) * 256
+    if os.environ.get("SMOL_BENCH_SLOT_PAD"):           # experiment: another pitch between the images of an arena
+        slot_in += int(os.environ["SMOL_BENCH_SLOT_PAD"]) // 256 * 256
+        slot_out += int(os.environ.get("SMOL_BENCH_SLOT_PAD_OUT", "0")) // 256 * 256
     if use_arena:
         arena_in, arena_out = sm.DeviceBuffer(n_images * slot_in), sm.DeviceBuffer(n_images * slot_out)
         if os.environ.get("SMOL_BENCH_PRINT_ARENA"):
@@ -268,6 +271,19 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
     }
     if state:
         line["gpu_state"] = state
+    if arena_in is not None and os.environ.get("SMOL_BENCH_ARENA_PROBE"):
+        # what the address translation of THIS input arena costs (tools/microbench/tlb_probe.hip): ns per dependent read
+        # at strides of 4 KiB, 64 KiB and 2 MiB (+ a cache line)
+        import ctypes
+        probe = ctypes.CDLL(os.path.abspath(os.environ["SMOL_BENCH_ARENA_PROBE"]))
+        probe.smol_probe_latency.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
+        res = {}
+        for label, stride in (("4K", 4096 + 64), ("64K", 65536 + 64), ("2M", (2 << 20) + 64)):
+            ns = ctypes.c_double(0.0)
+            rc = probe.smol_probe_latency(arena_in.ptr, n_images * slot_in, stride, 20000, ctypes.byref(ns))
+            res[label] = round(ns.value, 1) if rc == 0 else None
+        line["arena_probe_ns"] = res
+        line["arena_in_ptr"] = "%x" % arena_in.ptr
     if checker is not None:
         # checker (host_src, type_in, w_in, h_in, stride_in, type_out, w_out, h_out, stride_out, srgb, got) -> bool
         t_in, t_out, s_in, s_out = specs[0]

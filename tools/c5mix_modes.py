@@ -25,7 +25,7 @@ keep = []
 for r in range(rounds):
     line = B.run_config(cfg, 20, 3, settle=0.2)
     print(json.dumps({"round": r, "step_us": line["step_us"], "min": line["step_us_min"], "median": line["step_us_median"],
-                      "frac": line["frac_of_8TBps"]}), flush=True)
+                      "frac": line["frac_of_8TBps"], "probe_ns": line.get("arena_probe_ns"), "arena": line.get("arena_in_ptr")}), flush=True)
     # move the next round's arenas: hold on to an allocation of another size (freed two rounds later)
     keep.append(sm.DeviceBuffer(int(rng.integers(1, 64)) << 20))
     if len(keep) > 2:
