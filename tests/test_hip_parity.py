@@ -359,6 +359,9 @@ def test_two_pass_box_thumbnails_single_and_batched():
     shapes = [
         (8, 4000, 300, 8, 200, 15, 0), (8, 4000, 300, 8, 200, 15, 1), (4, 2000, 900, 4, 64, 30, 0),
         (0, 3000, 2000, 1, 100, 5, 1), (5, 999, 777, 9, 1, 1, 1), (9, 1300, 500, 2, 65, 9, 0),
+        # boxes wider than 255 pixels (128bpp class): 8 lanes per column, and the whole wave on one column from a ratio of
+        # 400 (its own kernel: the batch launches the two flavours separately)
+        (0, 9000, 40, 0, 30, 4, 0), (2, 20000, 240, 3, 9, 3, 0), (8, 30000, 9, 0, 40, 2, 1), (4, 65535, 12, 4, 64, 3, 0),
     ]
     lib = sm.lib()
     images, bufs, wants = [], [], []
