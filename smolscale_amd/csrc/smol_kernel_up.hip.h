@@ -398,7 +398,10 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
 
     /* ---- V + un-premultiply + store -------------------------------------------------------- */
     const bool fast = (xn == x0 + TW) && J.out_vec16_ok;
-    const uint32_t dr = 8u * J.pos_out [0], dg = 8u * J.pos_out [1], db = 8u * J.pos_out [2], da = 8u * J.pos_out [3];
+    /* the destination word from the registers the un-premultiply leaves its byte in (byte 2 of each product) and the
+     * alpha byte: two v_perm + one OR (WidePack<WP_P16>'s assembly, smol_kernels.hip.h) */
+    const uint32_t sel01 = wide_sel (wide_sel (0x0c0c0c0cu, J.pos_out [0], 4u + 2u), J.pos_out [1], 2u);
+    const uint32_t sel2a = wide_sel (wide_sel (0x0c0c0c0cu, J.pos_out [2], 4u + 2u), J.pos_out [3] & 3u, 0u);
     gbyte *out_row = gptr (J.dst) + (size_t) yrel0 * J.dst_stride;
     uint32_t r = 0;
     uint32_t e = smol_readlane (sched, 0);
@@ -406,22 +409,39 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
 #pragma unroll
     for (int s = 0; s + 1 < UP_NSRC_W; s++)
     {
+        /* rows s and s + 1 of every column side by side, channel by channel (top | bottom << 16): four v_perm per column
+         * and row pair, shared by the output rows between them, after which an output pixel's vertical tap is ONE
+         * v_dot2_u32_u16 per channel against (F, 256 - F) and comes out unpacked, as the un-premultiply wants it --
+         * 17 instructions per pixel where two packed taps, their re-packing, the extractions and the shifts of the
+         * assembly took 31 (premul16 x4: 62 -> see profiles/r04_up16_ab.txt) */
+        uint32_t pr [UP_CPL][4];
+        if (r < nrows && (e & 0xffffu) == (uint32_t) s)
+        {
+#pragma unroll
+            for (int c = 0; c < UP_CPL; c++)
+            {
+                pr [c][0] = __builtin_amdgcn_perm (h_rg [s + 1][c], h_rg [s][c], PAIR_LO);
+                pr [c][1] = __builtin_amdgcn_perm (h_rg [s + 1][c], h_rg [s][c], PAIR_HI);
+                pr [c][2] = __builtin_amdgcn_perm (h_ba [s + 1][c], h_ba [s][c], PAIR_LO);
+                pr [c][3] = __builtin_amdgcn_perm (h_ba [s + 1][c], h_ba [s][c], PAIR_HI);
+            }
+        }
         while (r < nrows && (e & 0xffffu) == (uint32_t) s)
         {
             const uint32_t F = e >> 16, G = 256u - F;
+            const uint32_t FG = F | (G << 16);
             uint32_t o [UP_CPL];
 #pragma unroll
             for (int c = 0; c < UP_CPL; c++)
             {
-                const uint32_t rg = up16_tap<true> (h_rg [s][c], h_rg [s + 1][c], F, G);
-                const uint32_t ba = up16_tap<true> (h_ba [s][c], h_ba [s + 1][c], F, G);
-                const uint32_t a = ba >> 24;                    /* (alpha lane >> 8) & 0xff */
+                const uint32_t vr = pair_word_dot (pr [c][0], FG) >> 8;
+                const uint32_t vg = pair_word_dot (pr [c][1], FG) >> 8;
+                const uint32_t vb = pair_word_dot (pr [c][2], FG) >> 8;
+                const uint32_t a = pair_word_dot (pr [c][3], FG) >> 16;       /* (alpha lane >> 8) & 0xff */
                 const uint32_t inv = inv_lut [a];
-                /* (s * inv) >> 16 & 0xff (:1036-1100): s < 2^16, inv <= 2^16, the product fits 32 bits */
-                const uint32_t cr = (__umul24 (rg & 0xffffu, inv) >> 16) & 0xffu;
-                const uint32_t cg = (__umul24 (rg >> 16, inv) >> 16) & 0xffu;
-                const uint32_t cb = (__umul24 (ba & 0xffffu, inv) >> 16) & 0xffu;
-                o [c] = (cr << dr) | (cg << dg) | (cb << db) | (a << da);
+                /* (s * inv) >> 16 & 0xff (:1036-1100): s < 2^16, inv <= 2^16, the product fits 32 bits; byte 2 of it */
+                o [c] = __builtin_amdgcn_perm (__umul24 (vr, inv), __umul24 (vg, inv), sel01)
+                      | __builtin_amdgcn_perm (__umul24 (vb, inv), a, sel2a);
             }
 
             if (fast)
