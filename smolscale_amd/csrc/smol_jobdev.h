@@ -60,7 +60,7 @@ struct JobDev
     uint8_t tile_aligned4;         /* every staged pixel sits on a 4-byte LDS boundary   */
     uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
     uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
-    uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8; k_boxh 128bpp class: also 64) */
+    uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8; k_boxh 128bpp class: also 16, 64) */
     uint8_t tile_band;             /* k_tile: deal tiles out in XCD bands (very wide images) */
     uint8_t tile_vm;               /* k_tile: vertical specialisation (TILE_VM_*): 0 decided at run time, 1 copy, 2 bilinear, 3 box */
     uint8_t out_vec16_ok;          /* 4 output pixels of a lane may go out as one 16-B store */
@@ -804,6 +804,13 @@ boxh_lpc (const JobDev &d)
         lpc64_min = (uint64_t) atoi (e);
     if (d.wide && d.step_x > (lpc64_min << 16))
         return 64u;
+    /* from a ratio of 96, sixteen: four columns' spans per row buffer instead of eight (8192 -> 64 gamma-correct 235 -> 208 us,
+     * 8192 -> 30 103 -> 101; 32 lanes per column lose to their longer reduction: profiles/r04_boxh_tail_ab.txt) */
+    uint64_t lpc16_min = 96;
+    if (const char *e = tune_env ("SMOL_BOX2_LPC16_MIN"))
+        lpc16_min = (uint64_t) atoi (e);
+    if (d.wide && d.step_x > (lpc16_min << 16))
+        return 16u;
     return (d.step_x > (boxh_lpc8_min () << 16)) ? 8u : 1u;
 }
 

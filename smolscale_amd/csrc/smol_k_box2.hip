@@ -98,7 +98,7 @@ box2 (const JobDev *jobs_dev, const JobDev &rep, uint32_t n_jobs, uint32_t h_gri
     /* pass 1: horizontal */
     if (twopass_lin_h (rep))
         launch_linh (jobs_dev, rep, gh, h_lds, s);
-    else if (rep.wide && rep.tile_lpc == 64)
+    else if (rep.wide && rep.tile_lpc >= 16)
     {
         if (jobs_dev)
             hipLaunchKernelGGL ((smolhip::k_boxh_batch<true, true>), gh, dim3 (256), h_lds, s, jobs_dev);

@@ -52,8 +52,8 @@ __device__ __forceinline__ uint32_t box2_px_word (const JobDev &J, const uint8_t
 }
 
 /* LPC = lanes per output column: 1 (64 columns per wave), for very wide spans 8 (8 columns per wave) or -- spans of
- * hundreds of pixels, 128bpp class only -- 64 (the whole wave on one column: a row buffer of one span instead of eight,
- * so that enough waves fit a CU to cover each other's loads); originally: 1 or, for very wide spans, 8 (8 columns
+ * hundreds of pixels, 128bpp class only -- 16 (from a ratio of 96) or 64 (from 400: the whole wave on one column): a row
+ * buffer of four spans or one instead of eight, so that enough waves fit a CU to cover each other's loads; originally: 1 or, for very wide spans, 8 (8 columns
  * per wave; the 8 lanes of a column take consecutive eighths of its interior pixels and meet
  * through wave shuffles -- sums of exact integers, so the order does not matter) */
 template <bool WIDE, int LPC>
@@ -485,8 +485,8 @@ __device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_l
 }
 
 /* 4 waves per workgroup, each on its own tile; the 128bpp class shares one LDS copy of the tables */
-/* LPC64: the kernel of the whole-wave-per-column jobs (a kernel of its own: with a third body in it the common kernel
- * ran 3-4 % slower on the rows that never take it) */
+/* LPC64: the kernel of the jobs with 16 or 64 lanes per column (a kernel of its own: with a third body in it the common
+ * kernel ran 3-4 % slower on the rows that never take it) */
 template <bool WIDE, bool LPC64 = false>
 __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
 {
@@ -497,7 +497,12 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     /* host emulation: one wave per block, blocks numbered row group by row group */
     const uint32_t e_tiles_x = (J.w_out + 64u / J.tile_lpc - 1) / (64u / J.tile_lpc);
     if (LPC64)
-        boxh_body<WIDE, LPC64 ? 64 : 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
+    {
+        if (J.tile_lpc == 16)
+            boxh_body<WIDE, LPC64 ? 16 : 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
+        else
+            boxh_body<WIDE, LPC64 ? 64 : 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
+    }
     else if (J.tile_lpc == 8)
         boxh_body<WIDE, 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
     else
@@ -514,7 +519,13 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     }
     const uint32_t lut_bytes = WIDE ? ((LUT_LDS_BYTES + 15u) & ~15u) : 0u;
     if (LPC64)
-        boxh_body<WIDE, LPC64 ? 64 : 8> (J, lds + lut_bytes + wave * J.span_chunks * 16u, lds, threadIdx.x & 63u, tx, tr);
+    {
+        uint8_t *buf = lds + lut_bytes + wave * J.span_chunks * 16u;
+        if (J.tile_lpc == 16)
+            boxh_body<WIDE, LPC64 ? 16 : 8> (J, buf, lds, threadIdx.x & 63u, tx, tr);
+        else
+            boxh_body<WIDE, LPC64 ? 64 : 8> (J, buf, lds, threadIdx.x & 63u, tx, tr);
+    }
     else if (J.tile_lpc == 8)
         boxh_body<WIDE, 8> (J, lds + lut_bytes + wave * J.span_chunks * 16u, lds, threadIdx.x & 63u, tx, tr);
     else
@@ -550,7 +561,7 @@ __device__ __forceinline__ void boxv_entry (const JobDev &J, uint8_t *lds)
 __global__ void k_boxh_one (const JobDev J)
 {
     if (twopass_lin_h (J)) { linh_dispatch (J, smol_dyn_lds); return; }
-    if (J.wide && J.tile_lpc == 64) boxh_entry<true, true> (J, smol_dyn_lds);
+    if (J.wide && J.tile_lpc >= 16) boxh_entry<true, true> (J, smol_dyn_lds);
     else if (J.wide) boxh_entry<true> (J, smol_dyn_lds); else boxh_entry<false> (J, smol_dyn_lds);
 }
 

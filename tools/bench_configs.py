@@ -111,6 +111,8 @@ CONFIGS = {
     "SRGBBOXBIL": (0, 4096, 4096, None, 0, 300, 2000, 2, "4096^2->300x2000 RGBA8 premul with_srgb=1 (H BOX ratio 13.7, V bilinear), 2 frames", 1),
     "P16BOXBIL": (4, 4096, 4096, None, 4, 300, 2000, 2, "4096^2->300x2000 rgbA->rgbA (premul16; H BOX, V bilinear), 2 frames"),
     "P16HDVU": (4, 4096, 2048, None, 4, 2731, 3000, 2, "4096x2048->2731x3000 rgbA->rgbA (premul16; H ratio 1.5 down, V up), 2 frames"),
+    "SRGBBOX64": (0, 4096, 4096, None, 0, 64, 64, 8, "4096^2->64^2 RGBA8 premul with_srgb=1 (BOX ratio 64, 128bpp class), 8 frames", 1),
+    "SRGBBOX128": (0, 8192, 8192, None, 0, 64, 64, 2, "8192^2->64^2 RGBA8 premul with_srgb=1 (BOX ratio 128, 128bpp class), 2 frames", 1),
     "WIDEBOX": (0, 65535, 512, None, 0, 64, 8, 4, "65535x512->64x8 RGBA8 premul (BOX ratio 1024 x 64, 128bpp class, 32 KB of source per output-column group and row), 4 frames"),
     "BOX128": (0, 8192, 8192, None, 0, 30, 30, 2, "8192^2->30^2 RGBA8 premul (BOX ratio 273 > 255: 128bpp class), 2 frames"),
 }
