@@ -991,7 +991,11 @@ twopass_v_rows (const JobDev &d, uint32_t &y0, uint32_t &y1)
 inline bool
 twopass_setup (JobDev &d)
 {
-    if (!d.wide || (!d.linear && !d.p16) || d.n_rows == 0 || tune_env ("SMOL_NO_TWOPASS"))
+    if (!d.wide || d.n_rows == 0 || tune_env ("SMOL_NO_TWOPASS"))
+        return false;
+    /* (neither sRGB nor premul16: the class's compressed storage, which a box of 256+ pixels on one axis brings -- 8-bit
+     * values that the 11-bit passes carry as they are) */
+    if (!d.linear && !d.p16 && tune_env ("SMOL_NO_TWOPASS_FLAT"))
         return false;
     if (d.p16 && d.bpp_in != 4)
         return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */

@@ -269,6 +269,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             else
                 conv (WideUnpack<WU_P16> (J, lut));
         }
+        else if (PASS == LIND_H && !J.linear)
+            conv (WideUnpack<WU_ANY> (J, lut));         /* the class's compressed storage (a box of 256+ pixels on the other axis): bytes as they are */
         else if (IN24 || uk == WU_LIN_O)
             conv (WideUnpack<WU_LIN_O> (J, lut));
         else
@@ -430,6 +432,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                     else
                         put (WidePack<WP_P16> (J, lut));
                 }
+                else if (PASS == LIND_V && pk == WP_ANY)
+                    put (WidePack<WP_ANY> (J, lut));     /* compressed storage behind a box of 256+ pixels on the other axis */
                 else if ((pk == WP_LIN_P || pk == WP_LIN_U) && smol_wave_all_opaque (all_a))
                     put (WidePack<WP_LIN_O> (J, lut));
                 else if (pk == WP_LIN_P)

@@ -389,6 +389,45 @@ def test_emulated_mixed_axis_roads():
     assert {p for (a, b, p) in seen if "box" not in (a, b)} == {0, 1}
 
 
+def test_emulated_mixed_axis_road_with_compressed_storage():
+    """A box of 256+ pixels on one axis puts a job without sRGB and without unassociated alpha into the 128bpp class's
+    compressed storage (8-bit values in 32-bit lanes); with a bilinear, COPY or ONE other axis it takes the two-pass road
+    too (k_boxh + k_linv, k_linh + k_boxv), 64 or 16 lanes per column for the longest boxes."""
+    rng = random.Random(97)
+
+    def axis(kind, d_out):
+        if kind == "one":
+            return 1
+        if kind == "copy":
+            return d_out
+        if kind == "up":
+            return max(2, int(d_out / rng.uniform(1.05, 9)))
+        if kind == "down":
+            return max(d_out + 1, int(d_out * rng.uniform(1.01, 7.99)))
+        return min(65535, int(d_out * rng.uniform(256, 700)) + 1)
+
+    pairs = [("bigbox", "down"), ("bigbox", "up"), ("bigbox", "copy"), ("down", "bigbox"), ("up", "bigbox"), ("copy", "bigbox"),
+             ("bigbox", "one"), ("one", "bigbox")]
+    seen = set()
+    for it in range(40):
+        kh, kv = pairs[it % len(pairs)]
+        w_out = rng.choice([2, 3, 5]) if kh == "bigbox" else rng.choice([2, 7, 40, 65])
+        h_out = rng.choice([2, 3]) if kv == "bigbox" else rng.choice([2, 5, 17])
+        w_in, h_in = axis(kh, w_out), axis(kv, h_out)
+        t_in, t_out = rng.choice([0, 1, 2, 3, 8, 9]), rng.randrange(10)
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 4, 16])
+        sout = w_out * H.bpp(t_out) + rng.choice([0, 1, 4])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        assert np.array_equal(got, want), (kh, kv, t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
+        if k == 10:
+            seen.add((kh, kv))
+    assert seen == set(pairs)
+
+
 def test_dispatcher_keeps_proportional_resizes_off_the_backstops():
     """smol_hip_kernel_name(): no size of the reference's proportional benchmark matrix (bench.sh:39-71) -- as it is run,
     with sRGB, with 24-bit and with unassociated types -- ends in k_general / k_wavepx / k_wtile, bar the one 1:1 copy of
