@@ -562,7 +562,8 @@ up_setup (JobDev &d)
         return false;
     if (d.step_x >= ((uint64_t) 1 << 32) || d.step_y >= ((uint64_t) 1 << 32) || d.step_x == 0 || d.step_y == 0)
         return false;
-    if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_UP") || (flavour >= 2 && tune_env ("SMOL_NO_UP_GEN")))
+    if (d.w_in < 2 || d.h_in < 2 || tune_env ("SMOL_NO_UP") || (flavour >= 2 && tune_env ("SMOL_NO_UP_GEN"))
+        || (flavour == 1 && tune_env ("SMOL_NO_UP_P16")))
         return false;
 
     /* 64bpp class, slight magnification (below 2 on either axis): every source row feeds barely more than one
@@ -575,6 +576,25 @@ up_setup (JobDev &d)
          * widths of the sweep: 3840x2160 -> 6758x3801 641 -> 569 us, -> 7411x4168 674 -> 634: profiles/r03d_sweep_points.txt) */
         const uint64_t lim = (uint64_t) 1 << 31;                    /* step 0.5 = magnification 2 */
         if (d.step_x > lim || d.step_y > lim)
+            return false;
+    }
+
+    /* 128bpp class: k_up's tiles keep the horizontal results of 8 source rows in registers and pay for them per tile -- worth it
+     * when every source row feeds several output rows. Below that the row-streaming k_lind (down_setup takes what is
+     * refused here) is ahead, as k_tile is in the 64bpp class; step us on 8-12 frames, k_up / k_upg against k_lind
+     * (profiles/r04_up_vs_lind.txt):
+     *   gamma-correct RGBA      x1.1 435 / 156   x1.5 403 / 245   x2 416 / 368   x2.6 210 / 202   x3 250 / 237   x4 191 / 201
+     *   premul16 + gamma        x1.1 341 / 168   x1.5 350 / 261   x2 470 / 389   x2.6 198 / 218   x3 214 / 253   x4 169 / 215
+     *   gamma-correct RGB8 (24-bit out: k_upg stores pixel by pixel)    x1.1 490 / 151   x2 504 / 347   x4 269 / 184
+     *   premul16                x1.1 158 / 149   x1.5 182 / 234   x2 227 / 354   x4 112 / 197 */
+    if (flavour != 0 && !tune_env ("SMOL_UP_ALWAYS"))
+    {
+        const uint64_t one = (uint64_t) 1 << 32;
+        const uint64_t smax = d.step_x > d.step_y ? d.step_x : d.step_y;         /* the less magnified axis */
+        const uint64_t lim = flavour == 1 ? one * 5 / 6                            /* premul16: k_up from x1.2 */
+                           : flavour == 3 ? one * 10 / 23                          /* premul16 + gamma: k_upg from x2.3 */
+                           : one * 2 / 7;                                          /* gamma-correct: k_upg from x3.5 */
+        if (smax > lim || (flavour >= 2 && d.bpp_out == 3))
             return false;
     }
 

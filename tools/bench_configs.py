@@ -93,6 +93,9 @@ CONFIGS = {
     "SRGB": (0, 4096, 4096, None, 0, 1024, 1024, 4, "4096^2->1024^2 RGBA8 premul with_srgb=1 (linear, 128bpp class), 4 frames", 1),
     "P16UP": (4, 1920, 1080, None, 4, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 unassociated->unassociated (premul16 magnify), 2 frames"),
     "SRGBUP": (0, 1920, 1080, None, 0, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 premul with_srgb=1 (linear magnify), 2 frames", 1),
+    "SRGBU1.1": (0, 3840, 2160, None, 0, 4224, 2376, 6, "3840x2160->4224x2376 RGBA8 premul with_srgb=1 (gamma-correct magnify x1.1), 6 frames", 1),
+    "SRGBU2": (0, 3840, 2160, None, 0, 7680, 4320, 6, "3840x2160->7680x4320 RGBA8 premul with_srgb=1 (gamma-correct magnify x2), 6 frames", 1),
+    "SRGBUP24": (8, 1920, 1080, None, 8, 7680, 4320, 4, "1920x1080->7680x4320 RGB8 with_srgb=1 (gamma-correct magnify x4, 24-bit rows), 4 frames", 1),
     "SRGBUPODD": (0, 1920, 1080, None, 0, 4993, 2809, 4, "1920x1080->4993x2809 RGBA8 premul with_srgb=1 (linear magnify x2.6, output rows start on 4-byte boundaries only), 4 frames", 1),
     "P16UPODD": (4, 1920, 1080, None, 4, 4993, 2809, 4, "1920x1080->4993x2809 rgbA->rgbA (premul16 magnify x2.6, odd width), 4 frames"),
     "P16HALFODD": (4, 4096, 4096, None, 4, 2733, 2733, 2, "4096^2->2733^2 unassociated->unassociated (premul16, ratio 1.5, odd width), 2 frames"),
