@@ -78,6 +78,8 @@ struct JobDev
     uint8_t dbg;                   /* -DSMOL_TUNING builds only (env SMOL_TILE_DBG): 1 no taps, 2 no staging, 4 no stores; else 0 */
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
+    uint16_t launch_src_mb;        /* batches: source megabytes of ALL the batch's images (0: a call of its own); host side only, box2_setup */
+    uint16_t reserved1;
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
     uint32_t span_chunks_inv;      /* floor(2^32 / span_chunks) + 1                      */
     uint32_t box_nmax;             /* horizontal box: most interior pixels any column has */
@@ -839,11 +841,30 @@ box2_setup (JobDev &d)
 {
     if (d.filter_h != F_BOX || d.filter_v != F_BOX || tune_env ("SMOL_NO_BOX2") || d.n_rows == 0)
         return false;
-    uint64_t min_ratio = 12;
-    if (const char *e = tune_env ("SMOL_BOX2_MIN"))
-        min_ratio = (uint64_t) atoi (e);
-    if (!d.wide && d.step_y < (min_ratio << 16))
-        return false;
+    /* 64bpp class: the single-pass k_tile or the two passes? k_tile has one wave per 64 columns x a few rows -- a few
+     * hundred waves per image at these ratios, each a chain of row groups -- and takes 45-75 us for ONE 4096 x 3072 image
+     * whatever the ratio, where the two passes (one wave per 64 columns and source row) take 17-20; with a launch's worth
+     * of images in flight it is the faster one up to a ratio of 24 (32-bit sources; 8 lanes per column beyond that do not
+     * pay) or 19 (24-bit sources): 8 frames at ratio 9: 96 against 126 us, 10 frames at 16-24: 82-97 against 99-102,
+     * RGB8 at 12-17: 72-80 against 80-98 (profiles/r04_box_threshold.txt). So: by the source bytes of the launch. */
+    if (!d.wide)
+    {
+        const uint64_t ratio16 = d.step_y;          /* 16.16 */
+        bool tile;
+        if (const char *e = tune_env ("SMOL_BOX2_MIN"))
+            tile = ratio16 < ((uint64_t) atoi (e) << 16);
+        else
+        {
+            const uint64_t own_mb = ((uint64_t) d.w_in * d.bpp_in * (((uint64_t) d.n_rows * ratio16) >> 16)) >> 20;
+            const uint64_t mb = own_mb > d.launch_src_mb ? own_mb : d.launch_src_mb;
+            const uint64_t r12 = (uint64_t) 12 << 16, r16 = (uint64_t) 16 << 16, r19 = (uint64_t) 19 << 16, r24 = (uint64_t) 24 << 16;
+            /* (32-bit sources between 12 and 16: k_tile's box loop reads 114-136 us there against the two passes' 108-116) */
+            const bool ratio_ok = d.bpp_in == 3 ? ratio16 < r19 : (ratio16 < r12 || (ratio16 >= r16 && ratio16 <= r24));
+            tile = ratio_ok && mb >= (ratio16 < r12 ? 150u : 300u);
+        }
+        if (tile)
+            return false;
+    }
 
     uint32_t y0, y1, t;
     box_span_host (d.step_y, d.h_in, d.first_row, y0, t);

@@ -55,6 +55,14 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
     jobs.reserve (n_images);
     cls.reserve (n_images);
 
+    /* what the launch reads in all: the box filter's choice between its single-pass and two-pass kernels goes by it */
+    uint64_t src_bytes = 0;
+    for (uint32_t i = 0; i < n_images; i++)
+        if (images [i].job.pixel_type_in < 10 && images [i].job.height_out)
+            src_bytes += (uint64_t) images [i].job.width_in * images [i].job.height_in * (images [i].job.pixel_type_in >= 8 ? 3u : 4u)
+                         * images [i].n_rows / images [i].job.height_out;
+    const uint16_t launch_src_mb = (uint16_t) ((src_bytes >> 20) > 65535u ? 65535u : (src_bytes >> 20));
+
     for (uint32_t i = 0; i < n_images; i++)
     {
         const SmolHipImage &im = images [i];
@@ -68,6 +76,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
         JobDev jd;
         fill_jobdev (jd, im.job, im.src, im.rowstride_in, im.dst, im.rowstride_out,
                      im.first_row, im.n_rows);
+        jd.launch_src_mb = launch_src_mb;
         cls.push_back (classify (jd));
         jobs.push_back (jd);
     }

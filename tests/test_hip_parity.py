@@ -398,6 +398,46 @@ def test_two_pass_box_thumbnails_single_and_batched():
         ddst.free()
 
 
+def test_box_filter_single_pass_in_launches_of_150_mb_and_more():
+    """64bpp class, box on both axes: one image or a few go through the two passes (k_boxh + k_boxv), a launch that reads
+    150 MB or more at ratios up to 12 (300 MB up to 24; 24-bit sources up to 19) through the single-pass k_tile
+    (smol_jobdev.h: box2_setup). Both roads on the same images, every output against the oracle."""
+    import smolscale_amd as sm
+    lib = sm.lib()
+    for (t_in, t_out, w_in, h_in, w_out, h_out, n_few, n_many) in ((0, 1, 4096, 2600, 430, 273, 1, 4), (8, 8, 4000, 3000, 380, 285, 2, 5),
+                                                                 (2, 0, 4096, 3072, 228, 171, 1, 7)):
+        srcs = [H.make_input(t_in, w_in, h_in, seed=40 + i, valid=True, pad=0) for i in range(2)]
+        wants = [H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0) for src in srcs]
+        dsrcs = []
+        for src in srcs:
+            d = sm.DeviceBuffer(src.size + 16)
+            d.upload(src)
+            dsrcs.append(d)
+        for n in (n_few, n_many):
+            images, ddsts = [], []
+            for i in range(n):
+                ddst = sm.DeviceBuffer(wants[0].size + 16)
+                ddst.fill(0)
+                im = sm.SmolHipImage()
+                im.job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+                im.src, im.dst = dsrcs[i & 1].ptr, ddst.ptr
+                im.rowstride_in, im.rowstride_out = w_in * H.bpp(t_in), w_out * H.bpp(t_out)
+                im.first_row, im.n_rows = 0, h_out
+                images.append(im)
+                ddsts.append(ddst)
+            batch = sm.HipBatch(images)
+            kname = batch.info()[1]
+            assert ("k_tile" in kname) == (n == n_many), (kname, n, t_in, w_in)
+            batch.launch()
+            sm.check(lib.smol_hip_device_synchronize(0))
+            for i, ddst in enumerate(ddsts):
+                assert np.array_equal(ddst.download(wants[0].size), wants[i & 1]), (kname, n, i, t_in)
+                ddst.free()
+            batch.destroy()
+        for d in dsrcs:
+            d.free()
+
+
 def test_workgroups_with_more_than_64k_of_lds():
     """Geometries whose workgroups need 70-130 KB of dynamic LDS (gfx950 has 160 KB per CU)."""
     cases = [

@@ -117,6 +117,8 @@ CONFIGS = {
     "FLATBOXBIL": (0, 65535, 64, None, 0, 128, 40, 8, "65535x64->128x40 RGBA8 premul (H BOX ratio 512: the 128bpp class's compressed storage; V bilinear), 8 frames"),
     "FLATBILBOX": (0, 300, 20000, None, 0, 200, 40, 8, "300x20000->200x40 RGBA8 premul (H ratio 1.5, V BOX ratio 500: compressed storage), 8 frames"),
     "FLATTALL": (0, 64, 60000, None, 0, 100, 4, 16, "64x60000->100x4 RGBA8 premul (H magnify, V BOX ratio 15000: compressed storage, few output pixels), 16 frames"),
+    "BOX12": (0, 4096, 4096, None, 0, 336, 336, 8, "4096^2->336^2 RGBA8 premul (BOX ratio 12.2, 64bpp class: the two-pass threshold), 8 frames"),
+    "BOX16": (0, 4096, 4096, None, 0, 256, 256, 8, "4096^2->256^2 RGBA8 premul (BOX ratio 16, 64bpp class), 8 frames"),
     "SRGBBOX64": (0, 4096, 4096, None, 0, 64, 64, 8, "4096^2->64^2 RGBA8 premul with_srgb=1 (BOX ratio 64, 128bpp class), 8 frames", 1),
     "SRGBBOX128": (0, 8192, 8192, None, 0, 64, 64, 2, "8192^2->64^2 RGBA8 premul with_srgb=1 (BOX ratio 128, 128bpp class), 2 frames", 1),
     "WIDEBOX": (0, 65535, 512, None, 0, 64, 8, 4, "65535x512->64x8 RGBA8 premul (BOX ratio 1024 x 64, 128bpp class, 32 KB of source per output-column group and row), 4 frames"),
