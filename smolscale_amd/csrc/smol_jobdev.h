@@ -579,6 +579,15 @@ up_setup (JobDev &d)
         const uint64_t lim = (uint64_t) 1 << 31;                    /* step 0.5 = magnification 2 */
         if (d.step_x > lim || d.step_y > lim)
             return false;
+        /* k_up's fast form is the 16-byte store of four premultiplied 32-bit pixels; 24-bit, unassociated and byte-aligned
+         * output leaves it through k_tile's column stores and loses to k_tile at every factor: 1920x1080 -> x4, 4 frames,
+         * RGB8 -> RGB8 179 / 120 us, RGBA -> RGB8 154 / 113, premultiplied -> unassociated 230 / 153; 3840x2160 -> x2, 6 frames,
+         * 401 / 185, 287 / 184, 561 / 241; x8 151 / 101, 178 / 125 (profiles/r04_up_vs_lind.txt). 24-bit sources into
+         * premultiplied 32-bit: k_up from x2.6 (x2 243 / 181, x2.6 118 / 117, x3 116 / 141, x4 91 / 99) */
+        if ((d.tile_variant & 3u) != 0)
+            return false;
+        if (d.bpp_in == 3 && (d.step_x > ((uint64_t) 5 << 32) / 13 || d.step_y > ((uint64_t) 5 << 32) / 13))
+            return false;
     }
 
     /* 128bpp class: k_up's tiles keep the horizontal results of 8 source rows in registers and pay for them per tile -- worth it

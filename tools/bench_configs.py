@@ -63,6 +63,9 @@ CONFIGS = {
     "S4K49": (2, 3840, 2160, None, 2, 1881, 1057, 19, "sweep point 3840x2160->1881x1057 ARGB8 premul (ratio 2.04, 1H), 19 frames"),
     "S4K25": (2, 3840, 2160, None, 2, 959, 539, 19, "sweep point 3840x2160->959x539 ARGB8 premul (ratio 4.004, 2H), 19 frames"),
     "U2": (0, 3840, 2160, None, 0, 7680, 4320, 6, "3840x2160->7680x4320 RGBA8 premul (magnify x2), 6 frames"),
+    "U4RGB": (8, 1920, 1080, None, 8, 7680, 4320, 4, "1920x1080->7680x4320 RGB8 -> RGB8 (magnify x4, 24-bit rows), 4 frames"),
+    "U2UNASSOC": (0, 3840, 2160, None, 4, 7680, 4320, 6, "3840x2160->7680x4320 RGBA8 premul -> unassociated (magnify x2), 6 frames"),
+    "U8": (0, 960, 540, None, 0, 7680, 4320, 4, "960x540->7680x4320 RGBA8 premul (magnify x8), 4 frames"),
     "U3": (0, 1920, 1080, None, 0, 5760, 3240, 8, "1920x1080->5760x3240 RGBA8 premul (magnify x3), 8 frames"),
     "C5": (0, 256, 256, None, 0, 64, 64, 10000, "10000 thumbnails 256^2->64^2 RGBA8 premul (1H/1H), one batch"),
     "C5mix": (-1, 256, 256, None, -1, 64, 64, 10000, "10000 thumbnails 256^2->64^2, pixel types drawn uniformly from the 10x10 table"),
