@@ -57,12 +57,18 @@ launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds
         launch_up_k<INK, smolhip::OUT_W16> (jobs_dev, rep, grid, lds, s);
         return;
     }
+#ifdef SMOL_TUNING
+    /* (only the tuning build's SMOL_UP_ALWAYS sends unassociated, 24-bit or byte-aligned output here: up_setup keeps k_up to
+     * its fast store form, and the shipped library carries no kernels it never launches) */
     switch (rep.tile_variant & 3u)
     {
         case smolhip::OUT_P4: launch_up_k<INK, smolhip::OUT_P4> (jobs_dev, rep, grid, lds, s); break;
         case smolhip::OUT_U4: launch_up_k<INK, smolhip::OUT_U4> (jobs_dev, rep, grid, lds, s); break;
         default:              launch_up_k<INK, smolhip::OUT_ANY> (jobs_dev, rep, grid, lds, s); break;
     }
+#else
+    launch_up_k<INK, smolhip::OUT_P4> (jobs_dev, rep, grid, lds, s);
+#endif
 }
 
 } /* namespace */
