@@ -1,8 +1,12 @@
+#!/usr/bin/env python3
+"""64bpp-class box filter: the single-pass k_tile against the two passes for 1, 2 and 4 images of 4096x3072 per launch (one
+allocation per image) at ratios 9-24 (tuning build: SMOL_BOX2_MIN 1000 = always k_tile, 1 = always the two passes).
+    SMOLSCALE_AMD_LIB=smolscale_amd/libsmolscale_amd_tuning.so python tools/box_single_image.py"""
 import json, os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 import bench_configs as B
-for frames in (1, 2):
-    for w_out in (820, 585, 455, 390, 341):
+for frames in (1, 2, 4):
+    for w_out in (455, 390, 341, 256, 205, 171):
         row = {"frames": frames, "ratio": round(4096 / w_out, 1)}
         for label, env in (("k_tile", "1000"), ("two_pass", "1")):
             os.environ["SMOL_BOX2_MIN"] = env
