@@ -96,6 +96,8 @@ CONFIGS = {
     "SRGB": (0, 4096, 4096, None, 0, 1024, 1024, 4, "4096^2->1024^2 RGBA8 premul with_srgb=1 (linear, 128bpp class), 4 frames", 1),
     "P16UP": (4, 1920, 1080, None, 4, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 unassociated->unassociated (premul16 magnify), 2 frames"),
     "SRGBUP": (0, 1920, 1080, None, 0, 7680, 4320, 2, "1920x1080->7680x4320 RGBA8 premul with_srgb=1 (linear magnify), 2 frames", 1),
+    "SRGBR6": (0, 4096, 4096, None, 0, 683, 683, 4, "4096^2->683^2 RGBA8 premul with_srgb=1 (gamma-correct, 2 halvings, ratio 6), 4 frames", 1),
+    "SRGBR7RGB": (8, 4000, 3000, None, 8, 560, 420, 8, "4000x3000->560x420 RGB8 with_srgb=1 (gamma-correct photo, ratio 7.1), 8 frames", 1),
     "SRGBU1.1": (0, 3840, 2160, None, 0, 4224, 2376, 6, "3840x2160->4224x2376 RGBA8 premul with_srgb=1 (gamma-correct magnify x1.1), 6 frames", 1),
     "SRGBU2": (0, 3840, 2160, None, 0, 7680, 4320, 6, "3840x2160->7680x4320 RGBA8 premul with_srgb=1 (gamma-correct magnify x2), 6 frames", 1),
     "SRGBUP24": (8, 1920, 1080, None, 8, 7680, 4320, 4, "1920x1080->7680x4320 RGB8 with_srgb=1 (gamma-correct magnify x4, 24-bit rows), 4 frames", 1),

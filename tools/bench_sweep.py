@@ -63,6 +63,9 @@ def main(argv=None, reference_rows=None):
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "results"))
     ap.add_argument("--tests", default=DEFAULT_TESTS)
     ap.add_argument("--steps", type=int, default=0, help="override the number of steps (quick runs)")
+    ap.add_argument("--pixel-type", type=int, default=ARGB_P, help="pixel type of both sides (default ARGB8 premultiplied, as the reference's matrix; 32-bit types only)")
+    ap.add_argument("--srgb", type=int, default=0, help="with_srgb (the reference's matrix runs without)")
+    ap.add_argument("--no-host-row", action="store_true", help="skip the host-pointer row (device rows only: quick looks)")
     args = ap.parse_args(argv)
     os.makedirs(args.out, exist_ok=True)
     rng = np.random.default_rng(7)
@@ -87,15 +90,15 @@ def main(argv=None, reference_rows=None):
             dst = np.empty(w_out * h_out * 4, np.uint8)
             # host-pointer row: fastest of `reps' (benchmark_postprocess, test.c:319-340)
             best = 1e9
-            for _ in range(reps):
+            for _ in range(0 if args.no_host_row else reps):
                 t0 = time.perf_counter()
-                sm.smol_scale_simple(src, ARGB_P, w_in, h_in, w_in * 4, dst, ARGB_P, w_out, h_out, w_out * 4, 0)
+                sm.smol_scale_simple(src, args.pixel_type, w_in, h_in, w_in * 4, dst, args.pixel_type, w_out, h_out, w_out * 4, args.srgb)
                 best = min(best, time.perf_counter() - t0)
             host.append((w_out, h_out, best, (w_in * h_in + w_out * h_out) / best))
             # device-resident rows: F frames, each with its own output
             out_slot = (dst.size + 64 + 255) // 256 * 256
             ddst = sm.DeviceBuffer(out_slot * n_frames)
-            job = sm.plan_job(ARGB_P, w_in, h_in, ARGB_P, w_out, h_out, 0)
+            job = sm.plan_job(args.pixel_type, w_in, h_in, args.pixel_type, w_out, h_out, args.srgb)
             images = []
             for f in range(n_frames):
                 im = sm.SmolHipImage()
