@@ -672,6 +672,7 @@ constexpr uint32_t DOWN_LUT_BYTES = (SMOL_LUT_LDS_BYTES + 15) & ~15u;
  * whole conversion rounds of 64 pixels -- K rounds hold 64 K pixels, a tile of W columns reaches at most
  * ((W << h) - 1) * step + 3 of them. */
 constexpr uint32_t LIND_KMAX_HOST = 5;
+constexpr uint32_t LIND_KMAX_NARROW_HOST = 8;       /* the fused kernel's one-column flavour (two halvings, tiles of <= 64 columns) */
 
 inline uint64_t
 lind_span (const JobDev &d, uint32_t w)
@@ -679,15 +680,18 @@ lind_span (const JobDev &d, uint32_t w)
     return ((((uint64_t) (w << d.halv_h) - 1u) * d.step_x) >> 32) + 3u;
 }
 
+inline bool lind_narrow (const JobDev &d) { return d.halv_h == 2 && d.group_rows <= 64; }
+
 inline uint32_t
-lind_pick_width (const JobDev &d)
+lind_pick_width (const JobDev &d, bool fused = false)
 {
     uint32_t best_w = 0;
     double best = 0.0;
-    for (uint32_t k = 1; k <= LIND_KMAX_HOST; k++)
+    const uint32_t kmax = (fused && d.halv_h == 2) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST;
+    for (uint32_t k = 1; k <= kmax; k++)
     {
-        /* the widest tile whose span fits k rounds */
-        uint32_t lo = 1, hi = 128;
+        /* the widest tile whose span fits k rounds (more than LIND_KMAX_HOST rounds: the one-column flavour only) */
+        uint32_t lo = 1, hi = k > LIND_KMAX_HOST ? 64 : 128;
         if (lind_span (d, lo) > 64u * k)
             continue;
         while (lo < hi)
@@ -701,7 +705,10 @@ lind_pick_width (const JobDev &d)
         /* slots used in the conversion rounds x lanes used by the filters, both of which scale the tile's cost; a
          * magnifying axis converts few pixels per tile: there the lanes the filters keep busy decide alone */
         const double eff = ((double) lind_span (d, lo) / (64.0 * k)) * ((double) lo / (lo > 64 ? 128.0 : 64.0));
-        const double score = d.step_x < ((uint64_t) 1 << 32) ? (double) lo : eff;
+        /* the one-column flavour's candidates (fused, two halvings): columns per unit of work -- a conversion round costs a
+         * lane about a third of what its column's filters and packer do */
+        const double per_work = (double) lo / (20.0 * k + 60.0 * (lo > 64 ? 2.0 : 1.0));
+        const double score = d.step_x < ((uint64_t) 1 << 32) ? (double) lo : (kmax > LIND_KMAX_HOST ? per_work : eff);
         if (score > best + 1e-9)
         {
             best = score;
@@ -710,7 +717,7 @@ lind_pick_width (const JobDev &d)
     }
     if (const char *e = tune_env ("SMOL_LIND_W"))
         best_w = (uint32_t) atoi (e);
-    if (best_w < 16 || best_w > 128 || lind_span (d, best_w) > 64u * LIND_KMAX_HOST)
+    if (best_w < 16 || best_w > 128 || lind_span (d, best_w) > 64u * ((fused && d.halv_h == 2 && best_w <= 64) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST))
         return 0;
     return best_w;
 }
@@ -744,7 +751,7 @@ down_setup (JobDev &d)
     if (t.filter_h == F_ONE) { t.frac0_x = 0; t.step_x = 0; t.halv_h = 0; }
     if (t.filter_v == F_COPY || t.filter_v == F_ONE) { t.frac0_y = 0; t.step_y = (uint64_t) 1 << 32; t.halv_v = 0; }
 
-    const uint32_t w = lind_pick_width (t);
+    const uint32_t w = lind_pick_width (t, true);
     if (!w)
         return false;
 
@@ -782,7 +789,7 @@ down_blocks (const JobDev &d)
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
-    return DOWN_LUT_BYTES + 4u * (64u * LIND_KMAX_HOST * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
+    return DOWN_LUT_BYTES + 4u * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
 }
 
 /* host twin of the device box_span (smol_kernels.hip.h; closed form of smolscale.c's box precalc) */

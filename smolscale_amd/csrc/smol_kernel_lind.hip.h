@@ -28,6 +28,7 @@
 namespace smolhip {
 
 constexpr int LIND_KMAX = 5;            /* conversion rounds per source row: spans of at most 320 pixels */
+constexpr int LIND_KMAX_NARROW = 8;     /* the one-column flavour (NARROW: half the registers per lane): 512 pixels, 64 columns up to a ratio of 8 */
 typedef uint32_t u32a1 __attribute__ ((aligned (1)));
 
 /* one tap on a 32-bit channel of at most 19 bits: (p * F + q * (256 - F)) >> 8, below 2^28 before the shift */
@@ -48,7 +49,8 @@ enum : int { LIND_FUSED = 0, LIND_H = 1, LIND_V = 2 };
 
 /* TMP8 (passes of the W32 flavour only): the intermediate pixel is 8 bytes of 16-bit channels -- what k_boxh writes and
  * k_boxv reads (premul16 without sRGB: every value fits 16 bits) -- instead of four 32-bit channels (16 bytes) */
-template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false>
+/* NARROW (chosen per job at the entry, two halvings only): tiles of at most 64 columns */
+template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
 {
@@ -59,6 +61,11 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     constexpr uint32_t PXB = W32 ? 16u : 8u;                        /* LDS bytes per staged pixel */
     constexpr int NCH = W32 ? 4 : 2;                                /* registers per filtered pixel */
     const uint32_t W = PASS == LIND_V ? 128u : J.group_rows;        /* output columns per tile (host) */
+    /* tiles of at most 64 columns (minification beyond ~5: the span of 64 columns fills the conversion rounds) leave the
+     * lanes' second column empty: nothing is filtered, packed or stored for it -- a compile-time flavour, picked per job
+     * (as a run-time test it cost the wide tiles 1-3 %): gamma-correct ratio 6 125 -> 104 us, photographs at 7.1 151 -> 128 */
+    constexpr int ncols = NARROW ? 1 : CPL;
+    constexpr int KMAX = NARROW ? LIND_KMAX_NARROW : LIND_KMAX;
 
     const uint32_t tiles_x = (J.w_out + W - 1) / W;
     const uint32_t tx = tile % tiles_x;
@@ -155,9 +162,9 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     const int uk = wide_unpack_kind (J), pk = wide_pack_kind (J);
     const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;   /* row being loaded */
     /* slot k * 64 + lane holds pixel min (slot, npx - 1) of the span; px_off: its byte offset in a source row */
-    uint32_t px_off [LIND_KMAX], px_sh [IN24 ? LIND_KMAX : 1];
+    uint32_t px_off [KMAX], px_sh [IN24 ? KMAX : 1];
 #pragma unroll
-    for (int k = 0; k < LIND_KMAX; k++)
+    for (int k = 0; k < KMAX; k++)
     {
         const uint32_t i = (uint32_t) k * 64u + lane;
         const uint32_t x = sx0 + (i < npx ? i : npx - 1);
@@ -170,7 +177,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         else
             px_off [k] = x * 4u;
     }
-    uint32_t rawpx [LIND_KMAX];                                     /* the pixels of the row in flight */
+    uint32_t rawpx [KMAX];                                     /* the pixels of the row in flight */
     /* LIND_V: the lane's two intermediate pixels of the row in flight */
     uint32_t tmp_in [CPL][NCH];
 #pragma unroll
@@ -212,7 +219,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             return;
         }
 #pragma unroll
-        for (int k = 0; k < LIND_KMAX; k++)
+        for (int k = 0; k < KMAX; k++)
             if ((uint32_t) k * 64u < npx)                           /* wave-uniform */
             {
                 if (IN24)
@@ -243,14 +250,14 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         if (IN24)
         {
 #pragma unroll
-            for (int k = 0; k < LIND_KMAX; k++)
+            for (int k = 0; k < KMAX; k++)
                 if ((uint32_t) k * 64u < npx)
                     rawpx [k] = __builtin_amdgcn_alignbyte (0u, rawpx [k], px_sh [k]);
         }
         auto conv = [&] (const auto &un)
         {
 #pragma unroll
-            for (int k = 0; k < LIND_KMAX; k++)
+            for (int k = 0; k < KMAX; k++)
                 if ((uint32_t) k * 64u < npx)
                 {
                     uint32_t ch [4];
@@ -277,7 +284,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         {
             uint32_t all = 0xffffffffu;
 #pragma unroll
-            for (int k = 0; k < LIND_KMAX; k++)
+            for (int k = 0; k < KMAX; k++)
                 if ((uint32_t) k * 64u < npx)
                     all &= rawpx [k];
             if (wide_batch_opaque (J, all))
@@ -327,6 +334,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
 #pragma unroll
         for (int c = 0; c < CPL && PASS != LIND_V; c++)
         {
+            if (c >= ncols)
+                continue;
             uint32_t hs [NCH];
 #pragma unroll
             for (uint32_t s = 0; s < NSX; s++)
@@ -382,11 +391,14 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             const uint32_t Gy = 256u - Fy;
 #pragma unroll
             for (int c = 0; c < CPL; c++)
-#pragma unroll
-                for (int i = 0; i < NCH; i++)
+                if (c < ncols)
                 {
-                    const uint32_t t = W32 ? tap32 (hp [c][i], h [c][i], Fy, Gy) : lerp11_pk (hp [c][i], h [c][i], wy);
-                    acc [c][i] = s_y ? acc [c][i] + t : t;
+#pragma unroll
+                    for (int i = 0; i < NCH; i++)
+                    {
+                        const uint32_t t = W32 ? tap32 (hp [c][i], h [c][i], Fy, Gy) : lerp11_pk (hp [c][i], h [c][i], wy);
+                        acc [c][i] = s_y ? acc [c][i] + t : t;
+                    }
                 }
             s_y++;
             ks++;
@@ -396,6 +408,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
                 {
+                    if (c >= ncols)
+                        continue;
                     if (W32)
                     {
 #pragma unroll
@@ -414,6 +428,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
                     {
+                        if (c >= ncols)
+                            continue;
                         const uint32_t w = pack (v [c]);
                         if (ok [c])
                         {
@@ -454,16 +470,19 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         }
 #pragma unroll
         for (int c = 0; c < CPL; c++)
+            if (c < ncols)
+            {
 #pragma unroll
-            for (int i = 0; i < NCH; i++)
-                hp [c][i] = h [c][i];
+                for (int i = 0; i < NCH; i++)
+                    hp [c][i] = h [c][i];
+            }
     }
 }
 
 /* LDS of one wave: the row buffer */
-__device__ __forceinline__ uint32_t lind_wave_lds (bool w32)
+__device__ __forceinline__ uint32_t lind_wave_lds (bool w32, bool narrow = false)
 {
-    return 64u * LIND_KMAX * (w32 ? 16u : 8u);
+    return 64u * (narrow ? LIND_KMAX_NARROW : LIND_KMAX) * (w32 ? 16u : 8u);
 }
 
 /* 4 waves per workgroup share one LDS copy of the tables, each wave works on its own tile in its own LDS region */
@@ -473,7 +492,10 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
-    lind_body<HX, IN24, W32> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    if (HX == 2 && J.group_rows <= 64)
+        lind_body<HX, IN24, W32, LIND_FUSED, false, HX == 2> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    else
+        lind_body<HX, IN24, W32> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     /* (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same on every lane of a wave, and
      * without it everything derived from the tile index -- every loop bound, every "is this round needed" test --
@@ -481,8 +503,11 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
-    lind_body<HX, IN24, W32> (J, lds + ((LUT_LDS_BYTES + 15u) & ~15u) + wave * lind_wave_lds (W32), lds,
-                         threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    uint8_t *tab_end = lds + ((LUT_LDS_BYTES + 15u) & ~15u);
+    if (HX == 2 && J.group_rows <= 64)          /* (the host sized the workgroup's LDS by the same rule: down_lds_bytes) */
+        lind_body<HX, IN24, W32, LIND_FUSED, false, HX == 2> (J, tab_end + wave * lind_wave_lds (W32, true), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    else
+        lind_body<HX, IN24, W32> (J, tab_end + wave * lind_wave_lds (W32), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
 }
 
