@@ -672,7 +672,7 @@ constexpr uint32_t DOWN_LUT_BYTES = (SMOL_LUT_LDS_BYTES + 15) & ~15u;
  * whole conversion rounds of 64 pixels -- K rounds hold 64 K pixels, a tile of W columns reaches at most
  * ((W << h) - 1) * step + 3 of them. */
 constexpr uint32_t LIND_KMAX_HOST = 5;
-constexpr uint32_t LIND_KMAX_NARROW_HOST = 8;       /* the fused kernel's one-column flavour (two halvings, tiles of <= 64 columns) */
+constexpr uint32_t LIND_KMAX_NARROW_HOST = 8;       /* the fused kernel's one-column flavour (one or two halvings, tiles of <= 64 columns) */
 
 inline uint64_t
 lind_span (const JobDev &d, uint32_t w)
@@ -680,14 +680,14 @@ lind_span (const JobDev &d, uint32_t w)
     return ((((uint64_t) (w << d.halv_h) - 1u) * d.step_x) >> 32) + 3u;
 }
 
-inline bool lind_narrow (const JobDev &d) { return d.halv_h == 2 && d.group_rows <= 64; }
+inline bool lind_narrow (const JobDev &d) { return d.halv_h >= 1 && d.group_rows <= 64; }
 
 inline uint32_t
 lind_pick_width (const JobDev &d, bool fused = false)
 {
     uint32_t best_w = 0;
     double best = 0.0;
-    const uint32_t kmax = (fused && d.halv_h == 2) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST;
+    const uint32_t kmax = (fused && d.halv_h >= 1) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST;
     for (uint32_t k = 1; k <= kmax; k++)
     {
         /* the widest tile whose span fits k rounds (more than LIND_KMAX_HOST rounds: the one-column flavour only) */
@@ -717,7 +717,7 @@ lind_pick_width (const JobDev &d, bool fused = false)
     }
     if (const char *e = tune_env ("SMOL_LIND_W"))
         best_w = (uint32_t) atoi (e);
-    if (best_w < 16 || best_w > 128 || lind_span (d, best_w) > 64u * ((fused && d.halv_h == 2 && best_w <= 64) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST))
+    if (best_w < 16 || best_w > 128 || lind_span (d, best_w) > 64u * ((fused && d.halv_h >= 1 && best_w <= 64) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST))
         return 0;
     return best_w;
 }

@@ -19,6 +19,15 @@ template <int HX, int IN>
 void
 launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
+    /* tiles of at most 64 columns (one or two halvings): the one-column flavour, a kernel of its own */
+    if (HX >= 1 && smolhip::dispatch::lind_narrow (rep))
+    {
+        if (jobs_dev)
+            hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN, HX >= 1>), grid, dim3 (256), lds, s, jobs_dev);
+        else
+            hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN, HX >= 1>), grid, dim3 (256), lds, s, rep);
+        return;
+    }
     if (jobs_dev)
         hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN>), grid, dim3 (256), lds, s, jobs_dev);
     else

@@ -16,6 +16,19 @@ namespace smolhip {
 __global__ void k_down_one (const JobDev J)
 {
     const int in = J.p16 ? 2 : J.bpp_in == 3 ? 1 : 0;
+    if (dispatch::lind_narrow (J))              /* tiles of at most 64 columns: the one-column flavour */
+    {
+        switch (J.halv_h * 3 + in)
+        {
+            case 3: lind_entry<1, false, false, true> (J, smol_dyn_lds); break;
+            case 4: lind_entry<1, true, false, true> (J, smol_dyn_lds); break;
+            case 5: lind_entry<1, false, true, true> (J, smol_dyn_lds); break;
+            case 6: lind_entry<2, false, false, true> (J, smol_dyn_lds); break;
+            case 7: lind_entry<2, true, false, true> (J, smol_dyn_lds); break;
+            default: lind_entry<2, false, true, true> (J, smol_dyn_lds); break;
+        }
+        return;
+    }
     switch (J.halv_h * 3 + in)
     {
         case 0: lind_entry<0, false, false> (J, smol_dyn_lds); break;

@@ -49,7 +49,7 @@ enum : int { LIND_FUSED = 0, LIND_H = 1, LIND_V = 2 };
 
 /* TMP8 (passes of the W32 flavour only): the intermediate pixel is 8 bytes of 16-bit channels -- what k_boxh writes and
  * k_boxv reads (premul16 without sRGB: every value fits 16 bits) -- instead of four 32-bit channels (16 bytes) */
-/* NARROW (chosen per job at the entry, two halvings only): tiles of at most 64 columns */
+/* NARROW (chosen per job at the entry, one or two halvings): tiles of at most 64 columns */
 template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
@@ -486,16 +486,15 @@ __device__ __forceinline__ uint32_t lind_wave_lds (bool w32, bool narrow = false
 }
 
 /* 4 waves per workgroup share one LDS copy of the tables, each wave works on its own tile in its own LDS region */
-template <int HX, bool IN24, bool W32>
+/* NARROW: the one-column flavour, a kernel of its own (k_lind_batch<HX, IN, true>; as a second body inside the common
+ * kernel it cost the wide tiles 3-4 %, as k_boxh's 64-lane flavour did); the host picks it per job: dispatch::lind_narrow */
+template <int HX, bool IN24, bool W32, bool NARROW = false>
 __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 {
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
-    if (HX == 2 && J.group_rows <= 64)
-        lind_body<HX, IN24, W32, LIND_FUSED, false, HX == 2> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
-    else
-        lind_body<HX, IN24, W32> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     /* (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same on every lane of a wave, and
      * without it everything derived from the tile index -- every loop bound, every "is this round needed" test --
@@ -503,11 +502,8 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
-    uint8_t *tab_end = lds + ((LUT_LDS_BYTES + 15u) & ~15u);
-    if (HX == 2 && J.group_rows <= 64)          /* (the host sized the workgroup's LDS by the same rule: down_lds_bytes) */
-        lind_body<HX, IN24, W32, LIND_FUSED, false, HX == 2> (J, tab_end + wave * lind_wave_lds (W32, true), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
-    else
-        lind_body<HX, IN24, W32> (J, tab_end + wave * lind_wave_lds (W32), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    uint8_t *tab_end = lds + ((LUT_LDS_BYTES + 15u) & ~15u);       /* (the host sizes the workgroup's LDS by the flavour too: down_lds_bytes) */
+    lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, tab_end + wave * lind_wave_lds (W32, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
 }
 
@@ -588,19 +584,19 @@ __device__ __forceinline__ void linv_dispatch (const JobDev &J, uint8_t *lds)
 
 #ifndef SMOL_KERNEL_EMU
 /* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels) */
-template <int HX, int IN>
+template <int HX, int IN, bool NARROW = false>
 __global__ void __launch_bounds__ (256)
 k_lind_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    lind_entry<HX, IN == 1, IN == 2> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW> (J, smol_dyn_lds);
 }
 
-template <int HX, int IN>
+template <int HX, int IN, bool NARROW = false>
 __global__ void __launch_bounds__ (256)
 k_lind_one (const JobDev J)
 {
-    lind_entry<HX, IN == 1, IN == 2> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW> (J, smol_dyn_lds);
 }
 
 /* (pass 1: jobs along blockIdx.z like k_boxh; pass 2: along blockIdx.y like k_boxv) */
