@@ -174,6 +174,10 @@ int smol_hip_host_unregister (void *host_ptr);
  * get buffers that take the zero-copy road. */
 int smol_hip_host_alloc (uint64_t n_bytes, void **host_ptr_out);
 int smol_hip_host_free (void *host_ptr);
+/* 1 when EVERY byte of the range is page-locked (so that the host entries hand it to the DMA engines in place), 0
+ * when any part of it is pageable or cannot be told (it then travels through the library's rings). The range is
+ * walked allocation by allocation -- two registrations with a pageable gap between them are pageable. */
+int smol_hip_host_range_is_pinned (const void *host_ptr, uint64_t n_bytes);
 
 /* Device-pointer entry: input image and output strip already live in device
  * memory. Asynchronous on `hip_stream' (a hipStream_t, NULL = default stream): no

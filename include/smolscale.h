@@ -14,7 +14,10 @@
  *   - the caller owns pixels_in / pixels_out for the lifetime of a context;
  *   - no function returns an error; unrecoverable internal failures abort()
  *     (reference smolscale.c:779-780, 812-813). A missing GPU / failed HIP call
- *     is such a failure here: there is NO CPU fallback in this library.
+ *     is such a failure here under the default SMOL_BACKEND=hip: nothing falls back
+ *     silently. The library's own CPU backend (smol_cpu.h, a correctness fallback)
+ *     runs only when asked for: SMOL_BACKEND=cpu, or SMOL_BACKEND=auto, which says
+ *     so on stderr once per process when it takes over.
  *   - results are bit-identical to the reference's generic backend. */
 
 #ifndef SMOLSCALE_AMD_SMOLSCALE_H

@@ -103,6 +103,7 @@ EXPORTS = {
     "smol_hip_host_register": (_int, [_vp, _u64]),
     "smol_hip_host_unregister": (_int, [_vp]),
     "smol_hip_host_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
+    "smol_hip_host_range_is_pinned": (_int, [_vp, _u64]),
     "smol_hip_host_free": (_int, [_vp]),
     "smol_hip_scale_rows_device": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp]),
     "smol_hip_batch_create": (_int, [ctypes.POINTER(SmolHipImage), _u32, _int, ctypes.POINTER(_vp)]),

@@ -79,7 +79,9 @@ struct JobDev
     uint16_t tile_rows;            /* output rows per tile                               */
     uint16_t group_rows;           /* source rows staged per LDS phase                   */
     uint16_t launch_src_mb;        /* batches: source megabytes of ALL the batch's images (0: a call of its own); host side only, box2_setup */
-    uint16_t reserved1;
+    uint8_t box_force;             /* host side only, box2_setup: 64bpp-class box x box -- 0 decide by the launch's bytes, 1 single pass (k_tile), 2 two passes.
+                                    * A strip that is cut into chunks decides ONCE and hands the verdict down */
+    uint8_t reserved1;
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
     uint32_t span_chunks_inv;      /* floor(2^32 / span_chunks) + 1                      */
     uint32_t box_nmax;             /* horizontal box: most interior pixels any column has */
@@ -867,7 +869,9 @@ box2_setup (JobDev &d)
     {
         const uint64_t ratio16 = d.step_y;          /* 16.16 */
         bool tile;
-        if (const char *e = tune_env ("SMOL_BOX2_MIN"))
+        if (d.box_force)
+            tile = d.box_force == 1;
+        else if (const char *e = tune_env ("SMOL_BOX2_MIN"))
             tile = ratio16 < ((uint64_t) atoi (e) << 16);
         else
         {
@@ -1171,6 +1175,34 @@ classify (JobDev &d)
     if (d.filter_v == F_BOX && (d.step_y >> 16) >= 32 && (uint64_t) d.w_out * d.n_rows <= 262144)
         return d.wide ? KC_WAVEPX_WIDE : KC_WAVEPX;
     return d.wide ? KC_GENERAL_WIDE : KC_GENERAL;
+}
+
+/* A strip of rows that the host road (smol_rt_lanes.hip) cuts into chunks of ~8 MB: the class is decided ONCE, on the
+ * whole strip. 64bpp-class box x box picks the single pass or the two passes by the bytes a launch reads (box2_setup);
+ * a chunk classified on its own rows would take the two passes where the strip's probe said k_tile and had sized no
+ * intermediate image (8000 x 6000 -> 800 x 600). The verdict travels to the chunks as
+ * JobDev::box_force; tmp_bytes is what the strip's intermediate image needs (0: none), an upper bound of any chunk's. */
+struct StripClass
+{
+    KClass k;
+    size_t tmp_bytes;
+    uint8_t box_force;
+};
+
+inline StripClass
+strip_classify (const SmolHipJob &job, uint32_t src_pitch, uint32_t dst_pitch, uint32_t first_row, uint32_t n_rows)
+{
+    JobDev probe;
+    StripClass sc = { KC_GENERAL, 0, 0 };
+
+    fill_jobdev (probe, job, reinterpret_cast<const void *> (uintptr_t (16)), src_pitch,
+                 reinterpret_cast<void *> (uintptr_t (16)), dst_pitch, first_row, n_rows);
+    sc.k = classify (probe);
+    if (sc.k == KC_BOX2)
+        sc.tmp_bytes = box2_tmp_bytes (probe);
+    if (!probe.wide && probe.filter_h == F_BOX && probe.filter_v == F_BOX)
+        sc.box_force = sc.k == KC_BOX2 ? 2 : 1;
+    return sc;
 }
 
 inline const char *

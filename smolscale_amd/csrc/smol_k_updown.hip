@@ -7,7 +7,7 @@
 #include "smol_kernels.hip.h"
 #include "smol_kernel_tile.hip.h"
 #include "smol_kernel_up.hip.h"
-#include "smol_kernel_down.hip.h"
+#include "smol_kernel_lind.hip.h"
 #include "smol_launch.h"
 
 using smolhip::JobDev;

@@ -5,6 +5,6 @@
 #include "smol_kernel_wtile.hip.h"
 #include "smol_kernel_pow2x.hip.h"
 #include "smol_kernel_up.hip.h"
-#include "smol_kernel_down.hip.h"
+#include "smol_kernel_lind.hip.h"
 #include "smol_kernel_box2.hip.h"
 #include "smol_kernel_hspan.hip.h"

@@ -47,7 +47,7 @@ hipError_t launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, cons
  * (plan, staging lane or batch), at least box2_tmp_bytes + 64 bytes for the job's rows, and is indexed from the
  * job's own first source row (tmp_row0). Nothing is allocated, freed or synchronised, so the launch is
  * asynchronous and legal under stream capture. *k_out (optional): the class that took the job. */
-hipError_t launch_single (JobDev &jd, hipStream_t s, void *scratch = nullptr, KClass *k_out = nullptr);
+hipError_t launch_single (JobDev &jd, hipStream_t s, void *scratch = nullptr, size_t scratch_bytes = 0, KClass *k_out = nullptr);
 
 /* first_row + n_rows <= height, without wrapping */
 inline bool

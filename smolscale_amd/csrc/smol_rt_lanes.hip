@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 using namespace smolhip::dispatch;
 
@@ -577,7 +578,8 @@ strip_issue_locked (Strip &st, Lane &ln)
      * on another GPU) straight to the DMA engines. */
     const uint8_t *src_first = st.src + (size_t) r0 * st.rowstride_in;
     const bool small = knobs ().bounce && !peer
-                       && n_in_rows * align_up (in_row_bytes, 16) + (size_t) st.n * align_up (out_row_bytes, 16) <= knobs ().zero_copy_bytes;
+                       && n_in_rows * align_up (in_row_bytes, 16) + (size_t) st.n * align_up (out_row_bytes, 16)
+                          <= (knobs ().zero_copy_bytes < knobs ().slot_bytes ? knobs ().zero_copy_bytes : knobs ().slot_bytes);   /* one ring slot holds it */
     const bool bounce_in = knobs ().bounce && !peer && !small
                            && !host_range_is_pinned (src_first, (n_in_rows - 1) * st.rowstride_in + in_row_bytes);
     const bool bounce_out = knobs ().bounce && !small
@@ -635,13 +637,13 @@ strip_issue_locked (Strip &st, Lane &ln)
                                      && src_bytes + dst_bytes <= zc_pageable);
 
     /* the two-pass box filter keeps its intermediate image in the lane */
-    size_t tmp_need = 0;
-    {
-        JobDev probe;
-        fill_jobdev (probe, job, (void *) 16, (uint32_t) src_pitch, (void *) 16, (uint32_t) dst_pitch, st.first, st.n);
-        if (classify (probe) == KC_BOX2)
-            tmp_need = box2_tmp_bytes (probe) + 64;
-    }
+    /* 64bpp-class box x box picks the single pass or the two passes by the bytes a launch reads (box2_setup): decided
+     * HERE, once, for the whole strip, and handed to every chunk as JobDev::box_force -- a chunk of 8 MB classified on
+     * its own rows would take the two passes where the strip's probe said k_tile and sized no intermediate image
+     * (8000 x 6000 -> 800 x 600 failed on a fresh lane, wrote past a smaller scratch on a used one) */
+    const StripClass sc = strip_classify (job, (uint32_t) src_pitch, (uint32_t) dst_pitch, st.first, st.n);
+    const size_t tmp_need = sc.tmp_bytes ? sc.tmp_bytes + 64 : 0;
+    const uint8_t box_force = sc.box_force;
     rc = lane_prepare (ln, zero_copy ? 0 : src_bytes + 64 + 16, zero_copy ? 0 : dst_bytes + 64 + 16, tmp_need);
     if (!rc && (bounce_in || zero_copy))
         rc = ring_prepare (ln.in, src_bytes, src_pitch);
@@ -659,7 +661,8 @@ strip_issue_locked (Strip &st, Lane &ln)
         copy_rows (RowCopy { hin, src_pitch, src_first, st.rowstride_in, in_row_bytes, (uint32_t) n_in_rows, knobs ().stream_stores });
         fill_jobdev (jd, job, hin - (size_t) r0 * src_pitch, (uint32_t) src_pitch, hout, (uint32_t) dst_pitch,
                      st.first, st.n);
-        hipError_t e = launch_single (jd, ln.s_k, ln.tmp_buf);
+        jd.box_force = box_force;
+        hipError_t e = launch_single (jd, ln.s_k, ln.tmp_buf, ln.tmp_cap);
         if (e == hipSuccess)
             e = hipStreamSynchronize (ln.s_k);
         if (e != hipSuccess)
@@ -781,7 +784,8 @@ strip_issue_locked (Strip &st, Lane &ln)
         uint8_t *dchunk = static_cast<uint8_t *> (ln.dst_buf) + dst_skew + (size_t) done * dst_pitch;
         JobDev jd;
         fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch, dchunk, (uint32_t) dst_pitch, st.first + done, rows);
-        if ((e = launch_single (jd, ln.s_k, ln.tmp_buf)) != hipSuccess) break;
+        jd.box_force = box_force;
+        if ((e = launch_single (jd, ln.s_k, ln.tmp_buf, ln.tmp_cap)) != hipSuccess) break;
         if (!one_stream)
         {
             if ((e = hipEventRecord (ln.ev_k [c], ln.s_k)) != hipSuccess) break;
@@ -994,21 +998,81 @@ transfer (int device, void *dev, void *host, size_t n_bytes, bool to_device)
 
 } /* namespace */
 
+/* Ranges this library page-locked itself (smol_hip_host_alloc / smol_hip_host_register): known end to end without
+ * asking the runtime. */
+namespace {
+std::mutex g_pinned_mtx;
+std::map<uintptr_t, size_t> g_pinned;           /* base -> bytes */
+
+void
+pinned_note (const void *p, size_t n)
+{
+    std::lock_guard<std::mutex> g (g_pinned_mtx);
+    g_pinned [(uintptr_t) p] = n;
+}
+
+void
+pinned_forget (const void *p)
+{
+    std::lock_guard<std::mutex> g (g_pinned_mtx);
+    g_pinned.erase ((uintptr_t) p);
+}
+
+/* end of the noted range that holds address q, 0 if none does */
+uintptr_t
+pinned_range_end (uintptr_t q)
+{
+    std::lock_guard<std::mutex> g (g_pinned_mtx);
+    auto it = g_pinned.upper_bound (q);
+    if (it == g_pinned.begin ())
+        return 0;
+    --it;
+    return q < it->first + it->second ? it->first + it->second : 0;
+}
+} /* namespace */
+
+/* Is EVERY byte of [p, p + n_bytes) page-locked? The range is walked allocation by allocation: the library's own
+ * registrations from its table, foreign ones (hipHostMalloc / hipHostRegister by the caller) through the runtime --
+ * hipPointerGetAttributes says what the address is, hipMemGetAddressRange where its allocation ends. Rounds 3-4 asked
+ * about the two END bytes only: two registrations with a pageable gap between them passed, and the gap went to the
+ * DMA engine. Any doubt -- a query that fails, an allocation whose extent the runtime does
+ * not tell -- means "pageable": the bounce rings are always correct. */
 bool
 host_range_is_pinned (const void *p, size_t n_bytes)
 {
-    const uint8_t *ends [2] = { static_cast<const uint8_t *> (p), static_cast<const uint8_t *> (p) + (n_bytes ? n_bytes - 1 : 0) };
+    uintptr_t q = (uintptr_t) p;
+    const uintptr_t end = q + (n_bytes ? n_bytes : 1);
 
-    for (const uint8_t *q : ends)
+    for (int hops = 0; q < end; hops++)
     {
+        if (hops > 64)
+            return false;               /* a range stitched from that many allocations: not worth the queries */
+        const uintptr_t own_end = pinned_range_end (q);
+        if (own_end)
+        {
+            q = own_end;
+            continue;
+        }
         hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes (&attr, q) != hipSuccess)
+        if (hipPointerGetAttributes (&attr, reinterpret_cast<const void *> (q)) != hipSuccess)
         {
             (void) hipGetLastError ();  /* unregistered host memory reports an error: not sticky */
             return false;
         }
-        if (attr.type != hipMemoryTypeHost)
+        if (attr.type != hipMemoryTypeHost || !attr.hostPointer || !attr.devicePointer)
             return false;
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange (&base, &size, attr.devicePointer) != hipSuccess || !size)
+        {
+            (void) hipGetLastError ();
+            return false;
+        }
+        /* the allocation's end, seen from the host address */
+        const uintptr_t dev_end = (uintptr_t) base + size;
+        if (dev_end <= (uintptr_t) attr.devicePointer)
+            return false;
+        q += dev_end - (uintptr_t) attr.devicePointer;
     }
     return true;
 }
@@ -1152,6 +1216,7 @@ smol_hip_host_register (void *host_ptr, uint64_t n_bytes)
     if (!host_ptr || !n_bytes)
         return SMOL_HIP_E_INVALID;
     HIP_TRY (hipHostRegister (host_ptr, n_bytes, hipHostRegisterPortable));
+    pinned_note (host_ptr, n_bytes);
     return 0;
 }
 
@@ -1160,6 +1225,7 @@ smol_hip_host_unregister (void *host_ptr)
 {
     if (!host_ptr)
         return SMOL_HIP_E_INVALID;
+    pinned_forget (host_ptr);
     HIP_TRY (hipHostUnregister (host_ptr));
     return 0;
 }
@@ -1170,6 +1236,7 @@ smol_hip_host_alloc (uint64_t n_bytes, void **host_ptr_out)
     if (!host_ptr_out || !n_bytes)
         return SMOL_HIP_E_INVALID;
     HIP_TRY (hipHostMalloc (host_ptr_out, n_bytes, hipHostMallocPortable));
+    pinned_note (*host_ptr_out, n_bytes);
     return 0;
 }
 
@@ -1178,8 +1245,15 @@ smol_hip_host_free (void *host_ptr)
 {
     if (!host_ptr)
         return SMOL_HIP_E_INVALID;
+    pinned_forget (host_ptr);
     HIP_TRY (hipHostFree (host_ptr));
     return 0;
+}
+
+int
+smol_hip_host_range_is_pinned (const void *host_ptr, uint64_t n_bytes)
+{
+    return host_ptr && host_range_is_pinned (host_ptr, (size_t) n_bytes) ? 1 : 0;
 }
 
 void

@@ -81,7 +81,7 @@ launch_class (KClass k, const JobDev *jobs_dev, uint32_t n_jobs, const JobDev &r
 }
 
 hipError_t
-launch_single (JobDev &jd, hipStream_t s, void *scratch, KClass *k_out)
+launch_single (JobDev &jd, hipStream_t s, void *scratch, size_t scratch_bytes, KClass *k_out)
 {
     const KClass k = classify (jd);
 
@@ -89,7 +89,9 @@ launch_single (JobDev &jd, hipStream_t s, void *scratch, KClass *k_out)
         *k_out = k;
     if (k == KC_BOX2)
     {
-        if (!scratch)
+        /* the intermediate image must hold what THIS call's classification needs (a caller that sized it from
+         * another probe and got it wrong is refused here instead of writing past the buffer) */
+        if (!scratch || scratch_bytes < box2_tmp_bytes (jd))
             return hipErrorInvalidValue;
         jd.tmp = static_cast<uint8_t *> (scratch);
     }

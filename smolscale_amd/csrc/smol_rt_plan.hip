@@ -16,7 +16,7 @@ namespace {
 
 /* could this plan's rows go through an intermediate image (two-pass box filter, or the two-pass road of the
  * gamma-correct jobs with mixed axes)? Decided as the dispatcher would for aligned rows -- alignment can only take a
- * job OFF these roads. */
+ * job OFF these roads -- and independent of the row range. */
 bool
 plan_may_need_scratch (const SmolHipPlan *plan)
 {
@@ -24,6 +24,10 @@ plan_may_need_scratch (const SmolHipPlan *plan)
     JobDev probe;
     fill_jobdev (probe, j, reinterpret_cast<const void *> (uintptr_t (256)), j.width_in * k_types [j.pixel_type_in].bpp,
                  reinterpret_cast<void *> (uintptr_t (256)), j.width_out * k_types [j.pixel_type_out].bpp, 0, j.height_out);
+    /* 64bpp-class box x box takes k_tile or the two passes by the bytes a CALL reads (box2_setup): the whole image may
+     * say k_tile where a later strip says two passes, and that strip must not find itself allocating under stream
+     * capture -- so ask "could any row range take the two passes?" */
+    probe.box_force = 2;
     return classify (probe) == KC_BOX2;
 }
 
@@ -278,8 +282,9 @@ smol_hip_scale_rows_device (SmolHipPlan *plan,
         return rc;
     /* the kernels index the intermediate image from the job's first source row:
      * shift the base so that row r of the image always lands at r * w_out * 8 */
-    void *scratch = static_cast<uint8_t *> (sl->buf) + (size_t) probe.tmp_row0 * probe.w_out * box2_tmp_px (probe);
-    HIP_TRY (launch_single (jd, stream, scratch));
+    const size_t scratch_ofs = (size_t) probe.tmp_row0 * probe.w_out * box2_tmp_px (probe);
+    void *scratch = static_cast<uint8_t *> (sl->buf) + scratch_ofs;
+    HIP_TRY (launch_single (jd, stream, scratch, plan_box_bytes (plan) - scratch_ofs));
     if (use)
     {
         HIP_TRY (hipEventRecord (use->done, stream));

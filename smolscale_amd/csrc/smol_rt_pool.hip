@@ -107,6 +107,8 @@ struct Pool
     {
         if (want > max_threads)
             want = max_threads;
+        if (stop)
+            return;
         try
         {
             while (threads.size () < want)
@@ -151,17 +153,24 @@ struct Pool
         }
     }
 
+    /* The thread vector only changes under `mtx': taken out here and joined outside the lock (a helper that is
+     * leaving a job needs the lock to say so). A run() that arrives meanwhile finds `stop' set and works through its
+     * items alone -- grow() makes no thread while the pool is stopping. */
     void shutdown ()
     {
+        std::vector<std::thread> gone;
         {
             std::lock_guard<std::mutex> g (mtx);
             stop = true;
+            gone.swap (threads);
         }
         cv.notify_all ();
-        for (std::thread &t : threads)
+        for (std::thread &t : gone)
             t.join ();
-        threads.clear ();
-        stop = false;
+        {
+            std::lock_guard<std::mutex> g (mtx);
+            stop = false;
+        }
     }
 };
 
@@ -185,7 +194,7 @@ copy_threads_default ()
 /* heap objects that are never destroyed at exit: threads may be parked in them */
 Pool *g_pools [2];
 std::mutex g_pools_mtx;
-uint32_t g_copy_helpers = 0;
+std::atomic<uint32_t> g_copy_helpers { 0 };  /* written once under g_pools_mtx, read anywhere */
 
 Pool *
 pool_get (PoolId id)
@@ -195,7 +204,8 @@ pool_get (PoolId id)
     {
         if (id == POOL_COPY)
             g_copy_helpers = copy_threads_default ();
-        g_pools [id] = new (std::nothrow) Pool (id == POOL_COPY ? (g_copy_helpers ? g_copy_helpers : 1) : MAX_DEVICES);
+        const uint32_t ch = g_copy_helpers.load ();
+        g_pools [id] = new (std::nothrow) Pool (id == POOL_COPY ? (ch ? ch : 1) : MAX_DEVICES);
     }
     return g_pools [id];
 }
@@ -332,7 +342,7 @@ copy_rows (const RowCopy &rc)
     c.total = total;
     c.slice = COPY_SLICE;
     const uint32_t n = (uint32_t) ((total + c.slice - 1) / c.slice);
-    run_items (POOL_COPY, copy_item, &c, n, g_copy_helpers);
+    run_items (POOL_COPY, copy_item, &c, n, g_copy_helpers.load ());
 }
 
 } /* namespace smolrt */

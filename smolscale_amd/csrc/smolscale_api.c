@@ -21,6 +21,7 @@
  *                                (the reference's "first capable implementation wins",
  *                                smolscale.c:790-810). */
 
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -278,10 +279,9 @@ ctx_init (SmolScaleCtx *ctx,
             if (i > 0)
             {
                 /* never silent: say once per process that a later backend took over */
-                static int said;
-                if (!said)
+                static atomic_flag said = ATOMIC_FLAG_INIT;
+                if (!atomic_flag_test_and_set (&said))
                 {
-                    said = 1;
                     fprintf (stderr, "smolscale_amd: backend %s is not usable here, using %s (SMOL_BACKEND=auto)\n",
                              backends [0]->name, backends [i]->name);
                 }

@@ -5,6 +5,40 @@
 #define SMOL_KERNEL_EMU 1
 #include "smol_kernels_all.hip.h"
 
+namespace smolhip {
+/* k_lind under host emulation: one entry that switches at run time (the product has one entry point per flavour,
+ * smol_k_updown.hip) */
+__global__ void k_down_one (const JobDev J)
+{
+    const int in = J.p16 ? 2 : J.bpp_in == 3 ? 1 : 0;
+    if (dispatch::lind_narrow (J))              /* tiles of at most 64 columns: the one-column flavour */
+    {
+        switch (J.halv_h * 3 + in)
+        {
+            case 3: lind_entry<1, false, false, true> (J, smol_dyn_lds); break;
+            case 4: lind_entry<1, true, false, true> (J, smol_dyn_lds); break;
+            case 5: lind_entry<1, false, true, true> (J, smol_dyn_lds); break;
+            case 6: lind_entry<2, false, false, true> (J, smol_dyn_lds); break;
+            case 7: lind_entry<2, true, false, true> (J, smol_dyn_lds); break;
+            default: lind_entry<2, false, true, true> (J, smol_dyn_lds); break;
+        }
+        return;
+    }
+    switch (J.halv_h * 3 + in)
+    {
+        case 0: lind_entry<0, false, false> (J, smol_dyn_lds); break;
+        case 1: lind_entry<0, true, false> (J, smol_dyn_lds); break;
+        case 2: lind_entry<0, false, true> (J, smol_dyn_lds); break;
+        case 3: lind_entry<1, false, false> (J, smol_dyn_lds); break;
+        case 4: lind_entry<1, true, false> (J, smol_dyn_lds); break;
+        case 5: lind_entry<1, false, true> (J, smol_dyn_lds); break;
+        case 6: lind_entry<2, false, false> (J, smol_dyn_lds); break;
+        case 7: lind_entry<2, true, false> (J, smol_dyn_lds); break;
+        default: lind_entry<2, false, true> (J, smol_dyn_lds); break;
+    }
+}
+} /* namespace smolhip */
+
 #include <thread>
 #include <vector>
 
@@ -210,6 +244,41 @@ emu_scale_rows (const SmolHipJob *job, const void *src, uint32_t stride_in,
 /* lerp11_pk (smol_kernel_tile.hip.h) against the reference's tap formula over EVERY (p, q, F) of the sRGB-linear
  * class: 11-bit p and q in the low lane (the high lane runs a permuted pair), F in 0..256. Returns the number of
  * mismatches. */
+/* The host road's rule for strips cut into chunks (smol_rt_lanes.hip: strip_classify, then JobDev::box_force on every
+ * chunk), replayed without a GPU: returns 0 when every chunk of `rows_per_chunk' rows takes the road the strip's probe
+ * chose and fits the intermediate image the probe sized; 1 + the first offending chunk otherwise. `use_force' = 0 shows
+ * what the chunks would decide on their own (the round-4 behaviour). *strip_class / *flips report what was seen. */
+extern "C" int
+emu_strip_chunks_agree (const SmolHipJob *job, uint32_t src_pitch, uint32_t dst_pitch, uint32_t first_row, uint32_t n_rows,
+                        uint32_t rows_per_chunk, int use_force, int *strip_class, int *flips)
+{
+    const StripClass sc = strip_classify (*job, src_pitch, dst_pitch, first_row, n_rows);
+    int bad = 0, n_flips = 0;
+
+    if (strip_class)
+        *strip_class = (int) sc.k;
+    for (uint32_t done = 0, c = 0; done < n_rows; done += rows_per_chunk, c++)
+    {
+        const uint32_t rows = n_rows - done < rows_per_chunk ? n_rows - done : rows_per_chunk;
+        JobDev jd;
+        fill_jobdev (jd, *job, reinterpret_cast<const void *> (uintptr_t (16)), src_pitch,
+                     reinterpret_cast<void *> (uintptr_t (16)), dst_pitch, first_row + done, rows);
+        if (use_force)
+            jd.box_force = sc.box_force;
+        const KClass k = classify (jd);
+        const bool flip = (k == KC_BOX2) != (sc.k == KC_BOX2) || (k == KC_BOX2 && box2_tmp_bytes (jd) > sc.tmp_bytes);
+        if (flip)
+        {
+            n_flips++;
+            if (!bad)
+                bad = 1 + (int) c;
+        }
+    }
+    if (flips)
+        *flips = n_flips;
+    return bad;
+}
+
 extern "C" long
 emu_lerp11_exhaustive (void)
 {

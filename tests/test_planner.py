@@ -156,3 +156,40 @@ def test_input_row_range_rejects_ranges_that_wrap_32_bits():
     for first, n in ((0xFFFFFFFF, 2), (0xFFFFFFF0, 0x20), (32, 1), (31, 2), (0, 33), (0, 0)):
         assert fn(ctypes.byref(job), first, n, ctypes.byref(a), ctypes.byref(b)) == -10001, (first, n)
     assert fn(ctypes.byref(job), 31, 1, ctypes.byref(a), ctypes.byref(b)) == 0
+
+
+def test_chunks_of_a_host_strip_take_the_road_the_strip_chose():
+    """64bpp-class box x box picks the single pass (k_tile) or the two passes by the bytes a
+    launch reads. The host road sizes the intermediate image from a probe of the whole strip and then launches the
+    strip in chunks of ~8 MB: every chunk must take the probe's road (JobDev::box_force) -- on their own the chunks
+    of a >= 150 MB source say "two passes" where the strip said k_tile, and find no intermediate image. Replayed
+    on the dispatcher itself (tests/emu: strip_classify + classify per chunk), no GPU."""
+    import ctypes
+    emu = H.emu()
+    emu.emu_strip_chunks_agree.restype = ctypes.c_int
+    KC_TILE, KC_BOX2 = 3, 10
+    seen = set()
+    for (t_in, w_in, h_in, t_out, w_out, h_out) in (
+            (0, 8000, 6000, 0, 800, 600),          # the advisor's three reproducers
+            (0, 12000, 9000, 0, 1200, 900),
+            (8, 16000, 12000, 8, 1000, 750),
+            (0, 4096, 4096, 0, 448, 448),          # BOX row: one image is below the threshold -> two passes throughout
+            (0, 16384, 16384, 0, 900, 900),        # ratio 18.2, 1 GiB
+            (8, 4000, 3000, 8, 200, 150)):         # thumbnails: two passes whatever the size
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+        sp, dp = w_in * H.bpp(t_in), w_out * H.bpp(t_out)
+        # the road's own chunking: ~8 MB of traffic per chunk, at most 32 chunks
+        total = h_in * sp + h_out * dp
+        n_chunks = max(1, min(32, h_out, -(-total // (8 << 20))))
+        rpc = -(-h_out // n_chunks)
+        for first, n in ((0, h_out), (h_out // 3, h_out // 2)):
+            k, flips = ctypes.c_int(), ctypes.c_int()
+            rc = emu.emu_strip_chunks_agree(ctypes.byref(job), sp, dp, first, n, rpc, 1, ctypes.byref(k), ctypes.byref(flips))
+            assert rc == 0 and flips.value == 0, (w_in, h_in, w_out, h_out, first, n, k.value, flips.value)
+            assert k.value in (KC_TILE, KC_BOX2)
+            seen.add(k.value)
+            if (w_in, h_in) == (8000, 6000) and n == h_out:
+                # ... and this is the hazard: without the verdict handed down, the chunks flip
+                rc = emu.emu_strip_chunks_agree(ctypes.byref(job), sp, dp, first, n, rpc, 0, ctypes.byref(k), ctypes.byref(flips))
+                assert k.value == KC_TILE and rc != 0 and flips.value > 0
+    assert seen == {KC_TILE, KC_BOX2}
