@@ -781,17 +781,19 @@ down_setup (JobDev &d)
     return true;
 }
 
-/* tiles of the job (a workgroup takes 4) */
+/* tiles of the job (a workgroup takes lind_waves () of them) */
 inline uint32_t
 down_blocks (const JobDev &d)
 {
     return ((d.w_out + d.group_rows - 1u) / d.group_rows) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
 }
 
+inline uint32_t lind_waves (const JobDev &) { return 4u; }     /* waves (= tiles) per workgroup, around one copy of the tables */
+
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
-    return DOWN_LUT_BYTES + 4u * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
+    return DOWN_LUT_BYTES + lind_waves (d) * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
 }
 
 /* host twin of the device box_span (smol_kernels.hip.h; closed form of smolscale.c's box precalc) */

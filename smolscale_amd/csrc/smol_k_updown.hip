@@ -20,18 +20,19 @@ void
 launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
     /* tiles of at most 64 columns (one or two halvings): the one-column flavour, a kernel of its own */
+    const dim3 block (64u * smolhip::dispatch::lind_waves (rep));
     if (HX >= 1 && smolhip::dispatch::lind_narrow (rep))
     {
         if (jobs_dev)
-            hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN, HX >= 1>), grid, dim3 (256), lds, s, jobs_dev);
+            hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN, HX >= 1>), grid, block, lds, s, jobs_dev);
         else
-            hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN, HX >= 1>), grid, dim3 (256), lds, s, rep);
+            hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN, HX >= 1>), grid, block, lds, s, rep);
         return;
     }
     if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN>), grid, dim3 (256), lds, s, jobs_dev);
+        hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN>), grid, block, lds, s, jobs_dev);
     else
-        hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN>), grid, dim3 (256), lds, s, rep);
+        hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN>), grid, block, lds, s, rep);
 }
 
 template <int IN>
@@ -85,11 +86,12 @@ launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds
 namespace smolhip {
 namespace launch {
 
-/* grid.x counts tiles; a workgroup runs 4 of them (4 waves) */
+/* grid.x counts tiles; a workgroup runs lind_waves () of them (one per wave) */
 void
 down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
-    grid.x = (grid.x + 3) / 4;
+    const uint32_t wv = smolhip::dispatch::lind_waves (rep);
+    grid.x = (grid.x + wv - 1) / wv;
     if (rep.p16)
         launch_lind<2> (jobs_dev, rep, grid, lds, s);
     else if (rep.bpp_in == 3)

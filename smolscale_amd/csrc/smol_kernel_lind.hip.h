@@ -479,6 +479,408 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     }
 }
 
+/* ------------------------------------------------------------------------------------------------------------ *
+ * k_lind for sources WITHOUT an alpha channel (24-bit rows, gamma-correct): three channels, hand-placed staging  *
+ * ------------------------------------------------------------------------------------------------------------ *
+ * Round 4's counters on the gamma-correct photograph row (4000 x 3000 RGB8 -> 1600 x 1200, profiles/
+ * r04final_sq_srgbphoto.txt): 39 vector lane-operations per SOURCE pixel for an image that has no alpha at all.
+ * The disassembly says where they go: staging a pixel is 15 of them -- a 64-bit address add for its load, a byte
+ * shift, then per channel a v_bfe + a v_lshl_add for the table address and, after the three look-ups, two packing
+ * instructions -- and a tap is twelve packed 16-bit instructions for four channels of which one is the constant
+ * 255. Here (same arithmetic as lind_body, smolscale-generic.c:588-614 unpack, :1290-1425 / :1648-2007 filters,
+ * :922-935 / :1010-1023 pack):
+ *   unpack   the pixel's three bytes in MEMORY order (whether that is R,G,B or B,G,R is folded into the packer's
+ *            byte selectors: nothing between unpack and pack tells the channels apart) through the fused table:
+ *            per channel ONE SDWA shift (byte k, times two = the table address) and one look-up with the table's
+ *            address in its offset field, all look-ups of a row in flight together: 3 + 3 + 1 instructions and a
+ *            ds_write_b64 per pixel; the byte shift only in the one tile per row that holds the row's last pixel;
+ *   taps     on the packed pair as it comes from LDS, without unpacking: v_mad_u32_u16 picks the half it wants
+ *            (op_sel) -- (p * F + q * (256 - F)) >> 8 is two of them and a shift per channel, six 4-cycle and three
+ *            2-cycle instructions per pixel-tap against twelve 4-cycle ones; results are one register per channel,
+ *            which is how the vertical filter (24-bit multiplies with wave-uniform weights) and the packer want them;
+ *   alpha    is the constant 255: neither staged nor filtered; the packer is WP_LIN_O (or the `123' packer's WP_LIN_Q).
+ * Tile geometry, schedules and row order are lind_body's. */
+
+/* (byte B of w) << `sh' (sh in a register): the address of a table entry, in one SDWA shift */
+template <int B>
+__device__ __forceinline__ uint32_t smol_byte_x2 (uint32_t w, uint32_t one)
+{
+#ifdef SMOL_KERNEL_EMU
+    return ((w >> (8 * B)) & 0xffu) << one;
+#else
+    uint32_t r;
+    if (B == 0)
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v" (r) : "v" (one), "v" (w));
+    else if (B == 1)
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v" (r) : "v" (one), "v" (w));
+    else if (B == 2)
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v" (r) : "v" (one), "v" (w));
+    else
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v" (r) : "v" (one), "v" (w));
+    return r;
+#endif
+}
+
+/* One look-up in the 16-bit (8-bit) table at offset OFS of the workgroup's table copy, which starts at LDS address 0 (the
+ * kernels of this family have no static LDS, and lind_entry traps if that ever changes): the LDS pointer is made from
+ * the INTEGER a + OFS, so OFS lands in the instruction's offset field. Through the `lds' symbol the compiler adds the
+ * base -- a literal 0 it only learns at link time -- to every address in a vector instruction of its own. a = 2 * index
+ * (16-bit entries), a = index (bytes). Plain loads: the compiler keeps every look-up of a row in flight and counts its
+ * waits itself. (Round 5 also tried them as asm statements -- ds_read_u16_d16 / _d16_hi would drop two results into
+ * the halves of one register and save the packing instruction: on a chip with SRAM ECC a d16 load CLEARS the other
+ * half; and an in-flight destination register of an asm load may be copied by the compiler before the wait: wrong
+ * bytes on the GPU, right ones in the emulation.) */
+#ifndef SMOL_KERNEL_EMU
+typedef __attribute__ ((address_space (3))) const uint16_t smol_lds_u16;
+typedef __attribute__ ((address_space (3))) const uint8_t smol_lds_u8;
+#endif
+
+template <uint32_t OFS>
+__device__ __forceinline__ uint32_t smol_tab16 (uint32_t a, const uint8_t *lut_lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    return reinterpret_cast<const uint16_t *> (lut_lds + OFS) [a >> 1];
+#else
+    (void) lut_lds;
+    return *reinterpret_cast<smol_lds_u16 *> (a + OFS);
+#endif
+}
+
+template <uint32_t OFS>
+__device__ __forceinline__ uint32_t smol_tab8 (uint32_t a, const uint8_t *lut_lds)
+{
+#ifdef SMOL_KERNEL_EMU
+    return lut_lds [OFS + a];
+#else
+    (void) lut_lds;
+    return *reinterpret_cast<smol_lds_u8 *> (a + OFS);
+#endif
+}
+
+/* value of `v' in the NEXT lane of this lane's quad (lane 3 of a quad: its own): one DPP move */
+__device__ __forceinline__ uint32_t smol_quad_next (uint32_t v)
+{
+#ifdef SMOL_KERNEL_EMU
+    return smol_shfl_idx (v, (threadIdx.x & 3u) == 3u ? threadIdx.x : threadIdx.x + 1u);
+#else
+    return (uint32_t) __builtin_amdgcn_mov_dpp ((int) v, 0xF9 /* quad_perm:[1,2,3,3] */, 0xf, 0xf, true);
+#endif
+}
+
+/* one tap on a 16-bit half (HI: the upper one) of packed pixels p and q, weights W = F | (256 - F) << 16:
+ * p * F + q * (256 - F), not yet shifted (below 2^19 for 11-bit values) */
+template <int HI>
+__device__ __forceinline__ uint32_t tap16_half (uint32_t p, uint32_t q, uint32_t W)
+{
+#ifdef SMOL_KERNEL_EMU
+    const uint32_t pv = HI ? p >> 16 : p & 0xffffu, qv = HI ? q >> 16 : q & 0xffffu;
+    return pv * (W & 0xffffu) + qv * (W >> 16);
+#else
+    uint32_t t, r;
+    if (HI)
+    {
+        asm ("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[1,1,0,0]" : "=v" (t) : "v" (q), "v" (W));
+        asm ("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v" (r) : "v" (p), "v" (W), "v" (t));
+    }
+    else
+    {
+        asm ("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[0,1,0,0]" : "=v" (t) : "v" (q), "v" (W));
+        asm ("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v" (r) : "v" (p), "v" (W), "v" (t));
+    }
+    return r;
+#endif
+}
+
+template <int HX, bool NARROW>
+__device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
+                                            const uint32_t lane, const uint32_t tile)
+{
+    constexpr uint32_t NSX = 1u << HX;
+    constexpr int CPL = NARROW ? 1 : 2;
+    constexpr int KMAX = NARROW ? LIND_KMAX_NARROW : LIND_KMAX;
+    constexpr uint32_t OQ = 6656u;                                  /* LutLds::oq, the fused table for opaque pixels */
+    const uint32_t W = J.group_rows;
+
+    const uint32_t tiles_x = (J.w_out + W - 1) / W;
+    const uint32_t tx = tile % tiles_x;
+    const uint32_t ty = tile / tiles_x;
+    const uint32_t yrel0 = ty * J.tile_rows;
+    if (yrel0 >= J.n_rows)
+        return;
+    const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
+    const uint32_t x0 = tx * W;
+    const uint32_t xn = (x0 + W < J.w_out) ? x0 + W : J.w_out;
+
+    /* ---- horizontal samples of this lane's columns ------------------------------------------------------------ */
+    uint32_t xc [CPL];
+    bool ok [CPL];
+    uint32_t tap_ofs [CPL][NSX], tap_w [CPL][NSX];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+    {
+        xc [c] = x0 + 64u * c + lane;
+        ok [c] = xc [c] < xn;
+        const uint32_t x = ok [c] ? xc [c] : xn - 1;
+        uint64_t pos = J.frac0_x + (uint64_t) (x << HX) * J.step_x;
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+        {
+            uint32_t f;
+            bilin_tap (pos, J.w_in, tap_ofs [c][s], f);
+            if (J.filter_h == F_ONE)
+            {
+                tap_ofs [c][s] = 0;                                 /* (an axis of ONE pixel: lind_body) */
+                f = 256;
+            }
+            tap_w [c][s] = f | ((256u - f) << 16);
+            pos += J.step_x;
+        }
+    }
+    const uint32_t sx0 = smol_readlane (tap_ofs [0][0], 0);
+    uint32_t sx1, f_unused;
+    bilin_tap (J.frac0_x + (uint64_t) ((xn << HX) - 1) * J.step_x, J.w_in, sx1, f_unused);
+    sx1 += 1;
+    if (J.filter_h == F_ONE)
+        sx1 = 0;
+    const uint32_t npx = sx1 - sx0 + 1;
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (uint32_t s = 0; s < NSX; s++)
+            tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * 8u;
+
+    /* ---- vertical schedule (lind_body's) ------------------------------------------------------------------------ */
+    const uint32_t hv = J.halv_v;
+    const uint32_t nsy = 1u << hv;
+    const uint32_t jy0 = (J.first_row + yrel0) << hv;
+    const uint32_t n_samples = (yrel1 - yrel0) << hv;
+    uint32_t sched [2] = { 0, 0 };
+    const bool v_flat = J.filter_v == F_COPY || J.filter_v == F_ONE;
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++)
+    {
+        uint32_t k = q * 64u + lane;
+        if (k >= n_samples)
+            k = n_samples - 1;
+        uint32_t o, f;
+        bilin_tap (J.frac0_y + (uint64_t) (jy0 + k) * J.step_y, J.h_in, o, f);
+        if (v_flat)
+        {
+            o = J.filter_v == F_ONE ? 0u : jy0 + k;
+            f = 0;
+        }
+        sched [q] = o | (f << 16);
+    }
+    uint32_t e = smol_readlane (sched [0], 0);
+    const uint32_t e_last = smol_readlane (sched [(n_samples - 1) >> 6], (n_samples - 1) & 63u);
+    const uint32_t vdue = v_flat ? 0u : 1u;
+    uint32_t oy = e & 0xffffu, Fy = e >> 16;
+    const uint32_t row_first = oy;
+    const uint32_t row_last = (e_last & 0xffffu) + vdue;
+
+    /* ---- staging ----------------------------------------------------------------------------------------------- */
+    const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;
+    /* the row's last pixel is read one byte early and shifted (its dword would end past the row): only the tile that
+     * holds it pays the shift */
+    const bool has_last = sx0 + npx == J.w_in;
+    uint32_t px_off [KMAX];
+    uint32_t px_sh = 0;                                             /* bytes to shift by: 1 in the slots of the last pixel */
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+    {
+        const uint32_t i = (uint32_t) k * 64u + lane;
+        const uint32_t x = sx0 + (i < npx ? i : npx - 1);
+        const uint32_t sh = x == J.w_in - 1u ? 1u : 0u;
+        px_off [k] = x * 3u - sh;
+        px_sh |= sh << k;
+    }
+    uint32_t rawpx [KMAX];
+    const uint32_t one = 1u;
+    const uint32_t n_rounds = (npx + 63u) >> 6;                     /* wave-uniform, <= KMAX (host) */
+
+    auto load_row = [&] ()
+    {
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if ((uint32_t) k < n_rounds)
+            {
+#ifdef SMOL_KERNEL_EMU
+                __builtin_memcpy (&rawpx [k], srow + px_off [k], 4);
+#else
+                /* (the offset is made opaque here so that the compiler keeps it a 32-bit value beside the row's scalar base
+                 * -- global_load_dword v, v_off, s[base] -- instead of widening it once outside the loop and adding 64-bit
+                 * pairs in a vector instruction per load) */
+                uint32_t off = px_off [k];
+                asm volatile ("" : "+v" (off));
+                rawpx [k] = *reinterpret_cast<const SMOL_AS_GLOBAL u32a1 *> (srow + off);
+#endif
+            }
+        srow += J.src_stride;
+    };
+
+    auto convert_row = [&] ()
+    {
+        if (has_last)
+        {
+            /* (a real branch, taken by one tile per row: the empty asm statement keeps the compiler from turning it into
+             * a shift and a select per pixel for everybody) */
+            asm volatile ("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                if ((uint32_t) k < n_rounds)
+                    rawpx [k] = __builtin_amdgcn_alignbyte (0u, rawpx [k], (px_sh >> k) & 1u);
+        }
+        /* all look-ups of the row in flight together, then the stores (two passes over the rounds, each behind the
+         * wave-uniform "does this round exist") */
+        uint32_t t [KMAX][3];
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if ((uint32_t) k < n_rounds)
+            {
+                t [k][0] = smol_tab16<OQ> (smol_byte_x2<0> (rawpx [k], one), lut_lds);
+                t [k][1] = smol_tab16<OQ> (smol_byte_x2<1> (rawpx [k], one), lut_lds);
+                t [k][2] = smol_tab16<OQ> (smol_byte_x2<2> (rawpx [k], one), lut_lds);
+            }
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if ((uint32_t) k < n_rounds)
+                *reinterpret_cast<u32x2a8 *> (buf + ((uint32_t) k * 64u + lane) * 8u) = u32x2a8 { t [k][0] | (t [k][1] << 16), t [k][2] };
+    };
+
+    /* ---- the row loop -------------------------------------------------------------------------------------------- */
+    /* the packer sees the channels in the source's memory order: R and B trade places in its selectors for B,G,R rows */
+    JobDev Jp = J;
+    if (J.pos_in [0] != 0)
+    {
+        Jp.pos_out [0] = J.pos_out [2];
+        Jp.pos_out [2] = J.pos_out [0];
+    }
+    /* 24-bit output: the four pixels of a quad of lanes are twelve bytes = three dwords. Lane j of the quad (j < 3) takes
+     * pixel j + 1 from its neighbour (one DPP move), cuts dword j out of the two (one v_perm, selector by j) and stores it
+     * at its pixel's address + j (global stores need no alignment on gfx950): one 4-byte store on 48 lanes where there
+     * were a 2-byte and a 1-byte store on 64, three instructions of shifting and a 64-bit address add. Quads that reach
+     * past the tile's last column keep the byte stores. */
+    const uint32_t qj = lane & 3u;
+    const uint32_t q_sel = qj == 0 ? 0x04020100u : qj == 1 ? 0x05040201u : 0x06050402u;
+    bool q_full [CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        q_full [c] = xc [c] - qj + 3u < xn;                         /* the quad's last pixel is inside the tile */
+    const LutLds lut (lut_lds);
+    const WidePack<WP_LIN_O> wp (Jp, lut);                          /* (its byte selectors; WP_LIN_Q's are the same) */
+    const bool quirk = wide_pack_kind (J) == WP_LIN_Q;
+    constexpr uint32_t TS = 4608u;                                  /* LutLds::ts, the to_srgb table */
+    gbyte *out_row = gptr (J.dst) + (size_t) yrel0 * J.dst_stride;
+    uint32_t ks = 0, s_y = 0;
+    uint32_t hp [CPL][3], acc [CPL][3];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            hp [c][i] = acc [c][i] = 0;
+
+    load_row ();
+
+    for (uint32_t r = row_first; r <= row_last; r++)
+    {
+        uint32_t h [CPL][3];
+        smol_wave_sync ();
+        convert_row ();
+        smol_wave_sync ();
+        if (r < row_last)
+            load_row ();
+
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+        {
+            uint32_t hs [3];
+#pragma unroll
+            for (uint32_t s = 0; s < NSX; s++)
+            {
+                const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (buf + tap_ofs [c][s]);
+                const uint32_t t0 = tap16_half<0> (pq.x, pq.z, tap_w [c][s]) >> 8;
+                const uint32_t t1 = tap16_half<1> (pq.x, pq.z, tap_w [c][s]) >> 8;
+                const uint32_t t2 = tap16_half<0> (pq.y, pq.w, tap_w [c][s]) >> 8;
+                hs [0] = s ? hs [0] + t0 : t0;
+                hs [1] = s ? hs [1] + t1 : t1;
+                hs [2] = s ? hs [2] + t2 : t2;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                h [c][i] = hs [i] >> HX;
+        }
+
+        while (ks < n_samples && oy + vdue == r)
+        {
+            const uint32_t Gy = 256u - Fy;
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    acc [c][i] += tap32 (hp [c][i], h [c][i], Fy, Gy);      /* (zeroed behind every output row) */
+            s_y++;
+            ks++;
+            if (s_y == nsy)
+            {
+                /* pack: alpha is 255 -- the inverse for 255 is 1028 = 1024 + 4, (s * 1028) >> 10 = s + (s >> 8), one look-up
+                 * per channel (WP_LIN_O); the `123' packer feeds the lane as it is (WP_LIN_Q, smolscale-generic.c:922-935) */
+                uint32_t tb [CPL][3];
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                    {
+                        const uint32_t v = acc [c][i] >> hv;
+                        tb [c][i] = smol_tab8<TS> ((quirk ? v : v + (v >> 8)) & 0x7ffu, lut_lds);
+                        acc [c][i] = 0;
+                    }
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                {
+                    const uint32_t w = wp.assemble (tb [c][0], tb [c][1], tb [c][2], 0xffu);
+                    if (J.bpp_out == 3)
+                    {
+                        const uint32_t d = __builtin_amdgcn_perm (smol_quad_next (w), w, q_sel);
+                        if (q_full [c])
+                        {
+                            if (qj != 3u)
+                            {
+#ifdef SMOL_KERNEL_EMU
+                                __builtin_memcpy (out_row + (size_t) xc [c] * 3 + qj, &d, 4);
+#else
+                                *reinterpret_cast<SMOL_AS_GLOBAL u32a1 *> (out_row + (xc [c] * 3u + qj)) = d;
+#endif
+                            }
+                        }
+                        else if (ok [c])
+                            wide_store_word (J, out_row, xc [c], w);
+                    }
+                    else if (ok [c])
+                    {
+                        if (J.out_dword_ok)
+                            *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;
+                        else
+                            wide_store_word (J, out_row, xc [c], w);
+                    }
+                }
+                s_y = 0;
+                out_row += J.dst_stride;
+            }
+            if (ks < n_samples)
+            {
+                e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
+                oy = e & 0xffffu;
+                Fy = e >> 16;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                hp [c][i] = h [c][i];
+    }
+}
+
 /* LDS of one wave: the row buffer */
 __device__ __forceinline__ uint32_t lind_wave_lds (bool w32, bool narrow = false)
 {
@@ -494,7 +896,10 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
-    lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    if (IN24 && !W32)
+        lind3_body<HX, NARROW> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+    else
+        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     /* (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same on every lane of a wave, and
      * without it everything derived from the tile index -- every loop bound, every "is this round needed" test --
@@ -503,7 +908,15 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     uint8_t *tab_end = lds + ((LUT_LDS_BYTES + 15u) & ~15u);       /* (the host sizes the workgroup's LDS by the flavour too: down_lds_bytes) */
-    lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, tab_end + wave * lind_wave_lds (W32, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    if (IN24 && !W32)
+    {
+        /* (lind3_body's look-ups carry the tables' LDS addresses as immediates: the workgroup's copy starts at address 0) */
+        if (reinterpret_cast<uintptr_t> (lds) & 0x3ffffu)
+            __builtin_trap ();
+        lind3_body<HX, NARROW> (J, tab_end + wave * lind_wave_lds (false, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+    }
+    else
+        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, tab_end + wave * lind_wave_lds (W32, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
 }
 

@@ -175,9 +175,14 @@ def natural_bytes(n_bytes, bytes_pp, width, rng):
     return out.reshape(-1)[:n_bytes]
 
 
+IMAGES_OVERRIDE = None      # --images N
+
+
 def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False, natural=False):
     cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
+    if IMAGES_OVERRIDE:
+        n_images = IMAGES_OVERRIDE                  # launch-size sensitivity (tail effects of small launches)
     srgb = cfg[9] if len(cfg) > 9 else 0
     src_off = cfg[10] if len(cfg) > 10 else 0
     if tin is not None:
@@ -327,8 +332,11 @@ def main(argv=None, checker=None):
     ap.add_argument("--no-arena", action="store_true", help="one allocation per image even for small images")
     ap.add_argument("--opaque", action="store_true", help="set the alpha channel of 32-bit inputs to 255 (like real photographs)")
     ap.add_argument("--natural", action="store_true", help="image-like source bytes (smooth ramps + a little noise) instead of white noise")
+    ap.add_argument("--images", type=int, default=None, help="override the number of images per launch")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of warm-up load before timing (clock settling)")
     args = ap.parse_args(argv)
+    global IMAGES_OVERRIDE
+    IMAGES_OVERRIDE = args.images
     for name in args.configs.split(","):
         print(json.dumps(run_config(name, args.iters, args.warmup, checker, args.graph,
                                     args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena, args.natural)), flush=True)
