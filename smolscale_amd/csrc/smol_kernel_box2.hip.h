@@ -97,7 +97,7 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
     const uint32_t first_ofs = (o0 - sx0) * bpp;
     const uint32_t int_ofs = first_ofs + (1u + i_begin) * bpp;      /* first interior pixel of this lane */
     const uint32_t last_ofs = first_ofs + (n_col + 1u) * bpp;       /* the column's last pixel */
-    const LutLds lut (lut_lds);
+    const LutLds lut (lut_lds, LUT_AT_LDS_0);       /* (boxh_entry / boxv_entry: lut_expect_lds_0) */
     const uintptr_t src_base = (uintptr_t) J.src;
 
     auto rows = [&] (auto aligned_tag, const auto &un)
@@ -406,7 +406,7 @@ __device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_l
         return;
     const uint32_t xc = active ? x : J.w_out - 1;                   /* idle lane groups shadow the last column (shuffles below) */
 
-    const LutLds lut (lut_lds);
+    const LutLds lut (lut_lds, LUT_AT_LDS_0);       /* (boxh_entry / boxv_entry: lut_expect_lds_0) */
     uint32_t y0, y1, w2, w1;
     box_span (J.step_y, J.h_in, J.first_row + row, y0, y1, w2, w1);
     /* 128bpp-class rows weight the last row by w2 - 1 and skip it when w2 == 0
@@ -521,6 +521,7 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     const uint32_t tr = J.box2_ygroup ? blockIdx.y * 4u + wave : blockIdx.y;
     if (WIDE)
     {
+        lut_expect_lds_0 (lds);
         lut_fill_lds (lds, threadIdx.x, 256);
         __syncthreads ();
     }
@@ -554,6 +555,7 @@ __device__ __forceinline__ void boxv_entry (const JobDev &J, uint8_t *lds)
 #else
     if (WIDE)
     {
+        lut_expect_lds_0 (lds);
         lut_fill_lds (lds, threadIdx.x, 256);
         __syncthreads ();
     }

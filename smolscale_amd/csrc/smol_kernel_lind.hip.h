@@ -158,7 +158,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                                              : (e_last & 0xffffu) + vdue;
 
     /* ---- staging -------------------------------------------------------------------- */
-    const LutLds lut (lut_lds);
+    const LutLds lut (lut_lds, LUT_AT_LDS_0);       /* (the entries see to it: lut_expect_lds_0) */
     const int uk = wide_unpack_kind (J), pk = wide_pack_kind (J);
     const gbyte *srow = gptr (J.src) + (size_t) row_first * J.src_stride;   /* row being loaded */
     /* slot k * 64 + lane holds pixel min (slot, npx - 1) of the span; px_off: its byte offset in a source row */
@@ -397,7 +397,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                     for (int i = 0; i < NCH; i++)
                     {
                         const uint32_t t = W32 ? tap32 (hp [c][i], h [c][i], Fy, Gy) : lerp11_pk (hp [c][i], h [c][i], wy);
-                        acc [c][i] = s_y ? acc [c][i] + t : t;
+                        acc [c][i] += t;                /* (zeroed behind every output row: a select per sample otherwise) */
                     }
                 }
             s_y++;
@@ -460,6 +460,11 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                     put (WidePack<WP_LIN_Q> (J, lut));
                 s_y = 0;
                 out_row += J.dst_stride;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+#pragma unroll
+                    for (int i = 0; i < NCH; i++)
+                        acc [c][i] = 0;
             }
             if (ks < n_samples)
             {
@@ -766,7 +771,7 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
 #pragma unroll
     for (int c = 0; c < CPL; c++)
         q_full [c] = xc [c] - qj + 3u < xn;                         /* the quad's last pixel is inside the tile */
-    const LutLds lut (lut_lds);
+    const LutLds lut (lut_lds, LUT_AT_LDS_0);
     const WidePack<WP_LIN_O> wp (Jp, lut);                          /* (its byte selectors; WP_LIN_Q's are the same) */
     const bool quirk = wide_pack_kind (J) == WP_LIN_Q;
     constexpr uint32_t TS = 4608u;                                  /* LutLds::ts, the to_srgb table */
@@ -905,14 +910,12 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
      * without it everything derived from the tile index -- every loop bound, every "is this round needed" test --
      * is computed per lane and branched on with exec masks) */
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
+    lut_expect_lds_0 (lds);                             /* (the bodies' look-ups carry the tables' LDS addresses as immediates) */
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     uint8_t *tab_end = lds + ((LUT_LDS_BYTES + 15u) & ~15u);       /* (the host sizes the workgroup's LDS by the flavour too: down_lds_bytes) */
     if (IN24 && !W32)
     {
-        /* (lind3_body's look-ups carry the tables' LDS addresses as immediates: the workgroup's copy starts at address 0) */
-        if (reinterpret_cast<uintptr_t> (lds) & 0x3ffffu)
-            __builtin_trap ();
         lind3_body<HX, NARROW> (J, tab_end + wave * lind_wave_lds (false, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
     }
     else
@@ -933,6 +936,7 @@ __device__ __forceinline__ void linh_entry (const JobDev &J, uint8_t *lds)
     lind_body<HX, KIND == 1, KIND >= 2, LIND_H, KIND == 3> (J, lds, lut_lds, threadIdx.x, blockIdx.x);     /* emulated: blocks numbered tile by tile */
 #else
     const uint32_t wave = smol_wave_index ();
+    lut_expect_lds_0 (lds);
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     const uint32_t tiles_x = (J.w_out + J.group_rows - 1u) / J.group_rows;
@@ -949,6 +953,7 @@ __device__ __forceinline__ void linv_entry (const JobDev &J, uint8_t *lds)
     lut_fill_lds (lut_lds, 0, 1);
     lind_body<0, false, KIND >= 2, LIND_V, KIND == 3> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
+    lut_expect_lds_0 (lds);
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     lind_body<0, false, KIND >= 2, LIND_V, KIND == 3> (J, lds, lds, threadIdx.x & 63u, blockIdx.x * 4u + smol_wave_index ());

@@ -519,7 +519,7 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
     const uint32_t x0 = tx * TW;
     const uint32_t xn = (x0 + TW < J.w_out) ? x0 + TW : J.w_out;
     const uint32_t xl = x0 + lane * CPL;
-    const LutLds lut (lut_lds);
+    const LutLds lut (lut_lds, LUT_AT_LDS_0);       /* (upg_entry: lut_expect_lds_0) */
     const int uk = wide_unpack_kind (J), pk = wide_pack_kind (J);
 
     uint32_t tap_ofs [CPL], tap_f [CPL];
@@ -768,6 +768,7 @@ __device__ __forceinline__ void upg_entry (const JobDev &J, uint8_t *lds)
     upg_body<W32> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     const uint32_t wave = smol_wave_index ();       /* a SCALAR: everything derived from the tile index stays wave-uniform */
+    lut_expect_lds_0 (lds);
     lut_fill_lds (lds, threadIdx.x, 256);
     __syncthreads ();
     const uint32_t region = (UPG_NSRC * J.span_px * (W32 ? 16u : 8u) + 15u) & ~15u;

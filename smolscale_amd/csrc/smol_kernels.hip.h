@@ -188,16 +188,32 @@ struct LutConst
 
 constexpr uint32_t LUT_LDS_BYTES = SMOL_LUT_LDS_BYTES;
 
+/* LUT_AT_LDS_0: the workgroup's table copy starts at LDS address 0 -- true of every kernel that keeps it at the head of
+ * its dynamic LDS and has no static LDS (k_lind / k_linh / k_linv, k_upg, k_boxh / k_boxv; their entries trap if that ever
+ * changes). The table pointers are then made from INTEGERS, and a look-up is `ds_read v, v_index offset:<table>'. Through
+ * the `lds' symbol the compiler adds the base -- a literal 0 it only learns at link time -- to every index in a vector
+ * instruction of its own: one more instruction per byte-table look-up (to_srgb: three per output pixel of every
+ * gamma-correct job). */
+struct LutAtLds0 {};
+constexpr LutAtLds0 LUT_AT_LDS_0 = {};
+
+#ifdef SMOL_KERNEL_EMU
+#define SMOL_AS_LDS
+#else
+#define SMOL_AS_LDS __attribute__ ((address_space (3)))
+#endif
+
 struct LutLds
 {
-    const uint32_t *p8, *p8l, *p16, *p16l;
-    const uint16_t *fs, *oq;
-    const uint8_t *ts;
+    const SMOL_AS_LDS uint32_t *p8, *p8l, *p16, *p16l;
+    const SMOL_AS_LDS uint16_t *fs, *oq;
+    const SMOL_AS_LDS uint8_t *ts;
 
-    /* Plain pointer arithmetic on `base': going through an integer here made the compiler forget that the tables live
+    /* Typed LDS pointers: going through an untyped integer here once made the compiler forget that the tables live
      * in LDS (flat_load instead of ds_read: the gamma-correct rows ran 10-20 % slower for a few commits of round 3).
      * The 64bpp-class instantiations of the shared bodies have no table copy; they pass any valid LDS address. */
     __device__ __forceinline__ explicit LutLds (const uint8_t *base)
+#ifdef SMOL_KERNEL_EMU
         : p8 (reinterpret_cast<const uint32_t *> (base)),
           p8l (reinterpret_cast<const uint32_t *> (base + 1024)),
           p16 (reinterpret_cast<const uint32_t *> (base + 2048)),
@@ -205,6 +221,28 @@ struct LutLds
           fs (reinterpret_cast<const uint16_t *> (base + 4096)),
           oq (reinterpret_cast<const uint16_t *> (base + 6656)),
           ts (base + 4608) {}
+#else
+        : p8 ((const SMOL_AS_LDS uint32_t *) (base)),
+          p8l ((const SMOL_AS_LDS uint32_t *) (base + 1024)),
+          p16 ((const SMOL_AS_LDS uint32_t *) (base + 2048)),
+          p16l ((const SMOL_AS_LDS uint32_t *) (base + 3072)),
+          fs ((const SMOL_AS_LDS uint16_t *) (base + 4096)),
+          oq ((const SMOL_AS_LDS uint16_t *) (base + 6656)),
+          ts ((const SMOL_AS_LDS uint8_t *) (base + 4608)) {}
+#endif
+
+    __device__ __forceinline__ LutLds (const uint8_t *base, LutAtLds0)
+#ifdef SMOL_KERNEL_EMU
+        : LutLds (base) {}
+#else
+        : p8 (reinterpret_cast<const SMOL_AS_LDS uint32_t *> (0u)),
+          p8l (reinterpret_cast<const SMOL_AS_LDS uint32_t *> (1024u)),
+          p16 (reinterpret_cast<const SMOL_AS_LDS uint32_t *> (2048u)),
+          p16l (reinterpret_cast<const SMOL_AS_LDS uint32_t *> (3072u)),
+          fs (reinterpret_cast<const SMOL_AS_LDS uint16_t *> (4096u)),
+          oq (reinterpret_cast<const SMOL_AS_LDS uint16_t *> (6656u)),
+          ts (reinterpret_cast<const SMOL_AS_LDS uint8_t *> (4608u)) { (void) base; }
+#endif
 
     __device__ __forceinline__ uint32_t inv_p8 (uint32_t a) const { return p8 [a]; }
     __device__ __forceinline__ uint32_t inv_p8l (uint32_t a) const { return p8l [a]; }
@@ -214,6 +252,17 @@ struct LutLds
     __device__ __forceinline__ uint32_t to_srgb (uint32_t v) const { return ts [v]; }
     __device__ __forceinline__ uint32_t opaque_lin (uint32_t v) const { return oq [v]; }
 };
+
+/* the entries' guard for LUT_AT_LDS_0 (folds away when the compiler knows the address, costs a scalar compare otherwise) */
+__device__ __forceinline__ void lut_expect_lds_0 (const uint8_t *lds)
+{
+#ifndef SMOL_KERNEL_EMU
+    if (reinterpret_cast<uintptr_t> (lds) & 0x3ffffu)
+        __builtin_trap ();
+#else
+    (void) lds;
+#endif
+}
 
 /* cooperative copy of the tables into LDS (caller synchronises afterwards) */
 __device__ __forceinline__ void lut_fill_lds (uint8_t *base, uint32_t tid, uint32_t nthreads)
