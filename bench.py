@@ -755,6 +755,34 @@ def main():
         }
         if args.config == "c5mix":
             line["images_per_s"] = round(10000 * args.steps / elapsed, 1)
+            if w.batch is not None and world == 1:
+                # BASELINE config 5's own wording: "hipGraph-captured per-image launches". The same images as ONE hipGraph
+                # of one kernel node per image (smol_hip_batch_use_graph: captured on forked streams, instantiated once),
+                # beside the descriptor-table launch timed above; outputs verified again after the replays.
+                try:
+                    w.keep[1].zero_()
+                    torch.cuda.synchronize()
+                    tb = time.perf_counter()
+                    w.batch.use_graph(True)                  # capture + instantiate
+                    torch.cuda.synchronize()
+                    build_ms = (time.perf_counter() - tb) * 1e3
+                    w.batch.time(0, 2)
+                    g_each = w.batch.time_each(1, 10)
+                    g_ok = w.check()
+                    w.batch.use_graph(False)
+                    n_img = w.config["images_per_rank"]
+                    line["graph_mode"] = {
+                        "what": "the same %d images as one hipGraph of per-image kernel nodes (capture on forked streams, "
+                                "instantiated once, replayed)" % n_img,
+                        "capture_and_instantiate_ms": round(build_ms, 1),
+                        "replay_us": stats_us(g_each),
+                        "images_per_s": round(n_img / (min(g_each) * 1e-3), 1),
+                        "single_launch_us": stats_us(each) if each else None,
+                        "replay_over_single_launch": round(float(np.median(g_each)) / float(np.median(each)), 2) if each else None,
+                        "verified_vs_oracle": g_ok,
+                    }
+                except Exception as e:              # noqa: BLE001
+                    line["graph_mode"] = {"error": repr(e)}
         if backend_used:
             line["barrier_backend"] = backend_used
         if args.config == "c4" and w.batch is not None:
