@@ -143,6 +143,17 @@ int smol_hip_scale_rows_host (SmolHipPlan *plan,
                               void *dest_host, uint32_t rowstride_out,
                               uint32_t first_row, uint32_t n_rows);
 
+/* Callers that ask for their rows a few at a time (the reference's own outer loop is one row per step with a
+ * two-row cache, smolscale.c:507-546, smolscale-generic.c:1648-1682): the second small call that continues where the
+ * previous one ended computes a BAND of the rows that follow (about 2 MB of traffic) into a page-locked buffer the
+ * plan keeps; later calls inside the band are a memcpy. Nothing in smolscale.h forbids rewriting pixels_in between
+ * calls, so a call is served from the band only while the source rows its output rows read still hold the bytes
+ * the band was computed from (a memcmp of two or three rows on a bilinear axis; calls that move more than 256 KiB
+ * take the ordinary road). smol_hip_plan_resident_source (plan, 1) -- or SMOL_HIP_RESIDENT_SRC=1 in the
+ * environment -- is the caller's promise that the source does not change while the plan lives: no comparison,
+ * read-ahead for calls of any size, bands of 8 MB. SMOL_HIP_READAHEAD=0 turns read-ahead off. */
+int smol_hip_plan_resident_source (SmolHipPlan *plan, int resident);
+
 /* The same over several devices: rows [first_row, first_row+n_rows) are cut into one
  * strip per plan (ceil (n_rows / n_plans) rows each -- the reference's worker-thread
  * rule, test.c:870-877), every strip goes through its own plan's device as above, all

@@ -104,6 +104,7 @@ EXPORTS = {
     "smol_hip_host_unregister": (_int, [_vp]),
     "smol_hip_host_alloc": (_int, [_u64, ctypes.POINTER(_vp)]),
     "smol_hip_host_range_is_pinned": (_int, [_vp, _u64]),
+    "smol_hip_plan_resident_source": (_int, [_vp, _int]),
     "smol_hip_host_free": (_int, [_vp]),
     "smol_hip_scale_rows_device": (_int, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _vp]),
     "smol_hip_batch_create": (_int, [ctypes.POINTER(SmolHipImage), _u32, _int, ctypes.POINTER(_vp)]),
@@ -327,6 +328,9 @@ class HipPlan:
 
     def prepare(self):
         check(lib().smol_hip_plan_prepare(self._h), "smol_hip_plan_prepare")
+
+    def resident_source(self, on=True):
+        check(lib().smol_hip_plan_resident_source(self._h, int(on)), "smol_hip_plan_resident_source")
 
     def reserve(self, images_in_flight):
         check(lib().smol_hip_plan_reserve(self._h, images_in_flight), "smol_hip_plan_reserve")

@@ -153,6 +153,8 @@ struct SmolBoxSlot
     uint64_t tick = 0;
 };
 
+struct SmolRowCache;                    /* smol_rt_lanes.hip: read-ahead for callers that ask for their rows a few at a time */
+
 struct SmolHipPlan
 {
     SmolHipJob job;
@@ -160,4 +162,11 @@ struct SmolHipPlan
     std::mutex mtx;
     SmolBoxSlot box [SMOL_BOX_SLOTS];
     uint64_t box_tick = 0;
+    std::mutex rc_mtx;
+    SmolRowCache *rc = nullptr;         /* made when a caller's second small call follows its first */
 };
+
+namespace smolrt {
+void row_cache_release (SmolHipPlan *plan);     /* plan destruction */
+void row_cache_shutdown ();                     /* smol_hip_shutdown (): the spare buffers */
+}

@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
+#include <vector>
 
 using namespace smolhip::dispatch;
 
@@ -152,6 +154,38 @@ struct DeviceState
 };
 
 DeviceState g_devices [MAX_DEVICES];
+
+/* Ranges this library page-locked itself (smol_hip_host_alloc / smol_hip_host_register): known end to end without
+ * asking the runtime. */
+std::mutex g_pinned_mtx;
+std::map<uintptr_t, size_t> g_pinned;           /* base -> bytes */
+
+void
+pinned_note (const void *p, size_t n)
+{
+    std::lock_guard<std::mutex> g (g_pinned_mtx);
+    g_pinned [(uintptr_t) p] = n;
+}
+
+void
+pinned_forget (const void *p)
+{
+    std::lock_guard<std::mutex> g (g_pinned_mtx);
+    g_pinned.erase ((uintptr_t) p);
+}
+
+/* end of the noted range that holds address q, 0 if none does */
+uintptr_t
+pinned_range_end (uintptr_t q)
+{
+    std::lock_guard<std::mutex> g (g_pinned_mtx);
+    auto it = g_pinned.upper_bound (q);
+    if (it == g_pinned.begin ())
+        return 0;
+    --it;
+    return q < it->first + it->second ? it->first + it->second : 0;
+}
+
 
 int
 grow (void *&buf, size_t &cap, size_t need)
@@ -883,6 +917,273 @@ strip_item (void *ctx, uint32_t i)
         strip_finish (st);
 }
 
+
+/* ---- read-ahead for row-at-a-time callers ------------------------------------------------------------------
+ *
+ * The reference's own outer loop asks for ONE output row per step and keeps the two source rows it filtered last
+ * (smolscale.c:507-546, smolscale-generic.c:1648-1682): a caller looping over smol_scale_batch (ctx, dest, y, 1)
+ * pays for a row. Here a call is a trip to the device -- rows in, one launch, one wait, rows out: 15-19 us however
+ * little it moves, 30-44 x the whole-image call for a 1080p context asked row by row. So the
+ * second small call that continues where the first one ended computes a BAND of the rows that follow (about
+ * RA_BAND_BYTES of traffic) into a page-locked buffer the plan keeps, and later calls inside the band are a memcpy.
+ *
+ * The caller may rewrite pixels_in between calls -- nothing in smolscale.h forbids it, and a row computed ahead
+ * would then be stale. The band keeps the source rows it was computed FROM (they have to pass through page-locked
+ * memory anyway: the staging copy is kept instead of thrown away), and a call is served from the band only if the
+ * source rows ITS output rows read (smol_hip_input_row_range) still hold the same bytes: a memcmp of two or three
+ * rows for a bilinear axis. Equal bytes, equal plan: the cached rows are what a fresh computation would produce.
+ * SMOL_HIP_RESIDENT_SRC=1 (or smol_hip_plan_resident_source ()) is the caller's promise that the source does not
+ * change while the context lives: no comparison, bands for calls of any size, larger bands.
+ * SMOL_HIP_READAHEAD=0 turns the whole thing off. */
+} /* namespace (anonymous) */
+} /* namespace smolrt */
+
+struct SmolRowCache
+{
+    uint8_t *host = nullptr;            /* hipHostMalloc: [staged source rows][band of output rows] */
+    size_t host_bytes = 0;
+    bool valid = false;
+    const uint8_t *src = nullptr;       /* the caller's image the band was computed from */
+    uint32_t rowstride_in = 0;
+    uint32_t r0 = 0, r1 = 0;            /* staged source rows */
+    size_t src_pitch = 0, out_pitch = 0, out_ofs = 0;
+    uint32_t first = 0, n = 0;          /* output rows in the band */
+    /* the pattern: where the last call on this plan ended */
+    const uint8_t *last_src = nullptr;
+    uint32_t last_end = 0;
+    int resident = -1;                  /* -1: the environment decides */
+};
+
+namespace smolrt {
+namespace {
+
+struct RaKnobs
+{
+    bool on = true, resident = false;
+    size_t band_bytes = 2u << 20, band_bytes_resident = 8u << 20, small_bytes = 256u << 10;
+    RaKnobs ()
+    {
+        const char *e;
+        if ((e = getenv ("SMOL_HIP_READAHEAD")) && *e == '0')
+            on = false;
+        if ((e = getenv ("SMOL_HIP_RESIDENT_SRC")) && *e == '1')
+            resident = true;
+        if ((e = getenv ("SMOL_HIP_READAHEAD_KB")) && *e)
+        {
+            const long v = strtol (e, nullptr, 10);
+            if (v >= 64 && v <= (64 << 10))
+                band_bytes = band_bytes_resident = (size_t) v << 10;
+        }
+    }
+};
+
+const RaKnobs &ra_knobs () { static const RaKnobs k; return k; }
+
+/* spare page-locked buffers of destroyed plans: a caller that makes a context per frame would otherwise pay a
+ * hipHostMalloc + hipHostFree of megabytes per frame */
+std::mutex g_ra_pool_mtx;
+struct RaSpare { uint8_t *p; size_t bytes; };
+std::vector<RaSpare> g_ra_pool;
+constexpr size_t RA_POOL_MAX = 4;
+
+int
+ra_buffer_get (size_t need, uint8_t **p_out, size_t *bytes_out)
+{
+    {
+        std::lock_guard<std::mutex> g (g_ra_pool_mtx);
+        for (size_t i = 0; i < g_ra_pool.size (); i++)
+            if (g_ra_pool [i].bytes >= need)
+            {
+                *p_out = g_ra_pool [i].p;
+                *bytes_out = g_ra_pool [i].bytes;
+                g_ra_pool.erase (g_ra_pool.begin () + (long) i);
+                return 0;
+            }
+    }
+    size_t sz = 1u << 20;
+    while (sz < need)
+        sz *= 2;
+    void *p = nullptr;
+    HIP_TRY (hipHostMalloc (&p, sz, hipHostMallocPortable));
+    pinned_note (p, sz);
+    *p_out = static_cast<uint8_t *> (p);
+    *bytes_out = sz;
+    return 0;
+}
+
+void
+ra_buffer_put (uint8_t *p, size_t bytes)
+{
+    if (!p)
+        return;
+    {
+        std::lock_guard<std::mutex> g (g_ra_pool_mtx);
+        if (g_ra_pool.size () < RA_POOL_MAX)
+        {
+            g_ra_pool.push_back (RaSpare { p, bytes });
+            return;
+        }
+    }
+    pinned_forget (p);
+    (void) hipHostFree (p);
+}
+
+bool
+rows_equal (const uint8_t *a, size_t a_pitch, const uint8_t *b, size_t b_pitch, size_t row_bytes, uint32_t n)
+{
+    if (a_pitch == row_bytes && b_pitch == row_bytes)
+        return memcmp (a, b, row_bytes * n) == 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (memcmp (a + i * a_pitch, b + i * b_pitch, row_bytes))
+            return false;
+    return true;
+}
+
+int run_strips (Strip *strips, uint32_t n, bool pinned);
+
+/* 1: the rows were delivered from (or through) the read-ahead band; 0: not this road, take the ordinary one;
+ * < 0: error */
+int
+read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_t *dest, uint32_t rowstride_out,
+            uint32_t first, uint32_t n)
+{
+    const RaKnobs &kn = ra_knobs ();
+    const SmolHipJob &job = plan->job;
+    if (!kn.on || n >= job.height_out)
+        return 0;
+
+    const TypeInfo &ti = k_types [job.pixel_type_in];
+    const TypeInfo &to = k_types [job.pixel_type_out];
+    const size_t in_row = (size_t) job.width_in * ti.bpp, out_row = (size_t) job.width_out * to.bpp;
+    uint32_t a = 0, b = 0;
+    if (smol_hip_input_row_range (&job, first, n, &a, &b))
+        return 0;
+
+    std::lock_guard<std::mutex> guard (plan->rc_mtx);
+    SmolRowCache *c = plan->rc;
+    const bool resident = c && c->resident >= 0 ? c->resident != 0 : kn.resident;
+    const size_t moved = ((size_t) b - a + 1) * in_row + (size_t) n * out_row;
+    if (!resident && moved > kn.small_bytes)
+    {
+        if (c)
+            c->last_src = nullptr;      /* (the pattern is broken) */
+        return 0;                       /* a call of this size is worth its own trip; comparing its rows is not */
+    }
+    if (!c)
+    {
+        c = plan->rc = new (std::nothrow) SmolRowCache;
+        if (!c)
+            return 0;
+    }
+
+    auto deliver = [&] () -> bool
+    {
+        if (!c->valid || c->src != src || c->rowstride_in != rowstride_in || first < c->first || first + n > c->first + c->n)
+            return false;
+        if (!resident
+            && !rows_equal (src + (size_t) a * rowstride_in, rowstride_in, c->host + (size_t) (a - c->r0) * c->src_pitch, c->src_pitch,
+                            in_row, b - a + 1))
+        {
+            c->valid = false;           /* the caller rewrote its source: what was computed ahead is stale */
+            return false;
+        }
+        const uint8_t *from = c->host + c->out_ofs + (size_t) (first - c->first) * c->out_pitch;
+        if (rowstride_out == out_row && c->out_pitch == out_row)
+            memcpy (dest, from, out_row * n);
+        else
+            for (uint32_t i = 0; i < n; i++)
+                memcpy (dest + (size_t) i * rowstride_out, from + (size_t) i * c->out_pitch, out_row);
+        return true;
+    };
+
+    const bool continues = c->last_src == src && c->last_end == first;
+    c->last_src = src;
+    c->last_end = first + n;
+    if (deliver ())
+        return 1;
+    if (!continues)
+        return 0;                       /* a first call, or one out of order: the ordinary road */
+
+    /* a band of the rows from `first' on */
+    const size_t per_out_row = moved / n + 1;
+    const size_t want = resident ? kn.band_bytes_resident : kn.band_bytes;
+    uint64_t rows = want / per_out_row;
+    if (rows < 2ull * n)
+        return 0;                       /* rows so fat that a band is hardly more than the call itself */
+    if (rows > job.height_out - first)
+        rows = job.height_out - first;
+    if (rows <= n)
+        return 0;
+    uint32_t r0 = 0, r1 = 0;
+    if (smol_hip_input_row_range (&job, first, (uint32_t) rows, &r0, &r1))
+        return 0;
+    const size_t src_pitch = align_up (in_row, 16), out_pitch = out_row;
+    const size_t src_bytes = ((size_t) r1 - r0 + 1) * src_pitch + 256, out_bytes = (size_t) rows * out_pitch + 256;
+    if (c->host_bytes < src_bytes + out_bytes)
+    {
+        if (hipSetDevice (plan->device) != hipSuccess)
+            return 0;
+        ra_buffer_put (c->host, c->host_bytes);
+        c->host = nullptr; c->host_bytes = 0; c->valid = false;
+        if (ra_buffer_get (src_bytes + out_bytes, &c->host, &c->host_bytes))
+        {
+            (void) hipGetLastError ();
+            return 0;
+        }
+    }
+    c->valid = false;
+    copy_rows (RowCopy { c->host, src_pitch, src + (size_t) r0 * rowstride_in, rowstride_in, in_row, r1 - r0 + 1, true });
+
+    Strip st;
+    st.plan = plan;
+    st.src = c->host - (size_t) r0 * src_pitch;     /* (row 0 of the virtual image; only rows r0 .. r1 are ever read) */
+    st.rowstride_in = (uint32_t) src_pitch;
+    st.dest = c->host + src_bytes;
+    st.rowstride_out = (uint32_t) out_pitch;
+    st.first = first;
+    st.n = (uint32_t) rows;
+    const int rc = run_strips (&st, 1, true);
+    if (rc)
+        return rc;
+    c->src = src; c->rowstride_in = rowstride_in;
+    c->r0 = r0; c->r1 = r1;
+    c->src_pitch = src_pitch; c->out_pitch = out_pitch; c->out_ofs = src_bytes;
+    c->first = first; c->n = (uint32_t) rows;
+    c->valid = true;
+    /* (delivered without another comparison: the staged rows were copied from the caller's a moment ago, inside this call) */
+    const uint8_t *from = c->host + c->out_ofs;
+    for (uint32_t i = 0; i < n; i++)
+        memcpy (dest + (size_t) i * rowstride_out, from + (size_t) i * out_pitch, out_row);
+    return 1;
+}
+
+} /* namespace */
+
+void
+row_cache_release (SmolHipPlan *plan)
+{
+    std::lock_guard<std::mutex> guard (plan->rc_mtx);
+    if (!plan->rc)
+        return;
+    ra_buffer_put (plan->rc->host, plan->rc->host_bytes);
+    delete plan->rc;
+    plan->rc = nullptr;
+}
+
+void
+row_cache_shutdown ()
+{
+    std::lock_guard<std::mutex> g (g_ra_pool_mtx);
+    for (RaSpare &sp : g_ra_pool)
+    {
+        pinned_forget (sp.p);
+        (void) hipHostFree (sp.p);
+    }
+    g_ra_pool.clear ();
+}
+
+namespace {
+
 int
 run_strips (Strip *strips, uint32_t n, bool pinned)
 {
@@ -998,39 +1299,6 @@ transfer (int device, void *dev, void *host, size_t n_bytes, bool to_device)
 
 } /* namespace */
 
-/* Ranges this library page-locked itself (smol_hip_host_alloc / smol_hip_host_register): known end to end without
- * asking the runtime. */
-namespace {
-std::mutex g_pinned_mtx;
-std::map<uintptr_t, size_t> g_pinned;           /* base -> bytes */
-
-void
-pinned_note (const void *p, size_t n)
-{
-    std::lock_guard<std::mutex> g (g_pinned_mtx);
-    g_pinned [(uintptr_t) p] = n;
-}
-
-void
-pinned_forget (const void *p)
-{
-    std::lock_guard<std::mutex> g (g_pinned_mtx);
-    g_pinned.erase ((uintptr_t) p);
-}
-
-/* end of the noted range that holds address q, 0 if none does */
-uintptr_t
-pinned_range_end (uintptr_t q)
-{
-    std::lock_guard<std::mutex> g (g_pinned_mtx);
-    auto it = g_pinned.upper_bound (q);
-    if (it == g_pinned.begin ())
-        return 0;
-    --it;
-    return q < it->first + it->second ? it->first + it->second : 0;
-}
-} /* namespace */
-
 /* Is EVERY byte of [p, p + n_bytes) page-locked? The range is walked allocation by allocation: the library's own
  * registrations from its table, foreign ones (hipHostMalloc / hipHostRegister by the caller) through the runtime --
  * hipPointerGetAttributes says what the address is, hipMemGetAddressRange where its allocation ends. Rounds 3-4 asked
@@ -1139,6 +1407,15 @@ smol_hip_scale_rows_host_multi (SmolHipPlan *const *plans, uint32_t n_plans,
         return 0;
     if (!rows_ok (first_row, n_rows, plans [0]->job.height_out))
         return SMOL_HIP_E_INVALID;
+
+    if (n_plans == 1)
+    {
+        /* a caller that asks for its rows a few at a time: served from (or starting) a band computed ahead */
+        const int ra = read_ahead (plans [0], static_cast<const uint8_t *> (pixels_in_host), rowstride_in,
+                                   static_cast<uint8_t *> (dest_host), rowstride_out, first_row, n_rows);
+        if (ra)
+            return ra < 0 ? ra : 0;
+    }
 
     Strip strips [MAX_DEVICES];
     const uint32_t per = (n_rows + n_plans - 1) / n_plans;
@@ -1251,6 +1528,21 @@ smol_hip_host_free (void *host_ptr)
 }
 
 int
+smol_hip_plan_resident_source (SmolHipPlan *plan, int resident)
+{
+    if (!plan)
+        return SMOL_HIP_E_INVALID;
+    std::lock_guard<std::mutex> guard (plan->rc_mtx);
+    if (!plan->rc)
+        plan->rc = new (std::nothrow) SmolRowCache;
+    if (!plan->rc)
+        return SMOL_HIP_E_INVALID;
+    plan->rc->resident = resident ? 1 : 0;
+    plan->rc->valid = false;
+    return 0;
+}
+
+int
 smol_hip_host_range_is_pinned (const void *host_ptr, uint64_t n_bytes)
 {
     return host_ptr && host_range_is_pinned (host_ptr, (size_t) n_bytes) ? 1 : 0;
@@ -1260,6 +1552,7 @@ void
 smol_hip_shutdown (void)
 {
     pools_shutdown ();
+    row_cache_shutdown ();
     const int n = smol_hip_device_count ();
     for (int d = 0; d < n && d < MAX_DEVICES; d++)
         device_release_lanes (d);

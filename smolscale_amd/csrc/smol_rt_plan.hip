@@ -193,6 +193,7 @@ smol_hip_plan_destroy (SmolHipPlan *plan)
     if (!plan)
         return;
     const int device = plan->device;
+    row_cache_release (plan);
     if (hipSetDevice (device) == hipSuccess)
         for (BoxSlot &sl : plan->box)
         {
