@@ -10,6 +10,13 @@
 
 #include "smol_hip.h"
 
+/* the few helpers below that device code shares with the host */
+#if defined (__HIPCC__) && !defined (SMOL_KERNEL_EMU)
+#define SMOL_HD __host__ __device__
+#else
+#define SMOL_HD
+#endif
+
 namespace smolhip {
 
 /* Tuning / ablation knobs (SMOL_TILE_ROWS, SMOL_NO_UP, SMOL_TILE_DBG ...) exist only in
@@ -941,28 +948,59 @@ box2_is (const JobDev &d)
     return d.box2 != 0;
 }
 
+/* box2 == 3 (twopass_setup): a bilinear (COPY, ONE) horizontal axis under a TALL vertical box. The intermediate image of
+ * the two-pass road would be larger than the source (300 x 20000 -> 200 x 40: 32 MB written and read back for 24 MB of
+ * source; 64 x 60000 -> 100 x 4 three times the source) and its second pass a handful of waves walking thousands of rows.
+ * Instead pass 1 (k_linh's staging + horizontal filter) keeps the vertical box sums in registers -- the order of the
+ * reference's passes stands, every row is filtered horizontally and rounded before it is summed (smolscale-generic.c:
+ * 2163-2260) -- with each output row's span of source rows cut into box_nmax SPLITS, one tile (wave) per (column tile,
+ * output row, split): 32-bit sums are associative. What reaches memory is one 16-byte partial sum per output pixel and
+ * split; pass 2 (k_boxv) adds the splits, normalises and packs. */
+SMOL_HD inline bool twopass_hbox (const JobDev &d) { return d.box2 == 3; }
+SMOL_HD inline uint32_t hbox_splits (const JobDev &d) { return d.box_nmax; }
+
 /* bytes per pixel of the intermediate image */
 inline uint32_t
 box2_tmp_px (const JobDev &d)
 {
+    if (twopass_hbox (d))
+        return 16u;
     return (d.box2 == 2 && d.p16 && d.linear && d.filter_h != F_BOX && d.filter_v != F_BOX) ? 16u : 8u;
 }
 
 inline size_t
 box2_tmp_bytes (const JobDev &d)
 {
+    if (twopass_hbox (d))
+        return (size_t) d.n_rows * hbox_splits (d) * d.w_out * 16u;
     return (size_t) (d.tmp_row1 - d.tmp_row0 + 1) * d.w_out * box2_tmp_px (d);
 }
 
+/* where this strip's part of the intermediate image starts in a buffer that holds the whole image's (the plan's ring
+ * slots: strips of one image share a slot and must not overlap) */
+inline size_t
+box2_tmp_offset (const JobDev &d)
+{
+    if (twopass_hbox (d))
+        return (size_t) d.first_row * hbox_splits (d) * d.w_out * 16u;
+    return (size_t) d.tmp_row0 * d.w_out * box2_tmp_px (d);
+}
+
 /* tiles (= waves) of each pass; a workgroup runs 4 of them */
-inline bool twopass_lin_h (const JobDev &d) { return d.box2 == 2 && d.filter_h != F_BOX; }
+inline bool twopass_lin_h (const JobDev &d) { return (d.box2 == 2 || d.box2 == 3) && d.filter_h != F_BOX; }
 inline bool twopass_lin_v (const JobDev &d) { return d.box2 == 2 && d.filter_v != F_BOX; }
+/* k_linh: row tiles of a job (rows of the intermediate image in groups of tile_rows; fused box: output rows x splits) */
+inline uint32_t
+linh_row_tiles (const JobDev &d)
+{
+    return twopass_hbox (d) ? d.n_rows * hbox_splits (d) : (d.tmp_row1 - d.tmp_row0 + d.tile_rows) / d.tile_rows;
+}
 
 inline uint32_t
 box2_h_tiles (const JobDev &d)
 {
     if (twopass_lin_h (d))
-        return ((d.w_out + d.group_rows - 1u) / d.group_rows) * ((d.tmp_row1 - d.tmp_row0 + d.tile_rows) / d.tile_rows);
+        return ((d.w_out + d.group_rows - 1u) / d.group_rows) * linh_row_tiles (d);
     const uint32_t cols = 64u / d.tile_lpc;
     return ((d.w_out + cols - 1u) / cols) * ((d.tmp_row1 - d.tmp_row0 + boxh_rows (d)) / boxh_rows (d));
 }
@@ -974,7 +1012,7 @@ inline uint32_t
 box2_h_grid (const JobDev &d)
 {
     if (twopass_lin_h (d))      /* k_linh: x = column tiles, y = groups of 4 row tiles (one per wave) */
-        return ((d.w_out + d.group_rows - 1u) / d.group_rows) | ((((d.tmp_row1 - d.tmp_row0 + d.tile_rows) / d.tile_rows + 3u) / 4u) << 16);
+        return ((d.w_out + d.group_rows - 1u) / d.group_rows) | (((linh_row_tiles (d) + 3u) / 4u) << 16);
     const uint32_t cols = 64u / d.tile_lpc;
     uint32_t gx = (d.w_out + cols - 1u) / cols;
     uint32_t gy = (d.tmp_row1 - d.tmp_row0 + boxh_rows (d)) / boxh_rows (d);
@@ -1106,6 +1144,27 @@ twopass_setup (JobDev &d)
     t.tile_cpl = 2;
     twopass_v_rows (t, t.tmp_row0, t.tmp_row1);
     t.box2 = 2;
+    /* a tall vertical box behind a bilinear horizontal axis: the vertical sums stay in pass 1's registers (box2 == 3,
+     * above). From a ratio of 64: below that the intermediate image is a fraction of the source and k_boxv has its waves.
+     * At most 64 splits and the grid's y limit (65535 workgroups of 4 row tiles). */
+    if (t.filter_h != F_BOX && t.filter_v == F_BOX && (t.step_y >> 16) >= 64u && !tune_env ("SMOL_NO_HBOX")
+        && (uint64_t) t.n_rows < 4u * 65535u)
+    {
+        /* enough splits for ~2048 tiles per image (the chip holds ~7000 waves), each at least 32 source rows long */
+        const uint32_t tiles = ((t.w_out + t.group_rows - 1u) / t.group_rows) * t.n_rows;
+        const uint32_t span = (uint32_t) (t.step_y >> 16);
+        uint32_t sp = (2048u + tiles - 1u) / tiles;
+        if (sp > span / 32u) sp = span / 32u;
+        if (const char *e = tune_env ("SMOL_HBOX_SPLITS"))
+            sp = (uint32_t) atoi (e);
+        if (sp > 64u) sp = 64u;                 /* (64 x 60000 -> 100 x 4: 64 splits 161 us, 128 157, 256 183) */
+        while (sp > 1u && (uint64_t) t.n_rows * sp > 4u * 65535u)
+            sp--;
+        if (sp < 1u) sp = 1u;
+        t.box_nmax = sp;
+        t.box2_vlpc = 1;
+        t.box2 = 3;
+    }
     d = t;
     return true;
 }
@@ -1216,7 +1275,8 @@ kclass_name (KClass k, const JobDev &d)
         case KC_POW2X: return "k_pow2x_batch";
         case KC_UP: return d.up_wide >= 2 ? "k_upg_batch" : "k_up_batch";
         case KC_DOWN: return "k_lind_batch";
-        case KC_BOX2: return d.box2 != 2 ? "k_boxh_batch + k_boxv_batch"
+        case KC_BOX2: return d.box2 == 3 ? "k_linh_batch (vertical box sums in registers) + k_boxv_batch"
+                             : d.box2 != 2 ? "k_boxh_batch + k_boxv_batch"
                              : twopass_lin_h (d) ? (twopass_lin_v (d) ? "k_linh_batch + k_linv_batch" : "k_linh_batch + k_boxv_batch")
                                                  : "k_boxh_batch + k_linv_batch";
         case KC_HSPAN: return "k_hspan_batch";

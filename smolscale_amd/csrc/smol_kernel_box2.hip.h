@@ -420,6 +420,18 @@ __device__ __forceinline__ void boxv_body (const JobDev &J, const uint8_t *lut_l
     if (WIDE)
     {
         uint32_t acc [4] = { 0, 0, 0, 0 };
+        if (LPC == 1 && dispatch::twopass_hbox (J))
+        {
+            /* pass 1 kept the box sums in its registers (JobDev::box2 == 3): what is left is adding the splits' partial sums */
+            const uint32_t S = dispatch::hbox_splits (J);
+            const gbyte *pp = gptr (J.tmp) + ((size_t) row * S * J.w_out + xc) * 16u;
+            for (uint32_t sp = 0; sp < S; sp++, pp += (size_t) J.w_out * 16u)
+            {
+                const u32x4 t = *reinterpret_cast<const SMOL_AS_GLOBAL u32x4 *> (pp);
+                acc [0] += t.x; acc [1] += t.y; acc [2] += t.z; acc [3] += t.w;
+            }
+        }
+        else
         /* rows eight at a time: the loads of a group are in flight together */
         for (uint32_t r = y0 + sub; r <= y_end; r += 8 * LPC, ip += 8 * LPC * ipitch)
         {

@@ -72,7 +72,30 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     const uint32_t ty = tile / tiles_x;
     const uint32_t yrel0 = ty * J.tile_rows;                        /* LIND_H: counted in rows of the intermediate image */
 
-    if (PASS == LIND_H ? J.tmp_row0 + yrel0 > J.tmp_row1 : yrel0 >= J.n_rows)
+    /* LIND_H under a tall vertical box (JobDev::box2 == 3, smol_jobdev.h): the tile is (column tile, output row, split);
+     * it walks its share of the output row's span of source rows and keeps the box sums in registers */
+    const bool hbox = PASS == LIND_H && dispatch::twopass_hbox (J);
+    uint32_t hb_row = 0, hb_first = 0, hb_last = 0, hb_y0 = 0, hb_y1 = 0, hb_w1 = 0, hb_lastw = 0;
+    bool hb_empty = false;
+    if (hbox)
+    {
+        const uint32_t S = dispatch::hbox_splits (J);
+        const uint32_t yo = ty / S, sp = ty - yo * S;
+        if (yo >= J.n_rows)
+            return;
+        /* the vertical box of boxv_body<true> (smolscale-generic.c:2163-2260): first row weighted w1, last row w2 - 1
+         * (skipped when w2 == 0), interior rows in full */
+        uint32_t w2;
+        box_span (J.step_y, J.h_in, J.first_row + yo, hb_y0, hb_y1, w2, hb_w1);
+        hb_lastw = w2 ? w2 - 1u : 0u;
+        const uint32_t y_end = w2 == 0u ? hb_y1 - 1u : hb_y1;
+        const uint32_t chunk = (y_end - hb_y0 + S) / S;
+        hb_first = hb_y0 + sp * chunk;
+        hb_last = hb_first + chunk - 1u < y_end ? hb_first + chunk - 1u : y_end;
+        hb_empty = hb_first > y_end;
+        hb_row = ty;                                                /* row of the partial-sum image */
+    }
+    else if (PASS == LIND_H ? J.tmp_row0 + yrel0 > J.tmp_row1 : yrel0 >= J.n_rows)
         return;
 
     const uint32_t yrel1 = (yrel0 + J.tile_rows < J.n_rows) ? yrel0 + J.tile_rows : J.n_rows;
@@ -153,8 +176,9 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     /* a sample is due when its BOTTOM row has passed: row o + 1 of a bilinear pair, row o itself on a COPY axis */
     const uint32_t vdue = (PASS != LIND_H && (J.filter_v == F_COPY || J.filter_v == F_ONE)) ? 0u : 1u;
     uint32_t oy = e & 0xffffu, Fy = e >> 16;
-    const uint32_t row_first = PASS == LIND_H ? J.tmp_row0 + yrel0 : oy;
-    const uint32_t row_last = PASS == LIND_H ? (row_first + J.tile_rows - 1u < J.tmp_row1 ? row_first + J.tile_rows - 1u : J.tmp_row1)
+    const uint32_t row_first = hbox ? hb_first : PASS == LIND_H ? J.tmp_row0 + yrel0 : oy;
+    const uint32_t row_last = hbox ? hb_last
+                            : PASS == LIND_H ? (row_first + J.tile_rows - 1u < J.tmp_row1 ? row_first + J.tile_rows - 1u : J.tmp_row1)
                                              : (e_last & 0xffffu) + vdue;
 
     /* ---- staging -------------------------------------------------------------------- */
@@ -186,7 +210,27 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         for (int i = 0; i < NCH; i++)
             tmp_in [c][i] = 0;
     /* LIND_H: row being written; LIND_V: row being loaded (the fused kernel has no intermediate image) */
-    const gbyte *trow = PASS == LIND_FUSED ? nullptr : gptr (J.tmp) + (size_t) (row_first - J.tmp_row0) * J.w_out * TPX;
+    const gbyte *trow = (PASS == LIND_FUSED || hbox) ? nullptr : gptr (J.tmp) + (size_t) (row_first - J.tmp_row0) * J.w_out * TPX;
+    /* hbox: the vertical box sums of this tile's rows, four 32-bit channels per column */
+    uint32_t hacc [CPL][4];
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            hacc [c][i] = 0;
+    auto hbox_flush = [&] ()
+    {
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+            if (ok [c])
+                *reinterpret_cast<SMOL_AS_GLOBAL u32x4 *> (gptr (J.tmp) + ((size_t) hb_row * J.w_out + xc [c]) * 16u)
+                    = u32x4 { hacc [c][0], hacc [c][1], hacc [c][2], hacc [c][3] };
+    };
+    if (hbox && hb_empty)
+    {
+        hbox_flush ();                                  /* (more splits than rows: this one adds nothing) */
+        return;
+    }
 
     auto load_row = [&] ()
     {
@@ -365,6 +409,40 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                 h [c][i] = !HX ? hs [i] : W32 ? hs [i] >> HX : (hs [i] >> HX) & (0xffffu >> HX) * 0x00010001u;
         }
 
+        if (hbox)
+        {
+            /* this source row into the vertical box sums (wave-uniform weight) */
+            const uint32_t wr = (r == hb_y0) ? hb_w1 : ((r == hb_y1) ? hb_lastw : 0x10000u);
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+            {
+                uint32_t ch [4];
+                if (W32)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        ch [i] = h [c][i < NCH ? i : 0];
+                }
+                else
+                {
+                    ch [0] = h [c][0] & 0xffffu; ch [1] = h [c][0] >> 16;
+                    ch [2] = h [c][NCH - 1] & 0xffffu; ch [3] = h [c][NCH - 1] >> 16;
+                }
+                if (wr == 0x10000u)
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        hacc [c][i] += ch [i];
+                }
+                else
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        hacc [c][i] += ((ch [i] * wr) >> 8) & 0x00ffffffu;
+                }
+            }
+            continue;
+        }
         if (PASS == LIND_H)
         {
             /* the horizontal result of this source row: row r of the intermediate image */
@@ -482,6 +560,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                     hp [c][i] = h [c][i];
             }
     }
+    if (hbox)
+        hbox_flush ();
 }
 
 /* ------------------------------------------------------------------------------------------------------------ *

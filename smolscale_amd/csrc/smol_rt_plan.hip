@@ -283,7 +283,7 @@ smol_hip_scale_rows_device (SmolHipPlan *plan,
         return rc;
     /* the kernels index the intermediate image from the job's first source row:
      * shift the base so that row r of the image always lands at r * w_out * 8 */
-    const size_t scratch_ofs = (size_t) probe.tmp_row0 * probe.w_out * box2_tmp_px (probe);
+    const size_t scratch_ofs = box2_tmp_offset (probe);
     void *scratch = static_cast<uint8_t *> (sl->buf) + scratch_ofs;
     HIP_TRY (launch_single (jd, stream, scratch, plan_box_bytes (plan) - scratch_ofs));
     if (use)

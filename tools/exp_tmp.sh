@@ -1,9 +1,7 @@
-show() { python -c "
+f() { python tools/bench_configs.py --configs $1 --iters 20 ${@:2} 2>/dev/null | python -c "
 import sys,json
-for l in sys.stdin:
-    d=json.loads(l); print('  ', d['rows_per_call'], ' '.join('%s: %.2fx (%.1f us)' % (k, d[k]['x_whole'], d[k]['us_per_call']) for k in ('1','8','64','all')))"; }
-echo default; python tools/bench_rows_per_call.py 2>/dev/null | show
-echo SMOL_HIP_RESIDENT_SRC=1; SMOL_HIP_RESIDENT_SRC=1 python tools/bench_rows_per_call.py 2>/dev/null | show
-echo SMOL_HIP_ZEROCOPY_KB=1024; SMOL_HIP_ZEROCOPY_KB=1024 python tools/bench_rows_per_call.py 2>/dev/null | show
-echo SMOL_HIP_ZEROCOPY_KB=4096; SMOL_HIP_ZEROCOPY_KB=4096 python tools/bench_rows_per_call.py 2>/dev/null | show
-echo SMOL_HIP_READAHEAD=0; SMOL_HIP_READAHEAD=0 python tools/bench_rows_per_call.py 2>/dev/null | show
+for d in map(json.loads, sys.stdin): print('  ', d['config'], d['kernel'][:30], '%.1f us  %.3f' % (d['step_us'], d['frac_of_8TBps']))"; }
+echo default; f FLATTALL,FLATBILBOX
+export SMOLSCALE_AMD_LIB=$PWD/smolscale_amd/libsmolscale_amd_tuning.so
+for s in 64 128 256; do echo "SMOL_HBOX_SPLITS=$s"; SMOL_HBOX_SPLITS=$s f FLATTALL,FLATBILBOX; done
+echo "SMOL_NO_HBOX=1"; SMOL_NO_HBOX=1 f FLATTALL,FLATBILBOX
