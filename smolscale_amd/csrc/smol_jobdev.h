@@ -1100,8 +1100,11 @@ twopass_setup (JobDev &d)
         return false;
     if (d.p16 && d.bpp_in != 4)
         return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */
-    /* premul16 + sRGB leaves 19-bit channels behind a bilinear horizontal pass: more than k_boxv's 16-bit pixels hold */
-    if (d.p16 && d.linear && d.filter_h != F_BOX && d.filter_v == F_BOX)
+    /* premul16 + sRGB leaves 19-bit channels behind a bilinear horizontal pass: more than the intermediate image's 16-bit
+     * pixels hold in front of k_boxv. With the vertical box sums kept in pass 1's registers (box2 == 3, below) nothing is
+     * narrowed: that road takes these jobs at every box ratio (round 5; k_general<true> before, 3.4 % of random jobs) */
+    const bool p16l_bilbox = d.p16 && d.linear && d.filter_h != F_BOX && d.filter_v == F_BOX;
+    if (p16l_bilbox && (tune_env ("SMOL_NO_HBOX") || (uint64_t) d.n_rows >= 4u * 65535u))
         return false;
     if (d.filter_h == F_BOX && d.filter_v == F_BOX)
         return false;                           /* box2_setup's */
@@ -1144,17 +1147,22 @@ twopass_setup (JobDev &d)
     t.tile_cpl = 2;
     twopass_v_rows (t, t.tmp_row0, t.tmp_row1);
     t.box2 = 2;
-    /* a tall vertical box behind a bilinear horizontal axis: the vertical sums stay in pass 1's registers (box2 == 3,
-     * above). From a ratio of 64: below that the intermediate image is a fraction of the source and k_boxv has its waves.
+    /* a vertical box behind a bilinear (COPY, ONE) horizontal axis: the vertical sums stay in pass 1's registers (box2 == 3,
+     * above).
      * At most 64 splits and the grid's y limit (65535 workgroups of 4 row tiles). */
-    if (t.filter_h != F_BOX && t.filter_v == F_BOX && (t.step_y >> 16) >= 64u && !tune_env ("SMOL_NO_HBOX")
+    /* (at every box ratio: 4096^2 -> 2731 x 300, V ratio 13.7: gamma-correct 95 -> 63 us, premul16 98 -> 47, premul16 + gamma
+     * 83 (k_general) -> 57; SMOL_HBOX_MIN in tuning builds: the old two-pass road below that ratio) */
+    uint32_t hbox_min = 0;
+    if (const char *e = tune_env ("SMOL_HBOX_MIN"))
+        hbox_min = (uint32_t) atoi (e);
+    if (t.filter_h != F_BOX && t.filter_v == F_BOX && ((t.step_y >> 16) >= hbox_min || p16l_bilbox) && !tune_env ("SMOL_NO_HBOX")
         && (uint64_t) t.n_rows < 4u * 65535u)
     {
         /* enough splits for ~2048 tiles per image (the chip holds ~7000 waves), each at least 32 source rows long */
         const uint32_t tiles = ((t.w_out + t.group_rows - 1u) / t.group_rows) * t.n_rows;
         const uint32_t span = (uint32_t) (t.step_y >> 16);
         uint32_t sp = (2048u + tiles - 1u) / tiles;
-        if (sp > span / 32u) sp = span / 32u;
+        if (sp > span / 32u) sp = span / 32u;       /* (short spans: one tile per output row) */
         if (const char *e = tune_env ("SMOL_HBOX_SPLITS"))
             sp = (uint32_t) atoi (e);
         if (sp > 64u) sp = 64u;                 /* (64 x 60000 -> 100 x 4: 64 splits 161 us, 128 157, 256 183) */

@@ -20,6 +20,8 @@ lin_pass_kind (const JobDev &J)
 {
     if (!J.p16)
         return J.bpp_in == 3 ? 1 : 0;
+    if (smolhip::dispatch::twopass_hbox (J))
+        return J.linear ? 2 : 3;
     return (!J.linear || J.filter_h == smolhip::F_BOX || J.filter_v == smolhip::F_BOX) ? 3 : 2;
 }
 

@@ -1047,6 +1047,8 @@ __device__ __forceinline__ int lin_pass_kind (const JobDev &J)
         return J.bpp_in == 3 ? 1 : 0;
     /* premul16 without sRGB: every value fits 16 bits, whatever the passes; with sRGB (19 bits) only next to a box pass
      * (whose results the reference masks to 16 bits: smolscale-generic.c:1231-1261) */
+    if (dispatch::twopass_hbox (J))
+        return J.linear ? 2 : 3;        /* (box sums in pass 1's registers: the 19-bit channels are never narrowed) */
     return (!J.linear || J.filter_h == F_BOX || J.filter_v == F_BOX) ? 3 : 2;
 }
 

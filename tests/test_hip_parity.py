@@ -307,7 +307,8 @@ def test_axes_scaled_independently_in_the_128bpp_class():
         (2, 1, 600, 3, 300, 250, 1, "k_lind"),              # H ONE
         (4, 2100, 130, 4, 300, 517, 0, "k_lind"),           # 2 halvings down, x4 up: tall tiles
         (0, 4096, 300, 0, 300, 200, 1, "k_boxh_batch + k_linv"),
-        (4, 300, 4000, 4, 900, 200, 0, "k_linh_batch + k_boxv"),
+        (4, 300, 4000, 4, 900, 200, 0, "k_linh_batch (vertical box sums in registers) + k_boxv"),
+        (6, 333, 2500, 5, 500, 200, 1, "k_linh_batch (vertical box sums in registers) + k_boxv"),   # premul16 + sRGB: 19-bit channels, never narrowed
         (9, 3000, 100, 1, 200, 333, 1, "k_boxh_batch + k_linv"),
     ]
     for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb, kernel) in enumerate(shapes):

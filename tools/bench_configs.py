@@ -120,6 +120,9 @@ CONFIGS = {
     "P16BOXBIL": (4, 4096, 4096, None, 4, 300, 2000, 2, "4096^2->300x2000 rgbA->rgbA (premul16; H BOX, V bilinear), 2 frames"),
     "P16HDVU": (4, 4096, 2048, None, 4, 2731, 3000, 2, "4096x2048->2731x3000 rgbA->rgbA (premul16; H ratio 1.5 down, V up), 2 frames"),
     "FLATBOXBIL": (0, 65535, 64, None, 0, 128, 40, 8, "65535x64->128x40 RGBA8 premul (H BOX ratio 512: the 128bpp class's compressed storage; V bilinear), 8 frames"),
+    "SRGBBILBOX": (0, 4096, 4096, None, 0, 2731, 300, 2, "4096^2->2731x300 RGBA8 premul with_srgb=1 (H ratio 1.5, V BOX ratio 13.7), 2 frames", 1),
+    "P16BILBOX": (4, 4096, 4096, None, 4, 2731, 300, 2, "4096^2->2731x300 rgbA->rgbA (premul16; H ratio 1.5, V BOX ratio 13.7), 2 frames"),
+    "P16LBILBOX": (4, 4096, 4096, None, 4, 2731, 300, 2, "4096^2->2731x300 rgbA->rgbA with_srgb=1 (premul16 + gamma: 19-bit channels; H ratio 1.5, V BOX ratio 13.7), 2 frames", 1),
     "FLATBILBOX": (0, 300, 20000, None, 0, 200, 40, 8, "300x20000->200x40 RGBA8 premul (H ratio 1.5, V BOX ratio 500: compressed storage), 8 frames"),
     "FLATTALL": (0, 64, 60000, None, 0, 100, 4, 16, "64x60000->100x4 RGBA8 premul (H magnify, V BOX ratio 15000: compressed storage, few output pixels), 16 frames"),
     "BOX12": (0, 4096, 4096, None, 0, 336, 336, 8, "4096^2->336^2 RGBA8 premul (BOX ratio 12.2, 64bpp class: the two-pass threshold), 8 frames"),

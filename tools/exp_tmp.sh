@@ -1,7 +1,8 @@
-f() { python tools/bench_configs.py --configs $1 --iters 20 ${@:2} 2>/dev/null | python -c "
+f() { python tests/bench_configs_checked.py --configs $1 --iters 20 ${@:2} 2>/dev/null | python -c "
 import sys,json
-for d in map(json.loads, sys.stdin): print('  ', d['config'], d['kernel'][:30], '%.1f us  %.3f' % (d['step_us'], d['frac_of_8TBps']))"; }
-echo default; f FLATTALL,FLATBILBOX
+for d in map(json.loads, sys.stdin): print('  ', d['config'], d['kernel'][:44], '%.1f us  %.3f' % (d['step_us'], d['frac_of_8TBps']), d.get('bit_exact_first_rows_vs_oracle'))"; }
+echo default; f SRGBBILBOX,P16BILBOX,P16LBILBOX,FLATBILBOX
 export SMOLSCALE_AMD_LIB=$PWD/smolscale_amd/libsmolscale_amd_tuning.so
-for s in 64 128 256; do echo "SMOL_HBOX_SPLITS=$s"; SMOL_HBOX_SPLITS=$s f FLATTALL,FLATBILBOX; done
-echo "SMOL_NO_HBOX=1"; SMOL_NO_HBOX=1 f FLATTALL,FLATBILBOX
+echo "SMOL_HBOX_MIN=8"; SMOL_HBOX_MIN=8 f SRGBBILBOX,P16BILBOX,P16LBILBOX
+echo "SMOL_HBOX_MIN=8 SMOL_HBOX_SPLITS=2"; SMOL_HBOX_MIN=8 SMOL_HBOX_SPLITS=2 f SRGBBILBOX,P16BILBOX,P16LBILBOX
+echo "SMOL_NO_HBOX=1"; SMOL_NO_HBOX=1 f SRGBBILBOX,P16BILBOX,P16LBILBOX
