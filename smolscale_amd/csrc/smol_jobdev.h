@@ -585,7 +585,10 @@ up_setup (JobDev &d)
     {
         /* (between 1.7 and 2 the two are equal on 16-byte aligned output rows and k_tile is 6-12 % ahead on the odd
          * widths of the sweep: 3840x2160 -> 6758x3801 641 -> 569 us, -> 7411x4168 674 -> 634: profiles/r03d_sweep_points.txt) */
-        const uint64_t lim = (uint64_t) 1 << 31;                    /* step 0.5 = magnification 2 */
+        /* (round 5, kernel against kernel in steps of 0.1 on aligned and odd output widths, profiles/r05_up_handover.txt:
+         * x2.0 k_tile 65 / 68 us against k_up 69 / 82, x2.2 72 / 74 against 76 / 83, x2.3 82 / 93 against 80 / 88: k_up
+         * from x2.25) */
+        const uint64_t lim = ((uint64_t) 4 << 32) / 9;              /* step 0.444 = magnification 2.25 */
         if (d.step_x > lim || d.step_y > lim)
             return false;
         /* k_up's fast form is the 16-byte store of four premultiplied 32-bit pixels; 24-bit, unassociated and byte-aligned
@@ -627,13 +630,22 @@ up_setup (JobDev &d)
      * (nearly) raster order -- flat tiles. Config 3: 8 rows 89-92 us, 7 or 9 rows 92, 6 rows 98, 12-29
      * rows 97-104, 4 rows 124 (per-tile set-up); profiles/r02e_up_tile_rows.txt. The table-driven
      * flavours are bound by arithmetic per tile and keep the tall tiles. */
-    if (flavour == 0 && tr > 8)
-        tr = 8;
+    /* (... below x2.75 twelve: a tile's two halo rows of horizontal work are shared by more output rows -- x2.4 83 -> 77 us,
+     * x2.6 91 -> 88, odd widths 95 -> 87 and 99 -> 97; from x2.8 eight rows are ahead, 95 against 98: profiles/r05_up_handover.txt) */
+    const uint64_t flat_rows = (flavour == 0 && d.step_y > ((uint64_t) 4 << 32) / 11) ? 12 : 8;
+    if (flavour == 0 && tr > flat_rows)
+        tr = flat_rows;
     if (flavour != 0 && tr > 16)
         tr = 16;                /* 1080p -> 4320p: sRGB-linear 224 -> 203 us, premul16 70 -> 67.5 (profiles/r02o_up_tile_rows.txt) */
     if (const char *e = tune_env ("SMOL_UP_ROWS"))
-        if ((uint64_t) atoi (e) >= 1 && (uint64_t) atoi (e) < tr)
-            tr = (uint64_t) atoi (e);
+    {
+        /* (up to what the tile's source rows allow) */
+        const uint64_t lim = (((uint64_t) ((flavour >= 2 ? UPG_NSRC_HOST : flavour ? UP_NSRC_W_HOST : UP_NSRC_HOST) - 3)) << 32) / d.step_y + 1;
+        if ((uint64_t) atoi (e) >= 1)
+            tr = (uint64_t) atoi (e) < lim ? (uint64_t) atoi (e) : lim;
+        if (tr > 64)
+            tr = 64;
+    }
     d.tile_rows = (uint16_t) tr;
 
     /* source pixels a tile can reach: ofs (x0 + cols - 1) + 1 - ofs (x0) + 1 */

@@ -237,6 +237,32 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
                                   __builtin_amdgcn_perm (hi [2], lo [2], J.up_perm), __builtin_amdgcn_perm (hi [3], lo [3], J.up_perm) };
                 /* non-temporal, not write-through: this kernel is bound by its stores, and write-through 16-byte
                  * stores run config 3 at 114 us against 88-93 us (profiles/r02m_store_policy.txt) */
+                /* Rows that start anywhere in a 128-byte line (every output width that is not a multiple of 32 pixels):
+                 * the wave's kilobyte is seven whole lines and two partial ones, and a streaming store of a PART of a line
+                 * is a read-modify-write in memory -- the other part comes from the neighbouring tile at another time
+                 * (1920x1080 x3: 104 us on 16-byte multiples, 149 us on an odd width). The lanes whose 16 bytes touch
+                 * the run's first or last line store write-back, so that the two parts meet in the L2 (neighbouring tiles
+                 * run on one XCD: tile_band), the whole lines in between keep streaming: x2.4 98 -> 86 us, x2.6 116 -> 95,
+                 * x3 149 -> 120, x4 268 -> 231; every lane write-back 123 / 141 / 174 / 282, write-through 147 / 164 / 206 / 390
+                 * (profiles/r05_up_handover.txt). Distinct instructions -- an asm store and a plain one: the compiler
+                 * merges two C stores that differ only in their cache policy. */
+                if (!J.out_wt)
+                {
+                    const uint32_t a = (uint32_t) (uintptr_t) out_row + xl * 4u;
+                    const uint32_t run = a - lane * 16u;
+                    const uint32_t lo_b = (run + 127u) & ~127u, hi_b = (run + 1024u) & ~127u;
+                    if (a < lo_b || a + 16u > hi_b)
+                    {
+#ifdef SMOL_KERNEL_EMU
+                        __builtin_memcpy (gptr (out_row) + (size_t) xl * 4, &v, 16);
+#else
+                        *reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (gptr (out_row) + (size_t) xl * 4) = v;
+#endif
+                    }
+                    else
+                        store_out128_nt (gptr (out_row) + (size_t) xl * 4, v);
+                }
+                else
                 store_nt128 (gptr (out_row) + (size_t) xl * 4, v);
             }
             else

@@ -1174,6 +1174,16 @@ __device__ __forceinline__ void store_out128 (gbyte *p, u32x4 v)
 #endif
 }
 
+/* the same, non-temporal (the nt bit): for runs of 16-byte stores on rows that start anywhere in a line (k_up) */
+__device__ __forceinline__ void store_out128_nt (gbyte *p, u32x4 v)
+{
+#if defined (SMOL_KERNEL_EMU)
+    __builtin_memcpy (p, &v, 16);
+#else
+    asm volatile ("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v" (p), "v" (v) : "memory");
+#endif
+}
+
 /* workgroup -> (x, y, job) under the XCD-aware order (smol_jobdev.h: TileSwz) */
 __device__ __forceinline__ void tile_coords (const TileSwz &S, uint32_t &bx, uint32_t &by, uint32_t &bz)
 {

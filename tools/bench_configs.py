@@ -182,7 +182,12 @@ IMAGES_OVERRIDE = None      # --images N
 
 
 def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False, natural=False):
-    cfg = CONFIGS[name]
+    if name.startswith("G:"):
+        # ad-hoc geometry: G:t_in:w_in:h_in:t_out:w_out:h_out:n_images[:srgb]
+        f = [int(v) for v in name.split(":")[1:]]
+        cfg = (f[0], f[1], f[2], None, f[3], f[4], f[5], f[6], "ad hoc %dx%d type %d -> %dx%d type %d, %d frames" % (f[1], f[2], f[0], f[4], f[5], f[3], f[6])) + ((f[7],) if len(f) > 7 else ())
+    else:
+        cfg = CONFIGS[name]
     t_in0, w_in, h_in, stride_in, t_out0, w_out, h_out, n_images, desc = cfg[:9]
     if IMAGES_OVERRIDE:
         n_images = IMAGES_OVERRIDE                  # launch-size sensitivity (tail effects of small launches)
