@@ -498,6 +498,9 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             else
             {
                 /* rows that start anywhere: write-back, so that the two parts of a shared line meet in the L2 (fill_jobdev) */
+                /* (k_up's rule -- whole lines non-temporal, only the lanes on the run's partial first / last line write-back -- was
+                 * tried here too: sweep points 3840x2160 -> 3724, 2803, 4185 wide -3 ... -5 %, -> 3494, 6758, 7411 wide +2 ... +6 %:
+                 * profiles/r05_up_handover.txt, section 5. Not kept.) */
 #ifdef SMOL_KERNEL_EMU
                 __builtin_memcpy (gptr (rowp) + (size_t) xl * 4, &v, 16);
 #else
