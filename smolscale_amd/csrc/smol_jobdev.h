@@ -410,6 +410,19 @@ fill_jobdev (JobDev &d, const SmolHipJob &j, const void *src, uint32_t src_strid
         d.pos_in [i] = ti.pos [i];
         d.pos_out [i] = to.pos [i];
     }
+    /* R and B are labels: nothing between unpack and pack tells the colour channels apart (every conversion and every
+     * filter treats them alike), so the two are swapped on BOTH sides whenever the source holds B in front of R. The
+     * kernels then only ever see colour bytes in ascending memory order -- 0,1,2 (alpha absent or last) or 1,2,3 (alpha
+     * first): k_lind's three-channel flavour reads bytes 0,1,2 with compile-time selectors (one SDWA instruction where a
+     * run-time position costs a v_bfe and a shift). (The same in WideUnpack for 32-bit sources -- SDWA shifts and multiplies,
+     * alpha-first words rotated -- measured neutral, -3 ... +4 % by row, and was not kept: profiles/r05_lind3_ab.txt.) The
+     * 64bpp class works on whole pixel words and out_perm (below), which is made from the types themselves. */
+    if (d.pos_in [0] > d.pos_in [2])
+    {
+        const uint8_t ti0 = d.pos_in [0], to0 = d.pos_out [0];
+        d.pos_in [0] = d.pos_in [2]; d.pos_in [2] = ti0;
+        d.pos_out [0] = d.pos_out [2]; d.pos_out [2] = to0;
+    }
     d.unassoc_in = ti.unassoc; d.unassoc_out = to.unassoc;
     d.wide = j.wide; d.p16 = j.premul16; d.linear = j.linear; d.quirk24 = j.quirk24;
     d.in_dword_ok = (ti.bpp == 4 && (((uintptr_t) src | src_stride) & 3) == 0);

@@ -586,26 +586,6 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
  *   alpha    is the constant 255: neither staged nor filtered; the packer is WP_LIN_O (or the `123' packer's WP_LIN_Q).
  * Tile geometry, schedules and row order are lind_body's. */
 
-/* (byte B of w) << `sh' (sh in a register): the address of a table entry, in one SDWA shift */
-template <int B>
-__device__ __forceinline__ uint32_t smol_byte_x2 (uint32_t w, uint32_t one)
-{
-#ifdef SMOL_KERNEL_EMU
-    return ((w >> (8 * B)) & 0xffu) << one;
-#else
-    uint32_t r;
-    if (B == 0)
-        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v" (r) : "v" (one), "v" (w));
-    else if (B == 1)
-        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v" (r) : "v" (one), "v" (w));
-    else if (B == 2)
-        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v" (r) : "v" (one), "v" (w));
-    else
-        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v" (r) : "v" (one), "v" (w));
-    return r;
-#endif
-}
-
 /* One look-up in the 16-bit (8-bit) table at offset OFS of the workgroup's table copy, which starts at LDS address 0 (the
  * kernels of this family have no static LDS, and lind_entry traps if that ever changes): the LDS pointer is made from
  * the INTEGER a + OFS, so OFS lands in the instruction's offset field. Through the `lds' symbol the compiler adds the
@@ -833,13 +813,8 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
     };
 
     /* ---- the row loop -------------------------------------------------------------------------------------------- */
-    /* the packer sees the channels in the source's memory order: R and B trade places in its selectors for B,G,R rows */
-    JobDev Jp = J;
-    if (J.pos_in [0] != 0)
-    {
-        Jp.pos_out [0] = J.pos_out [2];
-        Jp.pos_out [2] = J.pos_out [0];
-    }
+    /* (the channels travel in the source's memory order: fill_jobdev () has swapped the R / B labels of B,G,R rows on both sides) */
+    const JobDev &Jp = J;
     /* 24-bit output: the four pixels of a quad of lanes are twelve bytes = three dwords. Lane j of the quad (j < 3) takes
      * pixel j + 1 from its neighbour (one DPP move), cuts dword j out of the two (one v_perm, selector by j) and stores it
      * at its pixel's address + j (global stores need no alignment on gfx950): one 4-byte store on 48 lanes where there

@@ -251,6 +251,10 @@ struct LutLds
     __device__ __forceinline__ uint32_t from_srgb (uint32_t v) const { return fs [v]; }
     __device__ __forceinline__ uint32_t to_srgb (uint32_t v) const { return ts [v]; }
     __device__ __forceinline__ uint32_t opaque_lin (uint32_t v) const { return oq [v]; }
+    /* the same by BYTE offset into the table (index times the entry size, as smol_byte_x2 makes it in one instruction) */
+    __device__ __forceinline__ uint32_t inv_p8_at (uint32_t b) const { return *reinterpret_cast<const SMOL_AS_LDS uint32_t *> (reinterpret_cast<const SMOL_AS_LDS uint8_t *> (p8) + b); }
+    __device__ __forceinline__ uint32_t from_srgb_at (uint32_t b) const { return *reinterpret_cast<const SMOL_AS_LDS uint16_t *> (reinterpret_cast<const SMOL_AS_LDS uint8_t *> (fs) + b); }
+    __device__ __forceinline__ uint32_t opaque_lin_at (uint32_t b) const { return *reinterpret_cast<const SMOL_AS_LDS uint16_t *> (reinterpret_cast<const SMOL_AS_LDS uint8_t *> (oq) + b); }
 };
 
 /* the entries' guard for LUT_AT_LDS_0 (folds away when the compiler knows the address, costs a scalar compare otherwise) */
@@ -571,6 +575,59 @@ __device__ __forceinline__ int wide_pack_kind (const JobDev &J)
     if (J.bpp_out == 3)
         return J.quirk24 ? WP_LIN_Q : WP_LIN_U;
     return J.unassoc_out ? WP_LIN_U : WP_LIN_P;
+}
+
+/* (byte B of w) << `sh' (sh in a register): the address of a table entry, in one SDWA shift */
+template <int B>
+__device__ __forceinline__ uint32_t smol_byte_x2 (uint32_t w, uint32_t one)
+{
+#ifdef SMOL_KERNEL_EMU
+    return ((w >> (8 * B)) & 0xffu) << one;
+#else
+    uint32_t r;
+    if (B == 0)
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v" (r) : "v" (one), "v" (w));
+    else if (B == 1)
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v" (r) : "v" (one), "v" (w));
+    else if (B == 2)
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v" (r) : "v" (one), "v" (w));
+    else
+        asm ("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v" (r) : "v" (one), "v" (w));
+    return r;
+#endif
+}
+
+/* w rotated right by one byte (v_alignbit_b32) */
+__device__ __forceinline__ uint32_t smol_rotr8 (uint32_t w)
+{
+    return (w >> 8) | (w << 24);
+}
+
+/* byte B of w */
+template <int B>
+__device__ __forceinline__ uint32_t smol_byte (uint32_t w)
+{
+    return B == 3 ? w >> 24 : (w >> (8 * B)) & 0xffu;   /* (B = 0: v_and, B = 3: v_lshrrev -- the 2-cycle class; else one v_bfe) */
+}
+
+/* (byte B of w) * m, m < 2^24: one SDWA multiply, no extraction */
+template <int B>
+__device__ __forceinline__ uint32_t smol_byte_mul24 (uint32_t w, uint32_t m)
+{
+#ifdef SMOL_KERNEL_EMU
+    return ((w >> (8 * B)) & 0xffu) * (m & 0xffffffu);
+#else
+    uint32_t r;
+    if (B == 0)
+        asm ("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v" (r) : "v" (w), "v" (m));
+    else if (B == 1)
+        asm ("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v" (r) : "v" (w), "v" (m));
+    else if (B == 2)
+        asm ("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v" (r) : "v" (w), "v" (m));
+    else
+        asm ("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v" (r) : "v" (w), "v" (m));
+    return r;
+#endif
 }
 
 template <int K>

@@ -448,6 +448,7 @@ def test_dispatcher_keeps_proportional_resizes_off_the_backstops():
     assert sm.kernel_name(sm.plan_job(0, 4096, 2048, 0, 2731, 3000, 1)) == "k_lind_batch"        # H down, V up: one kernel
     assert sm.kernel_name(sm.plan_job(4, 1000, 3000, 4, 2731, 3000, 0)) == "k_lind_batch"        # H up, V COPY, premul16
     assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 300, 2000, 1)) == "k_boxh_batch + k_linv_batch"
-    assert sm.kernel_name(sm.plan_job(4, 300, 4000, 4, 900, 200, 0)) == "k_linh_batch + k_boxv_batch"
+    assert sm.kernel_name(sm.plan_job(4, 300, 4000, 4, 900, 200, 0)) == "k_linh_batch (vertical box sums in registers) + k_boxv_batch"
+    assert sm.kernel_name(sm.plan_job(4, 300, 4000, 4, 900, 200, 1)).startswith("k_linh_batch (vertical box sums")   # premul16 + sRGB: no backstop any more
     assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 2731, 2731, 1)) == "k_lind_batch"
     assert sm.kernel_name(sm.plan_job(8, 4000, 3000, 8, 1600, 1200, 1)) == "k_lind_batch"
