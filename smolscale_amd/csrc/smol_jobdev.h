@@ -809,17 +809,8 @@ down_setup (JobDev &d)
     t.tile_cpl = 2;
     t.up_wide = 1;
     t.down_mode = 3;
-    /* (tuning builds: SMOL_LIND_TRI=1 sends premultiplied 32-bit gamma-correct sources through the fused-table flavour) */
-    if (tune_env ("SMOL_LIND_TRI") && !t.p16 && t.linear && t.bpp_in == 4 && !t.unassoc_in && !(t.halv_h >= 1 && w <= 64))
-        t.down_mode = 4;
     d = t;
     return true;
-}
-
-SMOL_HD inline uint32_t
-down_blocks_dev (const JobDev &d)
-{
-    return ((d.w_out + d.group_rows - 1u) / d.group_rows) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
 }
 
 /* tiles of the job (a workgroup takes lind_waves () of them) */
@@ -829,17 +820,12 @@ down_blocks (const JobDev &d)
     return ((d.w_out + d.group_rows - 1u) / d.group_rows) * ((d.n_rows + d.tile_rows - 1u) / d.tile_rows);
 }
 
-/* down_mode 4: the fused-table flavour of k_lind (premultiplied 32-bit sources, gamma-correct; smol_kernel_lind.hip.h: TRI) --
- * 16 waves around 66 KB of table */
-inline bool lind_tri (const JobDev &d) { return d.down_mode == 4; }
-constexpr uint32_t LIND_TRI_BYTES_HOST = (256u * 257u + 15u) & ~15u;
-inline uint32_t lind_waves (const JobDev &d) { return lind_tri (d) ? 16u : 4u; }     /* waves (= tiles) per workgroup, around one copy of the tables */
+inline uint32_t lind_waves (const JobDev &) { return 4u; }     /* waves (= tiles) per workgroup, around one copy of the tables */
 
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
-    return DOWN_LUT_BYTES + (lind_tri (d) ? LIND_TRI_BYTES_HOST : 0u)
-           + lind_waves (d) * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
+    return DOWN_LUT_BYTES + lind_waves (d) * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
 }
 
 /* host twin of the device box_span (smol_kernels.hip.h; closed form of smolscale.c's box precalc) */

@@ -4,12 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
-#include <mutex>
-
 #include "smol_kernels.hip.h"
 #include "smol_kernel_tile.hip.h"
 #include "smol_kernel_up.hip.h"
-#define SMOL_LIND_TRI_TU 1
 #include "smol_kernel_lind.hip.h"
 #include "smol_launch.h"
 
@@ -38,48 +35,10 @@ launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
         hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN>), grid, block, lds, s, rep);
 }
 
-/* the fused-table flavour (premultiplied 32-bit sources): the table is made once per device, before the first launch */
-void
-lind_tri_ready ()
-{
-    static std::mutex mtx;
-    static bool done [64];
-    int dev = 0;
-    if (hipGetDevice (&dev) != hipSuccess || dev < 0 || dev >= 64)
-        return;
-    std::lock_guard<std::mutex> g (mtx);
-    if (done [dev])
-        return;
-    hipLaunchKernelGGL (smolhip::k_lind_tri_fill, dim3 (256), dim3 (256), 0, 0);
-    (void) hipDeviceSynchronize ();
-    done [dev] = true;
-}
-
-template <int HX>
-void
-launch_lindt (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
-{
-    lind_tri_ready ();
-    if (jobs_dev)
-        hipLaunchKernelGGL ((smolhip::k_lindt_batch<HX>), grid, dim3 (64u * 16u), lds, s, jobs_dev);
-    else
-        hipLaunchKernelGGL ((smolhip::k_lindt_one<HX>), grid, dim3 (64u * 16u), lds, s, rep);
-}
-
 template <int IN>
 void
 launch_lind (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
-    if (IN == 0 && smolhip::dispatch::lind_tri (rep))
-    {
-        switch (rep.halv_h)
-        {
-            case 0:  launch_lindt<0> (jobs_dev, rep, grid, lds, s); break;
-            case 1:  launch_lindt<1> (jobs_dev, rep, grid, lds, s); break;
-            default: launch_lindt<2> (jobs_dev, rep, grid, lds, s); break;
-        }
-        return;
-    }
     switch (rep.halv_h)
     {
         case 0:  launch_lind_k<0, IN> (jobs_dev, rep, grid, lds, s); break;
@@ -133,13 +92,6 @@ down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStr
 {
     const uint32_t wv = smolhip::dispatch::lind_waves (rep);
     grid.x = (grid.x + wv - 1) / wv;
-    if (smolhip::dispatch::lind_tri (rep))
-    {
-        /* persistent workgroups: one per CU over all the launch's jobs */
-        const uint32_t per_job = grid.y >= 256u ? 1u : 256u / grid.y;
-        if (grid.x > per_job)
-            grid.x = per_job;
-    }
     if (rep.p16)
         launch_lind<2> (jobs_dev, rep, grid, lds, s);
     else if (rep.bpp_in == 3)

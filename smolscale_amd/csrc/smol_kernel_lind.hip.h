@@ -50,19 +50,9 @@ enum : int { LIND_FUSED = 0, LIND_H = 1, LIND_V = 2 };
 /* TMP8 (passes of the W32 flavour only): the intermediate pixel is 8 bytes of 16-bit channels -- what k_boxh writes and
  * k_boxv reads (premul16 without sRGB: every value fits 16 bits) -- instead of four 32-bit channels (16 bytes) */
 /* NARROW (chosen per job at the entry, one or two halvings): tiles of at most 64 columns */
-/* TRI (round 5, the experiment the review asked for twice): premultiplied 32-bit sources through the FUSED table
- * L (c, a) = premul8l (from_srgb (unpremul8 (c, a)), a) for c <= a -- 32 896 16-bit entries, 66 KB of LDS, one workgroup
- * of 16 waves per CU around it. A translucent pixel is then three look-ups behind one multiply-add (the row of the
- * triangle) and an add per channel instead of the chain un-premultiply -> from_srgb -> premultiply (27 vector
- * instructions and 4 look-ups). A pixel with a colour byte above its alpha (not a premultiplied pixel, but the reference
- * defines what comes out) has no entry: a round that holds one on any lane takes the chain. tri_lds: the table's copy. */
-constexpr uint32_t LIND_TRI_ENTRIES = 256u * 257u / 2u;
-constexpr uint32_t LIND_TRI_BYTES = (LIND_TRI_ENTRIES * 2u + 15u) & ~15u;
-constexpr uint32_t LIND_TRI_WAVES = 16;
-
-template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false, bool TRI = false>
+template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
-                                           const uint32_t lane, const uint32_t tile, const uint8_t *tri_lds = nullptr)
+                                           const uint32_t lane, const uint32_t tile)
 {
     static_assert (!(IN24 && W32), "premul16 means 32-bit pixels on both sides");
     constexpr uint32_t TPX = (W32 && !TMP8) ? 16u : 8u;            /* bytes per pixel of the intermediate image */
@@ -343,36 +333,6 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                     all &= rawpx [k];
             if (wide_batch_opaque (J, all))
                 conv (WideUnpack<WU_LIN_O> (J, lut));
-            else if (TRI && uk == WU_LIN_P)
-            {
-                const WideUnpack<WU_LIN_P> chain (J, lut);
-                const uint32_t sa8 = 8u * (J.pos_in [3] & 3u), s0 = 8u * J.pos_in [0], s1 = 8u * J.pos_in [1], s2 = 8u * J.pos_in [2];
-                const uint16_t *tri = reinterpret_cast<const uint16_t *> (tri_lds);
-#pragma unroll
-                for (int k = 0; k < KMAX; k++)
-                    if ((uint32_t) k * 64u < npx)
-                    {
-                        const uint32_t w = rawpx [k];
-                        const uint32_t a = (w >> sa8) & 0xffu;
-                        const uint32_t row = (__umul24 (a, a) + a) >> 1;            /* entries in front of row a */
-                        const uint32_t i0 = row + ((w >> s0) & 0xffu), i1 = row + ((w >> s1) & 0xffu), i2 = row + ((w >> s2) & 0xffu);
-                        const uint32_t top = i0 > i1 ? (i0 > i2 ? i0 : i2) : (i1 > i2 ? i1 : i2);
-                        uint32_t ch [4];
-#ifdef SMOL_KERNEL_EMU
-                        const bool all_valid = top <= row + a;                      /* (emulated lanes decide one by one: same bytes) */
-#else
-                        const bool all_valid = __builtin_amdgcn_ballot_w64 (top > row + a) == 0;
-#endif
-                        if (all_valid)
-                        {
-                            ch [0] = tri [i0]; ch [1] = tri [i1]; ch [2] = tri [i2]; ch [3] = a;
-                        }
-                        else
-                            chain (w, ch);
-                        *reinterpret_cast<u32x2a8 *> (buf + ((uint32_t) k * 64u + lane) * 8u)
-                            = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
-                    }
-            }
             else if (uk == WU_LIN_P)
                 conv (WideUnpack<WU_LIN_P> (J, lut));
             else
@@ -981,6 +941,10 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
     }
 }
 
+/* (The fused 2-D table L (c, a) for premultiplied sources -- 66 KB of LDS, 16-wave persistent workgroups -- was built and
+ * measured in round 5: bit-exact and 1.5 x slower than the chain above, 0.39 -> 0.26 of the roofline; one workgroup per CU
+ * costs more than the table saves. profiles/r05_lind_tri_ab.txt, git 3f9fcfe.) */
+
 /* LDS of one wave: the row buffer */
 __device__ __forceinline__ uint32_t lind_wave_lds (bool w32, bool narrow = false)
 {
@@ -1096,74 +1060,6 @@ __device__ __forceinline__ void linv_dispatch (const JobDev &J, uint8_t *lds)
         default: linv_entry<0> (J, lds); break;
     }
 }
-
-/* entry (c, a), c <= a, of the fused table: the chain of WideUnpack<WU_LIN_P> (smolscale-generic.c:481-535) */
-__device__ __forceinline__ uint32_t lind_tri_entry (uint32_t c, uint32_t a)
-{
-    const uint32_t u = (inv_mul (c, smol_inv_p8_lut [a]) >> 13) & 0xffu;
-    const uint32_t a8 = a << 3;
-    return (__umul24 (smol_from_srgb_lut [u], a8 | 1u) + a8) >> 11;
-}
-
-#ifdef SMOL_KERNEL_EMU
-template <int HX>
-__device__ __forceinline__ void lindt_entry (const JobDev &J, uint8_t *lds)
-{
-    static uint8_t lut_lds [LUT_LDS_BYTES];
-    static uint16_t tri [LIND_TRI_ENTRIES];
-    lut_fill_lds (lut_lds, 0, 1);
-    for (uint32_t a = 0, i = 0; a < 256; a++)
-        for (uint32_t c = 0; c <= a; c++)
-            tri [i++] = (uint16_t) lind_tri_entry (c, a);
-    lind_body<HX, false, false, LIND_FUSED, false, false, true> (J, lds, lut_lds, threadIdx.x, blockIdx.x, reinterpret_cast<const uint8_t *> (tri));
-}
-#else
-#ifdef SMOL_LIND_TRI_TU
-/* the table in device memory, filled once per device (smol_k_updown.hip: lind_tri_ready) */
-__device__ uint16_t smol_lind_tri [LIND_TRI_BYTES / 2u];
-
-__global__ void __launch_bounds__ (256)
-k_lind_tri_fill ()
-{
-    const uint32_t a = blockIdx.x, row = (a * a + a) >> 1;
-    for (uint32_t c = threadIdx.x; c <= a; c += 256u)
-        smol_lind_tri [row + c] = (uint16_t) lind_tri_entry (c, a);
-}
-
-template <int HX>
-__device__ __forceinline__ void lindt_entry (const JobDev &J, uint8_t *lds)
-{
-    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
-    lut_expect_lds_0 (lds);
-    lut_fill_lds (lds, threadIdx.x, 64u * LIND_TRI_WAVES);
-    uint8_t *tri = lds + ((LUT_LDS_BYTES + 15u) & ~15u);
-    /* 66 KB from device memory (L2 after the first workgroups): 16 bytes per thread and step */
-    for (uint32_t o = threadIdx.x * 16u; o < LIND_TRI_BYTES; o += 64u * LIND_TRI_WAVES * 16u)
-        *reinterpret_cast<u32x4 *> (tri + o) = *reinterpret_cast<const u32x4 *> (reinterpret_cast<const uint8_t *> (smol_lind_tri) + o);
-    __syncthreads ();
-    /* persistent: one workgroup per CU (the host launches no more than the chip holds), every wave walks its share of the
-     * job's tiles -- a workgroup that ended with its slowest tile would leave the CU's other fifteen wave slots idle */
-    const uint32_t n_tiles = dispatch::down_blocks_dev (J);
-    for (uint32_t t = blockIdx.x * LIND_TRI_WAVES + wave; t < n_tiles; t += gridDim.x * LIND_TRI_WAVES)
-        lind_body<HX, false, false, LIND_FUSED, false, false, true> (J, tri + LIND_TRI_BYTES + wave * lind_wave_lds (false, false), lds, threadIdx.x & 63u, t, tri);
-}
-
-template <int HX>
-__global__ void __launch_bounds__ (64 * LIND_TRI_WAVES)
-k_lindt_batch (const JobDev *__restrict__ jobs)
-{
-    const JobDev J = load_job (jobs, blockIdx.y);
-    lindt_entry<HX> (J, smol_dyn_lds);
-}
-
-template <int HX>
-__global__ void __launch_bounds__ (64 * LIND_TRI_WAVES)
-k_lindt_one (const JobDev J)
-{
-    lindt_entry<HX> (J, smol_dyn_lds);
-}
-#endif
-#endif
 
 #ifndef SMOL_KERNEL_EMU
 /* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels) */

@@ -11,16 +11,6 @@ namespace smolhip {
 __global__ void k_down_one (const JobDev J)
 {
     const int in = J.p16 ? 2 : J.bpp_in == 3 ? 1 : 0;
-    if (dispatch::lind_tri (J))                 /* the fused-table flavour (SMOL_LIND_TRI in the emulation's environment) */
-    {
-        switch (J.halv_h)
-        {
-            case 0: lindt_entry<0> (J, smol_dyn_lds); break;
-            case 1: lindt_entry<1> (J, smol_dyn_lds); break;
-            default: lindt_entry<2> (J, smol_dyn_lds); break;
-        }
-        return;
-    }
     if (dispatch::lind_narrow (J))              /* tiles of at most 64 columns: the one-column flavour */
     {
         switch (J.halv_h * 3 + in)
