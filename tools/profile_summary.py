@@ -56,7 +56,8 @@ def by_grid(run, run_dir, last_n, out):
         tail = us[-last_n:] if last_n and len(us) > last_n else us
         out.append({"run": run, "kernel": k, "grid": g, "workgroup": wg, "dispatches": len(us), "timed": len(tail),
                     "mean_us": round(sum(tail) / len(tail), 3), "min_us": round(min(tail), 3),
-                    "median_us": round(statistics.median(tail), 3)})
+                    "median_us": round(statistics.median(tail), 3),
+                    "mean_all_us": round(sum(us) / len(us), 3)})        # every dispatch, clock-settling launches included (= rocprofv3 --stats)
 
 
 rows = []
@@ -67,7 +68,7 @@ for d in sorted(glob.glob(os.path.join(O, "kt_cfg_*"))):
         # tools/bench_configs.py --iters 20: settle + warm-up, `iters' launches in one timed region, then 20 single steps
         by_grid(c, os.path.basename(d), 40, rows)
 with open(os.path.join(P, tag + "_kernel_by_grid.csv"), "w", newline="") as fh:
-    wr = csv.DictWriter(fh, fieldnames=["run", "kernel", "grid", "workgroup", "dispatches", "timed", "mean_us", "min_us", "median_us"])
+    wr = csv.DictWriter(fh, fieldnames=["run", "kernel", "grid", "workgroup", "dispatches", "timed", "mean_us", "min_us", "median_us", "mean_all_us"])
     wr.writeheader()
     wr.writerows(rows)
 
@@ -140,6 +141,7 @@ try:
             prof = [r for r in rows if r["run"] == "bench_c2" and "k_pow2" in r["kernel"]]
             if prof:
                 latest["profiled_launch_us"] = prof[0]["mean_us"]
+                latest["profiled_launch_all_us"] = prof[0]["mean_all_us"]
                 latest["profiled_source"] = ("profiles/%s_kernel_by_grid.csv: mean of the last %d of %d dispatches, rocprofv3 "
                                              "--kernel-trace of bench.py alone" % (tag, prof[0]["timed"], prof[0]["dispatches"]))
             latest.update({"kernel": k, "algorithmic_bytes_per_launch": algo, "source": "profiles/%s_traffic.json" % tag,
