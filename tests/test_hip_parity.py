@@ -833,3 +833,36 @@ def test_tall_vertical_boxes_behind_a_bilinear_horizontal_axis():
             rb = w_out * H.bpp(t_out)
             assert np.array_equal(got, want[first * rb:(first + n) * rb]), (spec, name, "strip")
     assert seen >= 5
+
+
+def test_gamma_correct_24_bit_sources_three_channel_flavour():
+    """Round 5: sources without an alpha channel take k_lind's three-channel flavour (lind3_body: SDWA + offset-field look-ups,
+    v_mad_u32_u16 taps, alpha neither staged nor filtered) -- the wide tiles (two columns per lane), the one-column flavour
+    behind one and two halvings, magnification, mixed axes; into every output type, 24-bit output through the quad dword
+    stores at every row alignment (odd widths, odd strides, misaligned device buffers, tiles that end inside a quad)."""
+    shapes = [(4000, 300, 1600, 120),      # ratio 2.5, 1 halving: wide tiles of 127 columns
+              (3000, 210, 420, 30),        # ratio 7.1, 2 halvings: one-column flavour
+              (1500, 200, 1000, 133),      # ratio 1.5, no halving
+              (480, 100, 1921, 401),       # magnified x4: stores dominate
+              (1000, 64, 333, 200),        # H down, V up
+              (257, 300, 1031, 75)]        # H up, V down
+    lib = sm.lib()
+    k = 0
+    for (w_in, h_in, w_out, h_out) in shapes:
+        for t_in in (8, 9):
+            for t_out in (8, 9, 0, 3, 5):
+                k += 1
+                if (k % 3) and w_in * h_in > 600_000:
+                    continue
+                sin = w_in * 3 + (k % 4)
+                sout = w_out * H.bpp(t_out) + (k % 3)
+                src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+                assert sm.kernel_name(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 1)) == "k_lind_batch"
+                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin, sout)
+                got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin, sout)
+                rb = w_out * H.bpp(t_out)
+                assert np.array_equal(H.rows_view(got, h_out, rb, sout), H.rows_view(want, h_out, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "host")
+                first, n = h_out // 3, max(1, h_out // 2)
+                got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin, sout, first, n,
+                                         src_misalign=k % 4, dst_misalign=(k // 2) % 4)
+                assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "device")

@@ -11,8 +11,12 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 LINE_CFGS="C1 C3 C4 C5 C5mix BOX C2CROP4"
-TABLE=C1,C2,C3,C4,C5,C5mix,BOX,C2CROP4,C2ODD,R1.03,R1.1,R1.2,R1.35,R1.5,R1.7,R1.9,R2.5,R3,R3.5,R5,R6,R7,U1.1,U1.37,U1.5,U2,U2.6,U3,PHOTO,PHOTOODD,PNG,R1.5RGB,R1.5U,HDOWNVUP,THUMB,P16,SRGB,P16UP,P16HALF,SRGBUP,SRGBPNGUP,SRGBHALF,SRGBPHOTO,SRGBPNG,SRGBTHUMB,SRGBBOX,BOX128,WIDEBOX,SRGBHDVU,SRGBVCOPY,SRGBBOXBIL,P16BOXBIL,P16HDVU,S4K109ODD,S4K91ODD,SRGBUPODD,P16UPODD,P16HALFODD,SRGBBOX64,SRGBBOX128,FLATBOXBIL,FLATBILBOX,FLATTALL,SRGBU1.1,SRGBU2,SRGBUP24,BOX12,BOX16,U8,U4RGB,U2UNASSOC,SRGBR6,SRGBR7RGB
+TABLE=C1,C2,C3,C4,C5,C5mix,BOX,C2CROP4,C2ODD,R1.03,R1.1,R1.2,R1.35,R1.5,R1.7,R1.9,R2.5,R3,R3.5,R5,R6,R7,U1.1,U1.37,U1.5,U2,U2.6,U3,PHOTO,PHOTOODD,PNG,R1.5RGB,R1.5U,HDOWNVUP,THUMB,P16,SRGB,P16UP,P16HALF,SRGBUP,SRGBPNGUP,SRGBHALF,SRGBPHOTO,SRGBPNG,SRGBTHUMB,SRGBBOX,BOX128,WIDEBOX,SRGBHDVU,SRGBVCOPY,SRGBBOXBIL,P16BOXBIL,P16HDVU,S4K109ODD,S4K91ODD,SRGBUPODD,P16UPODD,P16HALFODD,SRGBBOX64,SRGBBOX128,FLATBOXBIL,FLATBILBOX,FLATTALL,SRGBU1.1,SRGBU2,SRGBUP24,BOX12,BOX16,U8,U4RGB,U2UNASSOC,SRGBR6,SRGBR7RGB,SRGBBILBOX,P16BILBOX,P16LBILBOX
 python3 bench.py --steps 50 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt
+# the two measurements BASELINE itself names (Next 3): config 5 as a hipGraph of per-image kernel nodes beside the
+# descriptor-table launch (graph_mode), config 4 with its PCIe-inclusive leg (e2e: page-locked and pageable)
+python3 bench.py --config c5mix --steps 20 --warmup 5 > $O/c5mix_line.json 2> $O/c5mix_err.txt
+python3 bench.py --config c4 --steps 20 --warmup 5 > $O/c4_line.json 2> $O/c4_err.txt
 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o b --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-e2e > $O/kt_bench.log 2>&1
 for c in $LINE_CFGS; do
   rocprofv3 --kernel-trace --stats -d $O/kt_cfg_$c -o c --output-format csv -- python3 tools/bench_configs.py --iters 20 --warmup 3 --configs $c > $O/kt_cfg_$c.log 2>&1
@@ -39,3 +43,4 @@ for c in SRGB SRGBUP SRGBHALF SRGBPHOTO SRGBBOX; do bash tools/sq_counters.sh $T
 python3 tools/profile_summary.py $TAG
 python3 tools/roofline_check.py $TAG | tee $O/roofline_check.txt
 cp $O/roofline_check.txt profiles/${TAG}_roofline_check.txt
+cp $O/c5mix_line.json profiles/${TAG}_c5mix_line.json; cp $O/c4_line.json profiles/${TAG}_c4_line.json
