@@ -108,6 +108,21 @@ def cpu_baseline(seconds_budget=12.0):
         n3, total3 = run_ref("generic", n_threads, seconds_budget * 0.15)
         info["generic_allthreads_Mpix_s"] = round(n3 * W_OUT * H_OUT / total3 / 1e6, 1)
         want = dst[:W_OUT * H_OUT * 4].copy()
+        # beside the reference: this library's own CPU backend (smol_cpu.c, SMOL_BACKEND=cpu -- product code, a fallback, not the
+        # path this benchmark measures): the same frame, a call cut into strips over the host cores (SMOL_CPU_THREADS, default <= 32)
+        try:
+            job = sm.plan_job(PIX_TYPE, W_IN, H_IN, PIX_TYPE, W_OUT, H_OUT, 0)
+            d2 = np.zeros(W_OUT * H_OUT * 4 + 16, np.uint8)
+            fn = sm.lib().smol_cpu_scale_rows
+            fn(ctypes.byref(job), src.ctypes.data, W_IN * 4, d2.ctypes.data, W_OUT * 4, 0, H_OUT)
+            t0, k = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 1.0:
+                fn(ctypes.byref(job), src.ctypes.data, W_IN * 4, d2.ctypes.data, W_OUT * 4, 0, H_OUT)
+                k += 1
+            info["library_cpu_backend"] = {"Mpix_s": round(k * W_OUT * H_OUT / (time.perf_counter() - t0) / 1e6, 1),
+                                           "threads": min(32, n_threads), "bit_exact_vs_reference": bool(np.array_equal(d2[:W_OUT * H_OUT * 4], want))}
+        except Exception as e:                      # noqa: BLE001
+            info["library_cpu_backend"] = {"error": repr(e)}
     else:
         t0 = time.perf_counter()
         n = 0

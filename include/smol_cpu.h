@@ -1,9 +1,10 @@
 /* smol_cpu.h -- C-ABI of the library's CPU backend: a from-scratch implementation of the same
- * resampling path, bit-exact with the reference's generic code (smolscale-generic.c:185-2318), kept as a CORRECTNESS
- * fallback -- scalar for every class but 32-bit premultiplied bilinear (packed 16-bit lanes, AVX2 / AVX-512BW chosen
- * at run time), one thread per call, about half the reference's AVX2 speed per thread. Not a performance path. It is what smol_scale_*() runs on when the caller selects it with
- * SMOL_BACKEND=cpu (or SMOL_BACKEND=auto on a machine without a usable GPU); the default backend
- * stays HIP, and a missing GPU then stays a loud failure. */
+ * resampling path, bit-exact with the reference's generic code (smolscale-generic.c:185-2318), kept as a FALLBACK:
+ * 32-bit lanes for every class but 32-bit premultiplied bilinear (packed 16-bit lanes, AVX2 / AVX-512BW chosen at run
+ * time: the reference's AVX2 speed per thread there); a call of enough rows is cut into strips of output rows over
+ * the host cores (SMOL_CPU_THREADS, default the online cores up to 32; 1 = stay on the calling thread). It is what
+ * smol_scale_*() runs on when the caller selects it with SMOL_BACKEND=cpu (or SMOL_BACKEND=auto on a machine without
+ * a usable GPU); the default backend stays HIP, and a missing GPU then stays a loud failure. */
 
 #ifndef SMOLSCALE_AMD_SMOL_CPU_H
 #define SMOLSCALE_AMD_SMOL_CPU_H
@@ -17,7 +18,7 @@ extern "C" {
 
 /* Rows [first_row, first_row + n_rows) of the job planned by smol_hip_plan_job(), host pointers,
  * row `first_row' written at dest + 0, rowstride_out apart (bytes between rows untouched).
- * Thread-safe (no shared state). Returns 0 or SMOL_HIP_E_INVALID. */
+ * Thread-safe. Returns 0 or SMOL_HIP_E_INVALID. */
 int smol_cpu_scale_rows (const SmolHipJob *job,
                          const void *pixels_in, uint32_t rowstride_in,
                          void *dest, uint32_t rowstride_out,

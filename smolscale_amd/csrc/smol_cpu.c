@@ -639,28 +639,20 @@ smol_cpu_scale_rows (const SmolHipJob *job,
     return rc;
 }
 
-int
-smol_cpu_plan_scale_rows (const SmolCpuPlan *plan,
-                          const void *pixels_in, uint32_t rowstride_in,
-                          void *dest, uint32_t rowstride_out,
-                          uint32_t first_row, uint32_t n_rows)
+/* one strip of output rows on the calling thread (the plan is immutable: any number of strips may run at once) */
+static int
+strip_scale_rows (const SmolCpuPlan *plan,
+                  const void *pixels_in, uint32_t rowstride_in,
+                  void *dest, uint32_t rowstride_out,
+                  uint32_t first_row, uint32_t n_rows)
 {
-    const Ctx *cp;
-    const SmolHipJob *job;
+    const Ctx *cp = &plan->c;
+    const SmolHipJob *job = &plan->job;
     RowSource rs;
     uint32_t *mem, *vout, *acc;
     uint32_t y, k, x;
     size_t row_lanes_in, row_lanes_out;
     uint8_t *drow = dest;
-
-    if (!plan || !pixels_in || !dest)
-        return SMOL_HIP_E_INVALID;
-    cp = &plan->c;
-    job = &plan->job;
-    if (n_rows == 0)
-        return 0;
-    if (first_row >= job->height_out || n_rows > job->height_out - first_row)
-        return SMOL_HIP_E_INVALID;
 
 #ifdef SMOL_CPU_X86
     if (fast_class_ok (cp))
@@ -742,4 +734,169 @@ smol_cpu_plan_scale_rows (const SmolCpuPlan *plan,
 
     free (mem);
     return 0;
+}
+
+/* ---- a call's rows over the host cores ------------------------------------------------------------------
+ * Output rows are independent given the source (the reference's own harness cuts an image into one strip per
+ * worker: test.c:838-883): a call of enough rows is cut into strips that run on a small persistent pool, the
+ * calling thread taking its share. SMOL_CPU_THREADS = threads per call (default: the online cores, at most 32;
+ * 1 = never leave the calling thread). Each strip re-filters the one or two source rows it shares with its
+ * neighbour -- a bilinear halo -- and nothing else is shared. */
+#include <pthread.h>
+#include <unistd.h>
+
+typedef struct
+{
+    const SmolCpuPlan *plan;
+    const uint8_t *src;
+    uint8_t *dest;
+    uint32_t stride_in, stride_out, first, n, n_strips;
+    uint32_t next;                      /* next strip to claim (under pool_mtx) */
+    uint32_t done;                      /* strips finished */
+    int rc;
+} CpuCall;
+
+static pthread_mutex_t pool_mtx = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t pool_work = PTHREAD_COND_INITIALIZER, pool_done = PTHREAD_COND_INITIALIZER;
+static CpuCall *pool_call;              /* the call being served (one at a time; others run on their own thread) */
+static uint32_t pool_threads;           /* helpers alive */
+
+static void
+call_run_strip (CpuCall *c, uint32_t i)
+{
+    const uint32_t per = (c->n + c->n_strips - 1) / c->n_strips;
+    const uint32_t a = i * per, b = a + per < c->n ? a + per : c->n;
+    if (a < b)
+    {
+        const int rc = strip_scale_rows (c->plan, c->src, c->stride_in, c->dest + (size_t) a * c->stride_out, c->stride_out,
+                                         c->first + a, b - a);
+        if (rc)
+        {
+            pthread_mutex_lock (&pool_mtx);
+            c->rc = rc;
+            pthread_mutex_unlock (&pool_mtx);
+        }
+    }
+}
+
+static void *
+pool_main (void *arg)
+{
+    (void) arg;
+    pthread_mutex_lock (&pool_mtx);
+    for (;;)
+    {
+        CpuCall *c = pool_call;
+        if (c && c->next < c->n_strips)
+        {
+            const uint32_t i = c->next++;
+            pthread_mutex_unlock (&pool_mtx);
+            call_run_strip (c, i);
+            pthread_mutex_lock (&pool_mtx);
+            if (++c->done == c->n_strips)
+                pthread_cond_broadcast (&pool_done);
+            continue;
+        }
+        pthread_cond_wait (&pool_work, &pool_mtx);
+    }
+    return NULL;
+}
+
+static uint32_t
+cpu_threads_wanted (void)
+{
+    static uint32_t cached;
+    if (!cached)
+    {
+        const char *e = getenv ("SMOL_CPU_THREADS");
+        long v = e && *e ? strtol (e, NULL, 10) : 0;
+        if (v <= 0)
+        {
+            v = sysconf (_SC_NPROCESSORS_ONLN);
+            if (v > 32) v = 32;
+        }
+        if (v < 1) v = 1;
+        if (v > 256) v = 256;
+        cached = (uint32_t) v;
+    }
+    return cached;
+}
+
+int
+smol_cpu_plan_scale_rows (const SmolCpuPlan *plan,
+                          const void *pixels_in, uint32_t rowstride_in,
+                          void *dest, uint32_t rowstride_out,
+                          uint32_t first_row, uint32_t n_rows)
+{
+    const SmolHipJob *job;
+    uint32_t want;
+    uint64_t work;
+
+    if (!plan || !pixels_in || !dest)
+        return SMOL_HIP_E_INVALID;
+    job = &plan->job;
+    if (n_rows == 0)
+        return 0;
+    if (first_row >= job->height_out || n_rows > job->height_out - first_row)
+        return SMOL_HIP_E_INVALID;
+
+    /* worth cutting up? (pixels read + written by the call, roughly) */
+    work = (uint64_t) n_rows * job->width_out + (uint64_t) n_rows * job->width_in * (job->height_in / (job->height_out ? job->height_out : 1) + 1);
+    want = cpu_threads_wanted ();
+    if (want > n_rows / 4)
+        want = n_rows / 4;
+    if (want < 2 || work < 262144)
+        return strip_scale_rows (plan, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
+
+    {
+        CpuCall call;
+        uint32_t i;
+
+        call.plan = plan; call.src = pixels_in; call.dest = dest;
+        call.stride_in = rowstride_in; call.stride_out = rowstride_out;
+        call.first = first_row; call.n = n_rows;
+        call.n_strips = want * 2;       /* twice the threads: the last strips even out the finish */
+        if (call.n_strips > n_rows)
+            call.n_strips = n_rows;
+        call.next = 0; call.done = 0; call.rc = 0;
+
+        pthread_mutex_lock (&pool_mtx);
+        if (pool_call)
+        {
+            /* the pool serves another caller's call: this one runs where it is (callers that thread themselves --
+             * the reference's harness does -- must not queue behind each other) */
+            pthread_mutex_unlock (&pool_mtx);
+            return strip_scale_rows (plan, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
+        }
+        while (pool_threads < want - 1)
+        {
+            pthread_t t;
+            pthread_attr_t at;
+            pthread_attr_init (&at);
+            pthread_attr_setdetachstate (&at, PTHREAD_CREATE_DETACHED);
+            if (pthread_create (&t, &at, pool_main, NULL))
+            {
+                pthread_attr_destroy (&at);
+                break;                  /* no thread to be had: the caller works through the strips itself */
+            }
+            pthread_attr_destroy (&at);
+            pool_threads++;
+        }
+        pool_call = &call;
+        pthread_cond_broadcast (&pool_work);
+        /* the caller takes strips too */
+        while (call.next < call.n_strips)
+        {
+            i = call.next++;
+            pthread_mutex_unlock (&pool_mtx);
+            call_run_strip (&call, i);
+            pthread_mutex_lock (&pool_mtx);
+            call.done++;
+        }
+        while (call.done < call.n_strips)
+            pthread_cond_wait (&pool_done, &pool_mtx);
+        pool_call = NULL;
+        pthread_mutex_unlock (&pool_mtx);
+        return call.rc;
+    }
 }

@@ -186,3 +186,41 @@ def test_cpu_plan_handle_row_batches_and_hand_built_jobs():
         setattr(bad, field, value)
         plan = ctypes.c_void_p()
         assert lib.smol_cpu_plan_create(ctypes.byref(bad), ctypes.byref(plan)) < 0, field
+
+
+def test_cpu_backend_cuts_a_large_call_into_strips_over_the_host_cores():
+    """Round 5: a call of enough rows runs as strips of output rows on a small persistent pool (SMOL_CPU_THREADS, default the
+    online cores; the reference's own harness cuts an image the same way: test.c:838-883). Byte-equal to the oracle for the
+    SIMD class and for generic classes with a vertical box and a bilinear halo; callers that come while the pool is busy run
+    on their own thread."""
+    import threading
+    import time
+    cases = [(0, 2048, 2048, 0, 512, 512, 0),          # the SIMD class (exact 4:1)
+             (1, 1500, 1200, 2, 1000, 777, 0),         # SIMD class, bilinear halo between strips
+             (8, 1600, 1400, 5, 150, 120, 0),          # box x box, 24-bit in, unassociated out
+             (4, 900, 700, 6, 1300, 1000, 1)]          # premul16 + sRGB magnification
+    for spec in cases:
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+        src = H.make_input(t_in, w_in, h_in, seed=3, valid=True, pad=16)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(cpu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb), want), spec
+        first, n = h_out // 5, h_out // 2 + 3
+        rb = w_out * H.bpp(t_out)
+        assert np.array_equal(cpu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, first=first, n=n), want[first * rb:(first + n) * rb]), spec
+    # several callers at once: one gets the pool, the others their own thread
+    t_in, w_in, h_in, t_out, w_out, h_out, srgb = cases[1]
+    src = H.make_input(t_in, w_in, h_in, seed=3, valid=True, pad=16)
+    want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+    bad = []
+
+    def worker():
+        for _ in range(3):
+            if not np.array_equal(cpu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb), want):
+                bad.append(1)
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad
