@@ -293,18 +293,49 @@ hrow_get (RowSource *rs, uint32_t r, const uint32_t *keep)
 
 #ifdef SMOL_CPU_X86
 
-/* horizontal: one source row of 32-bit pixels -> w_out pixels of four 16-bit lanes (memory byte order) */
-__attribute__ ((target ("avx2")))
-static void
-fast_hrow_avx2 (const Ctx *c, const uint8_t *src, uint16_t *out)
+/* one source pixel as a 32-bit word in memory byte order; 24-bit pixels get alpha = 255 as byte 3 */
+static inline __attribute__ ((always_inline)) uint32_t
+fast_px (const uint8_t *row, uint32_t o, const uint32_t bpp)
+{
+    uint32_t w;
+    uint16_t lo;
+    if (bpp == 4)
+    {
+        memcpy (&w, row + (size_t) o * 4, 4);
+        return w;
+    }
+    row += (size_t) o * 3;
+    memcpy (&lo, row, 2);
+    return (uint32_t) lo | ((uint32_t) row [2] << 16) | 0xff000000u;
+}
+
+/* horizontal: one source row of 3- or 4-byte pixels -> w_out pixels of four 16-bit lanes (memory byte order; a 24-bit
+ * pixel's fourth lane is 255). Unassociated pixels are premultiplied on the way in, as the reference's unpackers do
+ * (smolscale-generic.c:238-244, 415-464): ((c + 1) * (a + 1) - 1) >> 8 in 16-bit lanes -- (c + 1) * (a + 1) reaches 2^16
+ * only as 256 * 256, which wraps to 0, and the - 1 then gives 0xffff: the same value modulo 2^16. */
+__attribute__ ((target ("avx2"), always_inline))
+static inline void
+fast_hrow_body (const Ctx *c, const uint8_t *src, uint16_t *out, const uint32_t bpp, const int pm)
 {
     const SmolHipJob *j = c->job;
     const uint32_t w_out = j->width_out, h = j->halvings_h, ns = 1u << h;
-    const uint32_t *px = (const uint32_t *) src;        /* may be unaligned: loaded through memcpy below */
+    const uint32_t apos = c->ti->pos [3] & 3u;
     const uint32_t *ofs = c->h_ofs;
     const uint16_t *f = c->h_f;
     const __m128i shift = _mm_cvtsi32_si128 ((int) h);
-    uint32_t x = 0;
+    uint8_t bsel [32];
+    uint16_t amask [16];
+    __m256i v_bsel, v_amask;
+    const __m256i one = _mm256_set1_epi16 (1);
+    uint32_t x = 0, i;
+
+    /* per pixel (four 16-bit lanes = 8 bytes): every lane <- the alpha lane; and a mask that is all ones on alpha lanes */
+    for (i = 0; i < 32; i++)
+        bsel [i] = (uint8_t) ((i & 8u) + 2u * apos + (i & 1u));
+    for (i = 0; i < 16; i++)
+        amask [i] = (i & 3u) == apos ? 0xffffu : 0u;
+    v_bsel = _mm256_loadu_si256 ((const __m256i *) bsel);
+    v_amask = _mm256_loadu_si256 ((const __m256i *) amask);
 
     /* four output pixels per iteration: 16 lanes of 16 bits */
     for (; x + 4 <= w_out; x += 4, out += 16)
@@ -314,19 +345,28 @@ fast_hrow_avx2 (const Ctx *c, const uint8_t *src, uint16_t *out)
 
         for (s = 0; s < ns; s++)
         {
-            uint32_t p [4], q [4], i;
+            uint32_t p [4], q [4];
             uint64_t fw [4];
             __m256i vp, vq, vf, vg;
 
             for (i = 0; i < 4; i++)
             {
                 const uint32_t o = ofs [(x + i) * ns + s];
-                memcpy (&p [i], (const uint8_t *) px + (size_t) o * 4, 4);
-                memcpy (&q [i], (const uint8_t *) px + (size_t) o * 4 + 4, 4);
+                p [i] = fast_px (src, o, bpp);
+                q [i] = fast_px (src, o + 1, bpp);
                 fw [i] = (uint64_t) f [(x + i) * ns + s] * 0x0001000100010001ull;
             }
             vp = _mm256_cvtepu8_epi16 (_mm_loadu_si128 ((const __m128i *) p));
             vq = _mm256_cvtepu8_epi16 (_mm_loadu_si128 ((const __m128i *) q));
+            if (pm)
+            {
+                const __m256i mp = _mm256_add_epi16 (_mm256_shuffle_epi8 (vp, v_bsel), one);
+                const __m256i mq = _mm256_add_epi16 (_mm256_shuffle_epi8 (vq, v_bsel), one);
+                const __m256i rp = _mm256_srli_epi16 (_mm256_sub_epi16 (_mm256_mullo_epi16 (_mm256_add_epi16 (vp, one), mp), one), 8);
+                const __m256i rq = _mm256_srli_epi16 (_mm256_sub_epi16 (_mm256_mullo_epi16 (_mm256_add_epi16 (vq, one), mq), one), 8);
+                vp = _mm256_blendv_epi8 (rp, vp, v_amask);
+                vq = _mm256_blendv_epi8 (rq, vq, v_amask);
+            }
             vf = _mm256_loadu_si256 ((const __m256i *) fw);
             vg = _mm256_sub_epi16 (_mm256_set1_epi16 (256), vf);
             /* (p*F + q*(256-F)) >> 8 == q + (((p-q)*F) >> 8) for 8-bit lanes: at most 255*256, fits 16 bits */
@@ -340,14 +380,36 @@ fast_hrow_avx2 (const Ctx *c, const uint8_t *src, uint16_t *out)
         uint32_t acc [4] = { 0, 0, 0, 0 }, s, k;
         for (s = 0; s < ns; s++)
         {
-            const uint8_t *p = src + (size_t) ofs [x * ns + s] * 4;
+            const uint32_t o = ofs [x * ns + s];
+            const uint32_t wp = fast_px (src, o, bpp), wq = fast_px (src, o + 1, bpp);
             const uint32_t F = f [x * ns + s];
             for (k = 0; k < 4; k++)
-                acc [k] += lerp (p [k], p [4 + k], F, 0xffu);
+            {
+                uint32_t pv = (wp >> (8 * k)) & 0xffu, qv = (wq >> (8 * k)) & 0xffu;
+                if (pm && k != apos)
+                {
+                    pv = premul8 (pv, (wp >> (8 * apos)) & 0xffu);
+                    qv = premul8 (qv, (wq >> (8 * apos)) & 0xffu);
+                }
+                acc [k] += lerp (pv, qv, F, 0xffu);
+            }
         }
         for (k = 0; k < 4; k++)
             out [k] = (uint16_t) (acc [k] >> h);
     }
+}
+
+/* (one specialisation per source kind: the pixel fetch and the premultiply are compile-time choices in the loop) */
+__attribute__ ((target ("avx2")))
+static void
+fast_hrow_avx2 (const Ctx *c, const uint8_t *src, uint16_t *out)
+{
+    if (c->ti->bpp == 3)
+        fast_hrow_body (c, src, out, 3, 0);
+    else if (c->ti->unassoc)
+        fast_hrow_body (c, src, out, 4, 1);
+    else
+        fast_hrow_body (c, src, out, 4, 0);
 }
 
 /* vertical: acc += (top*F + bot*(256-F)) >> 8 over n 16-bit lanes */
@@ -397,39 +459,115 @@ fast_vblend_avx512 (const uint16_t *top, const uint16_t *bot, uint32_t F, uint16
     }
 }
 
-/* (acc >> hv) narrowed to bytes and permuted from input to output channel order */
-__attribute__ ((target ("avx2")))
-static void
-fast_pack_avx2 (const uint16_t *acc, uint32_t hv, const uint8_t perm [4], uint32_t n_px, uint8_t *dst)
+/* (acc >> hv) narrowed to bytes and permuted from input to output channel order. perm [k]: the input lane that holds
+ * output byte k's channel. Unassociated output: the colour lanes are un-premultiplied through the inverse table
+ * ((c * inv [a]) >> 13 & 0xff, smolscale-generic.c:227-236, 246-259) in 32-bit lanes, two pixels per vector. 24-bit
+ * output: four-byte pixels compressed to three with one byte shuffle per 128-bit half. */
+__attribute__ ((target ("avx2"), always_inline))
+static inline void
+fast_pack_body (const Ctx *c, const uint16_t *acc, uint32_t hv, const uint8_t perm [4], uint32_t n_px, uint8_t *dst,
+                const uint32_t bpp_out, const int unassoc)
 {
     const __m128i shift = _mm_cvtsi32_si128 ((int) hv);
+    /* the input lane that carries alpha (24-bit sources: the synthetic fourth lane) */
+    const uint32_t alane = c->ti->bpp == 4 ? (c->ti->pos [3] & 3u) : 3u;
     uint8_t sel [32];
     uint32_t i, k;
     __m256i vsel;
 
-    for (i = 0; i < 32; i++)
-        sel [i] = (uint8_t) ((i & ~3u) + perm [i & 3u]);
+    if (bpp_out == 4)
+        for (i = 0; i < 32; i++)
+            sel [i] = (uint8_t) ((i & ~3u) + perm [i & 3u]);
+    else
+        for (i = 0; i < 32; i++)
+        {
+            /* per 128-bit half: bytes 0 .. 11 <- the three colour bytes of its four pixels, the rest zero */
+            const uint32_t b = i & 15u;
+            sel [i] = b < 12u ? (uint8_t) (4u * (b / 3u) + perm [b % 3u]) : 0x80u;
+        }
     vsel = _mm256_loadu_si256 ((const __m256i *) sel);
-    for (i = 0; i + 8 <= n_px; i += 8)
+
+    i = 0;
+    /* (24-bit output: the second half's 16-byte store reaches 4 bytes past its 12; keep those inside the row) */
+    for (; i + 8 + (bpp_out == 3 ? 2u : 0u) <= n_px; i += 8)
     {
-        const __m256i a = _mm256_srl_epi16 (_mm256_loadu_si256 ((const __m256i *) (acc + (size_t) i * 4)), shift);
-        const __m256i b = _mm256_srl_epi16 (_mm256_loadu_si256 ((const __m256i *) (acc + (size_t) i * 4 + 16)), shift);
+        __m256i a = _mm256_srl_epi16 (_mm256_loadu_si256 ((const __m256i *) (acc + (size_t) i * 4)), shift);
+        __m256i b = _mm256_srl_epi16 (_mm256_loadu_si256 ((const __m256i *) (acc + (size_t) i * 4 + 16)), shift);
+        __m256i p;
+
+        if (unassoc)
+        {
+            /* 16 lanes of 16 bits = 4 pixels per vector -> 32-bit lanes, two pixels per vector */
+            __m256i v [4], r [4];
+            uint32_t u;
+            const __m256i amask32 = _mm256_cmpeq_epi32 (_mm256_and_si256 (_mm256_set_epi32 (7, 6, 5, 4, 3, 2, 1, 0), _mm256_set1_epi32 (3)),
+                                                        _mm256_set1_epi32 ((int) alane));
+            v [0] = _mm256_cvtepu16_epi32 (_mm256_castsi256_si128 (a));
+            v [1] = _mm256_cvtepu16_epi32 (_mm256_extracti128_si256 (a, 1));
+            v [2] = _mm256_cvtepu16_epi32 (_mm256_castsi256_si128 (b));
+            v [3] = _mm256_cvtepu16_epi32 (_mm256_extracti128_si256 (b, 1));
+            for (u = 0; u < 4; u++)
+            {
+                /* every lane of a pixel <- its alpha lane, then the table */
+                __m256i al;
+                switch (alane)
+                {
+                    case 0:  al = _mm256_shuffle_epi32 (v [u], 0x00); break;
+                    case 1:  al = _mm256_shuffle_epi32 (v [u], 0x55); break;
+                    case 2:  al = _mm256_shuffle_epi32 (v [u], 0xaa); break;
+                    default: al = _mm256_shuffle_epi32 (v [u], 0xff); break;
+                }
+                const __m256i inv = _mm256_i32gather_epi32 ((const int *) smol_inv_p8_lut, al, 4);
+                const __m256i un = _mm256_and_si256 (_mm256_srli_epi32 (_mm256_mullo_epi32 (v [u], inv), 13), _mm256_set1_epi32 (0xff));
+                r [u] = _mm256_blendv_epi8 (un, v [u], amask32);
+            }
+            /* back to 16-bit lanes in pixel order (packus works per 128-bit half) */
+            a = _mm256_permute4x64_epi64 (_mm256_packus_epi32 (r [0], r [1]), 0xd8);
+            b = _mm256_permute4x64_epi64 (_mm256_packus_epi32 (r [2], r [3]), 0xd8);
+        }
         /* packus works per 128-bit half: restore the order, then permute bytes inside each pixel */
-        __m256i p = _mm256_permute4x64_epi64 (_mm256_packus_epi16 (a, b), 0xd8);
+        p = _mm256_permute4x64_epi64 (_mm256_packus_epi16 (a, b), 0xd8);
         p = _mm256_shuffle_epi8 (p, vsel);
-        _mm256_storeu_si256 ((__m256i *) (dst + (size_t) i * 4), p);
+        if (bpp_out == 4)
+            _mm256_storeu_si256 ((__m256i *) (dst + (size_t) i * 4), p);
+        else
+        {
+            _mm_storeu_si128 ((__m128i *) (dst + (size_t) i * 3), _mm256_castsi256_si128 (p));
+            _mm_storeu_si128 ((__m128i *) (dst + (size_t) i * 3 + 12), _mm256_extracti128_si256 (p, 1));
+        }
     }
     for (; i < n_px; i++)
-        for (k = 0; k < 4; k++)
-            dst [(size_t) i * 4 + k] = (uint8_t) (acc [(size_t) i * 4 + perm [k]] >> hv);
+    {
+        const uint32_t a8 = (uint32_t) (acc [(size_t) i * 4 + alane] >> hv);
+        for (k = 0; k < bpp_out; k++)
+        {
+            uint32_t v = (uint32_t) (acc [(size_t) i * 4 + perm [k]] >> hv);
+            if (unassoc && perm [k] != alane)
+                v = unpremul8 (v, a8);
+            dst [(size_t) i * bpp_out + k] = (uint8_t) v;
+        }
+    }
+}
+
+__attribute__ ((target ("avx2")))
+static void
+fast_pack_avx2 (const Ctx *c, const uint16_t *acc, uint32_t hv, const uint8_t perm [4], uint32_t n_px, uint8_t *dst)
+{
+    if (c->to->bpp == 3)
+        fast_pack_body (c, acc, hv, perm, n_px, dst, 3, 0);
+    else if (c->to->unassoc)
+        fast_pack_body (c, acc, hv, perm, n_px, dst, 4, 1);
+    else
+        fast_pack_body (c, acc, hv, perm, n_px, dst, 4, 0);
 }
 
 static int
 fast_class_ok (const Ctx *c)
 {
     const SmolHipJob *j = c->job;
-    return !c->wide && c->ti->bpp == 4 && c->to->bpp == 4 && !c->ti->unassoc && !c->to->unassoc
-           && j->filter_h == F_BILINEAR && j->filter_v == F_BILINEAR && __builtin_cpu_supports ("avx2");
+    /* the whole 64bpp class with a bilinear filter on both axes: 3- and 4-byte pixels, either alpha convention on either
+     * side (round 5; rounds 3-4: 32-bit premultiplied in and out only) */
+    return !c->wide && j->filter_h == F_BILINEAR && j->filter_v == F_BILINEAR && __builtin_cpu_supports ("avx2");
 }
 
 static int
@@ -450,13 +588,14 @@ fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
     for (k = 0; k < 3; k++)
         hbuf [k] = (uint16_t *) mem + lanes * k;
     acc = (uint16_t *) mem + lanes * 3;
-    /* output byte k comes from the input byte that holds the same channel */
+    /* output byte k comes from the input lane that holds the same channel (a 24-bit source's alpha: the synthetic lane 3) */
     for (k = 0; k < 4; k++)
     {
         uint32_t ch;
+        perm [k] = 3;
         for (ch = 0; ch < 4; ch++)
             if (c->to->pos [ch] == k)
-                perm [k] = c->ti->pos [ch];
+                perm [k] = (uint8_t) ((ch == 3 && c->ti->bpp == 3) ? 3u : c->ti->pos [ch]);
     }
 
     for (y = first_row; y < first_row + n_rows; y++, dest += stride_out)
@@ -491,7 +630,7 @@ fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
             else
                 fast_vblend_avx2 (rows [0], rows [1], F, acc, s == 0, lanes);
         }
-        fast_pack_avx2 (acc, hv, perm, w_out, dest);
+        fast_pack_avx2 (c, acc, hv, perm, w_out, dest);
     }
     free (mem);
     return 0;

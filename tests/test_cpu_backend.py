@@ -72,21 +72,30 @@ def test_cpu_backend_random_sweep_vs_oracle():
 
 
 def test_cpu_fast_class_every_channel_order_and_misalignment():
-    """The AVX2 / AVX-512 path (32-bit premultiplied in and out, bilinear on both axes): all 16 order pairs,
-    0-2 halvings per axis, magnification, widths that are not multiples of the vector width, byte-misaligned
-    rows."""
+    """The AVX2 / AVX-512 path (the 64bpp class with a bilinear filter on both axes: 3- and 4-byte pixels, either alpha
+    convention on either side): all 100 type pairs (the pairs the planner sends to the 128bpp class run the generic path and are
+    checked all the same), 0-2 halvings per axis, magnification, widths that are not multiples of the vector width,
+    byte-misaligned rows, padded destination rows whose padding must stay untouched (24-bit rows are stored with 16-byte
+    stores that overlap the next pixels)."""
     rng = random.Random(7)
-    for t_in in range(4):
-        for t_out in range(4):
+    for t_in in range(10):
+        for t_out in range(10):
             for (w_in, h_in, w_out, h_out) in ((64, 48, 32, 24), (203, 101, 51, 26), (333, 90, 47, 13), (40, 30, 97, 71), (77, 50, 50, 49)):
-                sin = w_in * 4 + rng.choice([0, 1, 3])
-                raw = H.make_input(t_in, w_in, h_in, seed=rng.randrange(1000), valid=True, stride=sin, pad=32)
+                bi, bo = H.bpp(t_in), H.bpp(t_out)
+                sin = w_in * bi + rng.choice([0, 1, 3])
+                sout = w_out * bo + rng.choice([0, 0, 5, 16])
+                raw = H.make_input(t_in, w_in, h_in, seed=rng.randrange(1000), valid=bool(rng.getrandbits(1)), stride=sin, pad=32)
                 mis = rng.choice([0, 1, 2])
                 buf = np.zeros(raw.size + 8, np.uint8)
                 buf[mis:mis + raw.size] = raw
-                a = cpu_scale(buf[mis:], t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
-                b = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin)
-                assert np.array_equal(a, b), (t_in, t_out, w_in, h_in, w_out, h_out)
+                a = cpu_scale(buf[mis:], t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                b = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                rb = w_out * bo
+                assert np.array_equal(H.rows_view(a, h_out, rb, sout), H.rows_view(b, h_out, rb, sout)), \
+                    (t_in, t_out, w_in, h_in, w_out, h_out)
+                if sout > rb:
+                    gaps = np.lib.stride_tricks.as_strided(a[rb:], (h_out - 1, sout - rb), (sout, 1))
+                    assert np.all(gaps == 0xA5), (t_in, t_out, w_out)
 
 
 def test_cpu_backend_strips_and_threads():
