@@ -31,6 +31,11 @@
 #if defined (__x86_64__)
 #include <immintrin.h>
 #define SMOL_CPU_X86 1
+/* the generic (32-bit-lane) row functions are compiled twice, the loader picks the AVX2 copy where the CPU has it: their
+ * loops are plain arithmetic over lanes that the compiler vectorises itself */
+#define SMOL_CPU_CLONES __attribute__ ((target_clones ("avx2", "default")))
+#else
+#define SMOL_CPU_CLONES
 #endif
 
 #include "smol_hip.h"
@@ -106,6 +111,7 @@ box_span (uint64_t step, uint32_t dim_in, uint32_t k, uint32_t *o0, uint32_t *o1
 
 /* ---- unpack one row: memory pixels -> four 32-bit lanes (R, G, B, alpha lane) -------------------- */
 
+SMOL_CPU_CLONES
 static void
 unpack_row (const Ctx *c, const uint8_t *src, uint32_t n, uint32_t *out)
 {
@@ -152,6 +158,7 @@ unpack_row (const Ctx *c, const uint8_t *src, uint32_t n, uint32_t *out)
 
 /* ---- pack one row ---------------------------------------------------------------------------- */
 
+SMOL_CPU_CLONES
 static void
 pack_row (const Ctx *c, const uint32_t *in, uint32_t n, uint8_t *dst)
 {
@@ -199,6 +206,7 @@ pack_row (const Ctx *c, const uint32_t *in, uint32_t n, uint8_t *dst)
 
 /* ---- horizontal filter of one unpacked row ------------------------------------------------------ */
 
+SMOL_CPU_CLONES
 static void
 hfilter_row (const Ctx *c, const uint32_t *u, uint32_t *out)
 {
@@ -561,13 +569,209 @@ fast_pack_avx2 (const Ctx *c, const uint16_t *acc, uint32_t hv, const uint8_t pe
         fast_pack_body (c, acc, hv, perm, n_px, dst, 4, 0);
 }
 
+/* ---- box filters of the fast class (round 5) ---------------------------------------------------------
+ * A pixel is four 16-bit lanes in one 64-bit word, the reference's own 64bpp storage (smolscale-private.h:
+ * 64bpp = 4 x 16 bits): adding a pixel to a box is one 64-bit add, an edge weight one multiply + mask
+ * (lanes are <= 255 and weights <= 256, so no product leaves its lane). The planner keeps the class to spans of at
+ * most 255 pixels (smol_plan.c plan_axis; smolscale.c:443-478), so lane sums stay below 2^16 and no carry crosses
+ * lanes either; fast_class_ok () sends a hand-built job with a longer span down the generic road. */
+
+/* source row -> w_in pixels of four 16-bit lanes (memory byte order; premultiplied if the source is unassociated) */
+__attribute__ ((target ("avx2"), always_inline))
+static inline void
+fast_unpack_body (const Ctx *c, const uint8_t *src, uint64_t *out, const uint32_t bpp, const int pm)
+{
+    const uint32_t n = c->job->width_in;
+    const uint32_t apos = c->ti->pos [3] & 3u;
+    const __m256i one = _mm256_set1_epi16 (1);
+    const __m128i sel24 = _mm_setr_epi8 (0, 1, 2, -128, 3, 4, 5, -128, 6, 7, 8, -128, 9, 10, 11, -128);
+    const __m128i alpha24 = _mm_set1_epi32 ((int) 0xff000000u);
+    uint8_t bsel [32];
+    uint16_t amask [16];
+    __m256i v_bsel, v_amask;
+    uint32_t i, k;
+
+    for (i = 0; i < 32; i++)
+        bsel [i] = (uint8_t) ((i & 8u) + 2u * apos + (i & 1u));
+    for (i = 0; i < 16; i++)
+        amask [i] = (i & 3u) == apos ? 0xffffu : 0u;
+    v_bsel = _mm256_loadu_si256 ((const __m256i *) bsel);
+    v_amask = _mm256_loadu_si256 ((const __m256i *) amask);
+
+    /* (24-bit rows: the 16-byte load of four pixels reaches 4 bytes past them; keep those inside the row) */
+    for (i = 0; i + 4 + (bpp == 3 ? 2u : 0u) <= n; i += 4)
+    {
+        __m128i raw = _mm_loadu_si128 ((const __m128i *) (src + (size_t) i * bpp));
+        __m256i v;
+
+        if (bpp == 3)
+            raw = _mm_or_si128 (_mm_shuffle_epi8 (raw, sel24), alpha24);
+        v = _mm256_cvtepu8_epi16 (raw);
+        if (pm)
+        {
+            const __m256i m = _mm256_add_epi16 (_mm256_shuffle_epi8 (v, v_bsel), one);
+            const __m256i r = _mm256_srli_epi16 (_mm256_sub_epi16 (_mm256_mullo_epi16 (_mm256_add_epi16 (v, one), m), one), 8);
+            v = _mm256_blendv_epi8 (r, v, v_amask);
+        }
+        _mm256_storeu_si256 ((__m256i *) (out + i), v);
+    }
+    for (; i < n; i++)
+    {
+        const uint32_t w = fast_px (src, i, bpp), a = (w >> (8 * apos)) & 0xffu;
+        uint64_t v = 0;
+        for (k = 0; k < 4; k++)
+        {
+            uint32_t ch = (w >> (8 * k)) & 0xffu;
+            if (pm && k != apos)
+                ch = premul8 (ch, a);
+            v |= (uint64_t) ch << (16 * k);
+        }
+        out [i] = v;
+    }
+}
+
+__attribute__ ((target ("avx2")))
+static void
+fast_unpack_avx2 (const Ctx *c, const uint8_t *src, uint64_t *out)
+{
+    if (c->ti->bpp == 3)
+        fast_unpack_body (c, src, out, 3, 0);
+    else if (c->ti->unassoc)
+        fast_unpack_body (c, src, out, 4, 1);
+    else
+        fast_unpack_body (c, src, out, 4, 0);
+}
+
+/* box_scale () of n 16-bit lanes: (acc * mul + 2^23) >> 24 & 0xff, exact for any 32-bit mul (64-bit products) */
+__attribute__ ((target ("avx2")))
+static void
+fast_box_scale_avx2 (const uint16_t *acc, uint32_t mul, uint16_t *out, size_t n)
+{
+    const __m256i vm = _mm256_set1_epi64x ((long long) mul), half = _mm256_set1_epi64x (1ll << 23);
+    const __m256i ff = _mm256_set1_epi64x (0xff);
+    size_t i = 0;
+
+    for (; i + 16 <= n; i += 16)
+    {
+        const __m256i a = _mm256_loadu_si256 ((const __m256i *) (acc + i));
+        __m256i w [2];
+        int u;
+
+        w [0] = _mm256_cvtepu16_epi32 (_mm256_castsi256_si128 (a));
+        w [1] = _mm256_cvtepu16_epi32 (_mm256_extracti128_si256 (a, 1));
+        for (u = 0; u < 2; u++)
+        {
+            const __m256i ev = _mm256_and_si256 (_mm256_srli_epi64 (_mm256_add_epi64 (_mm256_mul_epu32 (w [u], vm), half), 24), ff);
+            const __m256i od = _mm256_and_si256 (_mm256_srli_epi64 (_mm256_add_epi64 (_mm256_mul_epu32 (_mm256_srli_epi64 (w [u], 32), vm), half), 24), ff);
+            w [u] = _mm256_or_si256 (ev, _mm256_slli_epi64 (od, 32));
+        }
+        _mm256_storeu_si256 ((__m256i *) (out + i), _mm256_permute4x64_epi64 (_mm256_packus_epi32 (w [0], w [1]), 0xd8));
+    }
+    for (; i < n; i++)
+        out [i] = (uint16_t) ((((uint64_t) acc [i] * mul + (1u << 23)) >> 24) & 0xffu);
+}
+
+/* horizontal box of one source row: `urow' = width_in words of scratch, `sums' = width_out words of scratch */
+__attribute__ ((target ("avx2")))
+static void
+fast_hbox_avx2 (const Ctx *c, const uint8_t *src, uint64_t *urow, uint64_t *sums, uint16_t *out)
+{
+    const SmolHipJob *j = c->job;
+    const uint32_t w_out = j->width_out;
+    const uint64_t M = 0x00ff00ff00ff00ffull;
+    uint32_t x;
+
+    fast_unpack_avx2 (c, src, urow);
+    for (x = 0; x < w_out; x++)
+    {
+        const uint32_t o0 = c->h_ofs [x], o1 = c->h_last [x];
+        uint64_t acc = ((urow [o0] * c->h_wl [x]) >> 8) & M;
+        uint32_t s;
+
+        if (o1 > o0)
+        {
+            uint64_t a2 = 0;
+            for (s = o0 + 1; s + 1 < o1; s += 2)
+            {
+                acc += urow [s];
+                a2 += urow [s + 1];
+            }
+            if (s < o1)
+                acc += urow [s];
+            acc += a2 + (((urow [o1] * c->h_fr [x]) >> 8) & M);
+        }
+        sums [x] = acc;
+    }
+    fast_box_scale_avx2 ((const uint16_t *) sums, j->span_mul_x, out, (size_t) w_out * 4);
+}
+
+/* vertical box: acc (+)= (row * w) >> 8 over n 16-bit lanes (w = 256: the row itself) */
+__attribute__ ((target ("avx2")))
+static void
+fast_vbox_add_avx2 (const uint16_t *row, uint32_t w, uint16_t *acc, int first, size_t n)
+{
+    const __m256i vw = _mm256_set1_epi16 ((short) w);
+    size_t i = 0;
+
+    for (; i + 16 <= n; i += 16)
+    {
+        __m256i v = _mm256_loadu_si256 ((const __m256i *) (row + i));
+        if (w != 256u)
+            v = _mm256_srli_epi16 (_mm256_mullo_epi16 (v, vw), 8);
+        if (!first)
+            v = _mm256_add_epi16 (v, _mm256_loadu_si256 ((const __m256i *) (acc + i)));
+        _mm256_storeu_si256 ((__m256i *) (acc + i), v);
+    }
+    for (; i < n; i++)
+    {
+        const uint16_t v = (uint16_t) ((row [i] * w) >> 8);
+        acc [i] = first ? v : (uint16_t) (acc [i] + v);
+    }
+}
+
 static int
 fast_class_ok (const Ctx *c)
 {
     const SmolHipJob *j = c->job;
-    /* the whole 64bpp class with a bilinear filter on both axes: 3- and 4-byte pixels, either alpha convention on either
-     * side (round 5; rounds 3-4: 32-bit premultiplied in and out only) */
-    return !c->wide && j->filter_h == F_BILINEAR && j->filter_v == F_BILINEAR && __builtin_cpu_supports ("avx2");
+    /* the whole 64bpp class with a bilinear or a box filter on either axis: 3- and 4-byte pixels, either alpha convention
+     * on either side (round 5; rounds 3-4: 32-bit premultiplied in and out, bilinear on both axes only) */
+    if (c->wide || !__builtin_cpu_supports ("avx2"))
+        return 0;
+    if (j->filter_h != F_BILINEAR && !(j->filter_h == F_BOX && j->step_x <= (255u << 16)))
+        return 0;
+    return j->filter_v == F_BILINEAR || (j->filter_v == F_BOX && j->step_y <= (255u << 16));
+}
+
+typedef struct
+{
+    const Ctx *c;
+    const uint8_t *src;
+    uint32_t stride;
+    uint16_t *hbuf [3];                 /* cache of horizontally filtered rows (four 16-bit lanes per pixel) */
+    uint32_t tag [3], next;
+    uint64_t *urow, *sums;              /* box rows: the unpacked source row, the box sums                   */
+}
+FastRows;
+
+/* `keep': a row handed out a moment ago that must stay valid (NULL: none) */
+static const uint16_t *
+fast_row_get (FastRows *fr, uint32_t r, const uint16_t *keep)
+{
+    uint32_t i, slot;
+
+    for (i = 0; i < 3; i++)
+        if (fr->tag [i] == r)
+            return fr->hbuf [i];
+    slot = fr->next;
+    if (fr->hbuf [slot] == keep)
+        slot = (slot + 1) % 3;
+    fr->next = (slot + 1) % 3;
+    if (fr->c->job->filter_h == F_BOX)
+        fast_hbox_avx2 (fr->c, fr->src + (size_t) r * fr->stride, fr->urow, fr->sums, fr->hbuf [slot]);
+    else
+        fast_hrow_avx2 (fr->c, fr->src + (size_t) r * fr->stride, fr->hbuf [slot]);
+    fr->tag [slot] = r;
+    return fr->hbuf [slot];
 }
 
 static int
@@ -577,17 +781,26 @@ fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
     const SmolHipJob *j = c->job;
     const uint32_t w_out = j->width_out, hv = j->halvings_v, nsy = 1u << hv;
     const size_t lanes = (size_t) w_out * 4;
+    const size_t box_words = j->filter_h == F_BOX ? (size_t) j->width_in + w_out : 0;
     const int use512 = __builtin_cpu_supports ("avx512bw");
-    uint16_t *hbuf [3], *acc;
-    uint32_t tag [3] = { UINT32_MAX, UINT32_MAX, UINT32_MAX }, next = 0, y, k;
+    FastRows fr;
+    uint16_t *acc, *vout;
+    uint32_t y, k;
     uint8_t perm [4];
-    uint8_t *mem = malloc ((lanes * 4 + 64) * sizeof (uint16_t));
+    uint8_t *mem = malloc (box_words * sizeof (uint64_t) + (lanes * 5 + 64) * sizeof (uint16_t));
 
     if (!mem)
         return SMOL_HIP_E_INVALID;
+    fr.c = c; fr.src = src; fr.stride = stride_in; fr.next = 0;
+    fr.urow = (uint64_t *) mem;
+    fr.sums = fr.urow + j->width_in;
     for (k = 0; k < 3; k++)
-        hbuf [k] = (uint16_t *) mem + lanes * k;
-    acc = (uint16_t *) mem + lanes * 3;
+    {
+        fr.hbuf [k] = (uint16_t *) (mem + box_words * sizeof (uint64_t)) + lanes * k;
+        fr.tag [k] = UINT32_MAX;
+    }
+    acc = fr.hbuf [0] + lanes * 3;
+    vout = acc + lanes;
     /* output byte k comes from the input lane that holds the same channel (a 24-bit source's alpha: the synthetic lane 3) */
     for (k = 0; k < 4; k++)
     {
@@ -600,35 +813,30 @@ fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
 
     for (y = first_row; y < first_row + n_rows; y++, dest += stride_out)
     {
-        uint32_t s;
-        for (s = 0; s < nsy; s++)
+        if (j->filter_v == F_BOX)
         {
-            const uint16_t *rows [2];
-            uint32_t oy, F, t;
+            /* 64bpp-class rows: the last row's weight is the fraction as it is (smolscale-generic.c:2042-2069) */
+            uint32_t y0, y1, w2, w1, r;
+
+            box_span (j->step_y, j->height_in, y, &y0, &y1, &w2, &w1);
+            for (r = y0; r <= y1; r++)
+                fast_vbox_add_avx2 (fast_row_get (&fr, r, NULL), r == y0 ? w1 : r == y1 ? w2 : 256u, acc, r == y0, lanes);
+            fast_box_scale_avx2 (acc, j->span_mul_y, vout, lanes);
+            fast_pack_avx2 (c, vout, 0, perm, w_out, dest);
+            continue;
+        }
+        for (uint32_t s = 0; s < nsy; s++)
+        {
+            const uint16_t *top, *bot;
+            uint32_t oy, F;
 
             bilin_tap (j->frac0_y + (uint64_t) ((y << hv) + s) * j->step_y, j->height_in, &oy, &F);
-            for (t = 0; t < 2; t++)
-            {
-                uint32_t i, r = oy + t, slot = 3;
-                for (i = 0; i < 3; i++)
-                    if (tag [i] == r)
-                        slot = i;
-                if (slot == 3)
-                {
-                    /* never evict the row fetched a moment ago for this same sample */
-                    slot = next;
-                    if (t == 1 && rows [0] == hbuf [slot])
-                        slot = (slot + 1) % 3;
-                    next = (slot + 1) % 3;
-                    fast_hrow_avx2 (c, src + (size_t) r * stride_in, hbuf [slot]);
-                    tag [slot] = r;
-                }
-                rows [t] = hbuf [slot];
-            }
+            top = fast_row_get (&fr, oy, NULL);
+            bot = fast_row_get (&fr, oy + 1, top);
             if (use512)
-                fast_vblend_avx512 (rows [0], rows [1], F, acc, s == 0, lanes);
+                fast_vblend_avx512 (top, bot, F, acc, s == 0, lanes);
             else
-                fast_vblend_avx2 (rows [0], rows [1], F, acc, s == 0, lanes);
+                fast_vblend_avx2 (top, bot, F, acc, s == 0, lanes);
         }
         fast_pack_avx2 (c, acc, hv, perm, w_out, dest);
     }
@@ -779,6 +987,7 @@ smol_cpu_scale_rows (const SmolHipJob *job,
 }
 
 /* one strip of output rows on the calling thread (the plan is immutable: any number of strips may run at once) */
+SMOL_CPU_CLONES
 static int
 strip_scale_rows (const SmolCpuPlan *plan,
                   const void *pixels_in, uint32_t rowstride_in,

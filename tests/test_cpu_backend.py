@@ -73,14 +73,15 @@ def test_cpu_backend_random_sweep_vs_oracle():
 
 def test_cpu_fast_class_every_channel_order_and_misalignment():
     """The AVX2 / AVX-512 path (the 64bpp class with a bilinear filter on both axes: 3- and 4-byte pixels, either alpha
-    convention on either side): all 100 type pairs (the pairs the planner sends to the 128bpp class run the generic path and are
+    convention on either side; bilinear or box on either axis): all 100 type pairs (the pairs the planner sends to the 128bpp class run the generic path and are
     checked all the same), 0-2 halvings per axis, magnification, widths that are not multiples of the vector width,
     byte-misaligned rows, padded destination rows whose padding must stay untouched (24-bit rows are stored with 16-byte
     stores that overlap the next pixels)."""
     rng = random.Random(7)
     for t_in in range(10):
         for t_out in range(10):
-            for (w_in, h_in, w_out, h_out) in ((64, 48, 32, 24), (203, 101, 51, 26), (333, 90, 47, 13), (40, 30, 97, 71), (77, 50, 50, 49)):
+            for (w_in, h_in, w_out, h_out) in ((64, 48, 32, 24), (203, 101, 51, 26), (333, 90, 47, 13), (40, 30, 97, 71), (77, 50, 50, 49),
+                                               (400, 300, 40, 30), (333, 200, 13, 7), (400, 60, 41, 40), (60, 400, 40, 39), (2000, 9, 8, 1)):
                 bi, bo = H.bpp(t_in), H.bpp(t_out)
                 sin = w_in * bi + rng.choice([0, 1, 3])
                 sout = w_out * bo + rng.choice([0, 0, 5, 16])
