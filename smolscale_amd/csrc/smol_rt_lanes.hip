@@ -42,6 +42,8 @@ constexpr size_t BOUNCE_MIN = 64u << 10;
  *                            over PCIe -- no DMA, one launch, one wait (default 256 KiB; 0 = off)
  *   SMOL_HIP_ZEROCOPY_PAGEABLE_KB  the same bound for calls whose memory is pageable on both sides and has to pass
  *                            through the ring anyway (default 8192 KiB, at most one ring slot)
+ *   SMOL_HIP_MAPPED=0        larger calls take the DMA road of rounds 1-4 instead of the mapped road (strip_issue_locked)
+ *   SMOL_HIP_MAPPED_CHUNK_KB mapped road, pageable memory: bytes a chunk moves, about (default 4096 KiB, at most one ring slot)
  *   SMOL_HIP_LINK_LANES, SMOL_HIP_STREAM_STORES, SMOL_HIP_COPY_THREADS (smol_rt_pool.hip): see where they are used */
 struct Knobs
 {
@@ -50,6 +52,9 @@ struct Knobs
     size_t slot_bytes = 8u << 20;
     size_t zero_copy_bytes = 256u << 10;
     size_t zero_copy_pageable_bytes = 8u << 20;
+    bool mapped = true;                 /* SMOL_HIP_MAPPED=0: the DMA road of rounds 1-4 for calls above the zero-copy bounds */
+    size_t mapped_chunk_bytes = 4u << 20;
+    bool mapped_chunk_set = false;
     bool stream_stores = true;          /* SMOL_HIP_STREAM_STORES=0: fill the upload ring with ordinary stores */
     int link_lanes = 1;                 /* SMOL_HIP_LINK_LANES: lanes (of N_LANES) that strips of the DMA road may use */
 
@@ -79,6 +84,17 @@ struct Knobs
             const long v = strtol (e, nullptr, 10);
             if (v >= 0 && v <= (1 << 20))
                 zero_copy_pageable_bytes = (size_t) v << 10;
+        }
+        if ((e = getenv ("SMOL_HIP_MAPPED")) && *e == '0')
+            mapped = false;
+        if ((e = getenv ("SMOL_HIP_MAPPED_CHUNK_KB")) && *e)
+        {
+            const long v = strtol (e, nullptr, 10);
+            if (v >= 64 && v <= (1 << 20))
+            {
+                mapped_chunk_bytes = (size_t) v << 10;
+                mapped_chunk_set = true;
+            }
         }
         if ((e = getenv ("SMOL_HIP_ZEROCOPY_KB")) && *e)
         {
@@ -619,6 +635,27 @@ strip_issue_locked (Strip &st, Lane &ln)
     const bool bounce_out = knobs ().bounce && !small
                             && !host_range_is_pinned (st.dest, (size_t) (st.n - 1) * st.rowstride_out + out_row_bytes);
 
+    /* The mapped road (round 5): no DMA engine at all. The kernel reads its source rows from, and writes its output
+     * rows to, page-locked HOST memory across PCIe -- the caller's own rows where they are page-locked (the runtime maps
+     * such memory into the device's address space; the kernels take any pitch and alignment), a ring slot the copy pool
+     * fills / empties where they are pageable. Reads and writes then share the link inside one kernel instead of
+     * queueing as an upload, a kernel and a download: 3-27 % less time per whole-image call in every job class
+     * (1080p -> 720p 0.251 -> 0.184 ms, 4096^2 -> 1024^2 1.40 -> 1.29 ms page-locked; profiles/r05_mapped_road.txt),
+     * and a 64-row call costs one launch and one wait. SMOL_HIP_MAPPED=0 brings the DMA road back. */
+    void *map_src = nullptr, *map_dst = nullptr;
+    bool mapped = knobs ().bounce && knobs ().mapped && !peer && !small;
+    if (mapped && !bounce_in
+        && (hipHostGetDevicePointer (&map_src, const_cast<uint8_t *> (src_first), 0) != hipSuccess || !map_src))
+    {
+        (void) hipGetLastError ();      /* (page-locked but not mapped: the DMA road) */
+        mapped = false;
+    }
+    if (mapped && !bounce_out && (hipHostGetDevicePointer (&map_dst, st.dest, 0) != hipSuccess || !map_dst))
+    {
+        (void) hipGetLastError ();
+        mapped = false;
+    }
+
     /* How rows lie in the device slabs.
      * Direct road: rows that are (nearly) back to back on the host travel as ONE linear copy per chunk and keep
      * the caller's stride and 16-byte phase on the device -- a linear DMA runs at the full link rate, a 2-D copy
@@ -653,6 +690,16 @@ strip_issue_locked (Strip &st, Lane &ln)
         dst_pitch = lin_out ? out_row_bytes : align_up (out_row_bytes, 16);
         dst_skew = lin_out ? ((uintptr_t) st.dest & 15u) : 0;
     }
+    if (mapped && !bounce_in)
+    {
+        src_pitch = st.rowstride_in;
+        src_skew = 0;
+    }
+    if (mapped && !bounce_out)
+    {
+        dst_pitch = st.rowstride_out;
+        dst_skew = 0;
+    }
     if (src_pitch > 0xffffffffu || dst_pitch > 0xffffffffu)
         return SMOL_HIP_E_INVALID;
 
@@ -665,9 +712,51 @@ strip_issue_locked (Strip &st, Lane &ln)
     /* ... and so does a larger call whose memory has to pass through the ring on both sides anyway, as long as
      * it fits one slot: no DMA submissions, no events (1080p -> 720p, 64 rows per call: 54 against 105 us;
      * 4096 -> 1024, 8 rows: 38 against 71 us; profiles/r04_host_path.txt) */
+    /* mapped road: chunks of output rows whose ring side(s) fit a slot; page-locked on both sides: one launch */
+    uint32_t map_rows = st.n;           /* output rows per chunk */
+    size_t map_in_max = 0, map_out_max = 0;
+    if (mapped && (bounce_in || bounce_out))
+    {
+        const size_t per_row = (n_in_rows * in_row_bytes + (size_t) st.n * out_row_bytes) / st.n + 1;
+        const size_t slot_max = knobs ().slot_bytes;
+        /* box filters run as two kernels per chunk, or as tiles that want many rows: whole slots (4000 x 3000 -> 400 x 300:
+         * 1.24 against 1.20 ms); everything else 4 MB (4096^2 -> 1024^2: 1.41 against 1.44 ms) */
+        const bool boxy = job.filter_h == SMOL_HIP_FILTER_BOX || job.filter_v == SMOL_HIP_FILTER_BOX;
+        const size_t chunk = boxy && !knobs ().mapped_chunk_set ? slot_max : knobs ().mapped_chunk_bytes;
+        const size_t want = chunk < slot_max ? chunk : slot_max;
+        uint64_t rows = want / per_row;
+        map_rows = rows < 1 ? 1u : rows > st.n ? st.n : (uint32_t) rows;
+        for (;;)
+        {
+            map_in_max = map_out_max = 0;
+            for (uint32_t y = 0; y < st.n && mapped; y += map_rows)
+            {
+                const uint32_t rows_here = st.n - y < map_rows ? st.n - y : map_rows;
+                uint32_t a = 0, b = 0;
+                if (smol_hip_input_row_range (&job, st.first + y, rows_here, &a, &b))
+                    mapped = false;
+                else
+                {
+                    const size_t in_b = bounce_in ? ((size_t) b - a + 1) * src_pitch : 0;
+                    const size_t out_b = bounce_out ? (size_t) rows_here * dst_pitch : 0;
+                    if (in_b > map_in_max) map_in_max = in_b;
+                    if (out_b > map_out_max) map_out_max = out_b;
+                }
+            }
+            if (!mapped || (map_in_max <= slot_max && map_out_max <= slot_max))
+                break;
+            if (map_rows == 1)
+            {
+                mapped = false;         /* (one output row reads more than a slot holds: the DMA road) */
+                break;
+            }
+            map_rows = (map_rows + 1) / 2;
+        }
+    }
+
     const size_t zc_pageable = knobs ().zero_copy_pageable_bytes < knobs ().slot_bytes ? knobs ().zero_copy_pageable_bytes
                                                                                          : knobs ().slot_bytes;
-    const bool zero_copy = small || (bounce_in && bounce_out && src_bytes <= zc_pageable && dst_bytes <= zc_pageable
+    const bool zero_copy = small || (!mapped && bounce_in && bounce_out && src_bytes <= zc_pageable && dst_bytes <= zc_pageable
                                      && src_bytes + dst_bytes <= zc_pageable);
 
     /* the two-pass box filter keeps its intermediate image in the lane */
@@ -678,14 +767,103 @@ strip_issue_locked (Strip &st, Lane &ln)
     const StripClass sc = strip_classify (job, (uint32_t) src_pitch, (uint32_t) dst_pitch, st.first, st.n);
     const size_t tmp_need = sc.tmp_bytes ? sc.tmp_bytes + 64 : 0;
     const uint8_t box_force = sc.box_force;
-    rc = lane_prepare (ln, zero_copy ? 0 : src_bytes + 64 + 16, zero_copy ? 0 : dst_bytes + 64 + 16, tmp_need);
+    rc = lane_prepare (ln, zero_copy || mapped ? 0 : src_bytes + 64 + 16, zero_copy || mapped ? 0 : dst_bytes + 64 + 16, tmp_need);
     if (!rc && (bounce_in || zero_copy))
-        rc = ring_prepare (ln.in, src_bytes, src_pitch);
+        rc = ring_prepare (ln.in, mapped ? map_in_max : src_bytes, src_pitch);
     if (!rc && (bounce_out || zero_copy))
-        rc = ring_prepare (ln.out, dst_bytes, dst_pitch);
+        rc = ring_prepare (ln.out, mapped ? map_out_max : dst_bytes, dst_pitch);
     if (rc)
         return rc;
     ln.s_last = ln.s_k;
+
+    if (mapped)
+    {
+        const uint32_t S = BOUNCE_SLOTS;
+        const uint32_t n_chunks = (st.n + map_rows - 1) / map_rows;
+        uint32_t retired = 0;
+        hipError_t e = hipSuccess;
+
+        auto rows_of = [&] (uint32_t i) { return st.n - i * map_rows < map_rows ? st.n - i * map_rows : map_rows; };
+        /* wait for chunk i's kernel; pageable destination: its rows leave the ring */
+        auto retire = [&] (uint32_t i) -> hipError_t
+        {
+            auto t = tick ();
+            /* (a strip of one chunk waits for its stream: cheaper than an event by 4 us, which a 64-row call notices) */
+            const hipError_t r = n_chunks == 1 ? hipStreamSynchronize (ln.s_k) : hipEventSynchronize (ln.ev_k [i % S]);
+            ln.tm.wait += since (t);
+            if (r != hipSuccess || !bounce_out)
+                return r;
+            t = tick ();
+            copy_rows (RowCopy { st.dest + (size_t) i * map_rows * st.rowstride_out, st.rowstride_out, ln.out.buf (i % S), dst_pitch,
+                                 out_row_bytes, rows_of (i), false });
+            ln.tm.copy_out += since (t);
+            ln.tm.pieces_out++;
+            return hipSuccess;
+        };
+
+        for (uint32_t i = 0; i < n_chunks && e == hipSuccess; i++)
+        {
+            const uint32_t first = st.first + i * map_rows, rows = rows_of (i), slot = i % S;
+            uint32_t a = 0, b = 0;
+            JobDev jd;
+
+            /* slot i % S is free once chunk i - S has left it; chunks whose kernels are done already leave now */
+            while (e == hipSuccess && retired < i)
+            {
+                if (i - retired < S)
+                {
+                    if (hipEventQuery (ln.ev_k [retired % S]) != hipSuccess)
+                    {
+                        (void) hipGetLastError ();
+                        break;
+                    }
+                }
+                e = retire (retired++);
+            }
+            if (e != hipSuccess)
+                break;
+            if (smol_hip_input_row_range (&job, first, rows, &a, &b))
+            {
+                lane_drain (ln);
+                return SMOL_HIP_E_INVALID;
+            }
+            const uint8_t *virt;        /* row 0 of the virtual source image */
+            if (bounce_in)
+            {
+                auto t = tick ();
+                copy_rows (RowCopy { ln.in.buf (slot), src_pitch, st.src + (size_t) a * st.rowstride_in, st.rowstride_in, in_row_bytes,
+                                     b - a + 1, knobs ().stream_stores });
+                ln.tm.copy_in += since (t);
+                ln.tm.pieces_in++;
+                virt = ln.in.buf (slot) - (size_t) a * src_pitch;
+            }
+            else
+                virt = static_cast<const uint8_t *> (map_src) - (size_t) r0 * src_pitch;
+            uint8_t *out = bounce_out ? ln.out.buf (slot) : static_cast<uint8_t *> (map_dst) + (size_t) i * map_rows * dst_pitch;
+
+            fill_jobdev (jd, job, virt, (uint32_t) src_pitch, out, (uint32_t) dst_pitch, first, rows);
+            jd.box_force = box_force;
+            auto t = tick ();
+            /* (ONE stream: a stream per ring slot, so that one chunk's head overlaps the tail of the one before, was
+             * measured and is 10-30 % slower -- kernels that share the link finish later each, and the copy pool waits
+             * for the oldest; profiles/r05_mapped_road.txt) */
+            e = launch_single (jd, ln.s_k, ln.tmp_buf, ln.tmp_cap);
+            if (e == hipSuccess && (bounce_in || bounce_out) && n_chunks > 1)
+                e = hipEventRecord (ln.ev_k [slot], ln.s_k);
+            ln.tm.submit += since (t);
+        }
+        /* (page-locked on both sides: one launch in flight, strip_finish () waits for it -- strips of several devices
+         * overlap; a ring side: the CPU copies are part of the strip, everything is home on return) */
+        if (bounce_in || bounce_out)
+            while (e == hipSuccess && retired < n_chunks)
+                e = retire (retired++);
+        if (e != hipSuccess)
+        {
+            lane_drain (ln);
+            return -(int) e;
+        }
+        return 0;
+    }
 
     if (zero_copy)
     {
@@ -1117,8 +1295,9 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
     uint32_t r0 = 0, r1 = 0;
     if (smol_hip_input_row_range (&job, first, (uint32_t) rows, &r0, &r1))
         return 0;
+    /* (under the promise nothing is ever compared: the band is computed from the caller's rows where they are) */
     const size_t src_pitch = align_up (in_row, 16), out_pitch = out_row;
-    const size_t src_bytes = ((size_t) r1 - r0 + 1) * src_pitch + 256, out_bytes = (size_t) rows * out_pitch + 256;
+    const size_t src_bytes = resident ? 0 : ((size_t) r1 - r0 + 1) * src_pitch + 256, out_bytes = (size_t) rows * out_pitch + 256;
     if (c->host_bytes < src_bytes + out_bytes)
     {
         if (hipSetDevice (plan->device) != hipSuccess)
@@ -1132,12 +1311,13 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
         }
     }
     c->valid = false;
-    copy_rows (RowCopy { c->host, src_pitch, src + (size_t) r0 * rowstride_in, rowstride_in, in_row, r1 - r0 + 1, true });
+    if (!resident)
+        copy_rows (RowCopy { c->host, src_pitch, src + (size_t) r0 * rowstride_in, rowstride_in, in_row, r1 - r0 + 1, true });
 
     Strip st;
     st.plan = plan;
-    st.src = c->host - (size_t) r0 * src_pitch;     /* (row 0 of the virtual image; only rows r0 .. r1 are ever read) */
-    st.rowstride_in = (uint32_t) src_pitch;
+    st.src = resident ? src : c->host - (size_t) r0 * src_pitch;    /* (row 0 of the virtual image; only rows r0 .. r1 are ever read) */
+    st.rowstride_in = resident ? rowstride_in : (uint32_t) src_pitch;
     st.dest = c->host + src_bytes;
     st.rowstride_out = (uint32_t) out_pitch;
     st.first = first;

@@ -5,6 +5,7 @@ thumbnail batch, and the asynchronous device-pointer box path. One GPU is enough
 device may be listed several times. Everything is compared byte for byte with the oracle.
 """
 import ctypes
+import os
 import random
 import threading
 
@@ -550,3 +551,77 @@ def test_resident_source_promise_and_read_ahead_off(monkeypatch):
     plan.scale_rows_host(s2, w_in * 4, dst[2 * w_out * 4:], w_out * 4, 2, 1)    # from the band: the old image
     assert np.array_equal(dst[:3 * w_out * 4], want[:3 * w_out * 4])
     plan.destroy()
+
+
+MAPPED_SPECS = [
+    (0, 4096, 2048, 0, 1024, 512, 0),           # 34 MB: nine chunks of the 4 MB kind (k_pow2)
+    (8, 3001, 2001, 9, 1203, 801, 0),           # 24-bit on both sides, odd everything (k_lind)
+    (0, 4000, 3000, 2, 400, 300, 0),            # box x box in two passes: the intermediate image in the lane
+    (4, 1000, 800, 4, 2500, 2000, 0),           # magnification, 128bpp class: the output is the large side
+    (4, 1600, 1200, 5, 1000, 750, 1),           # gamma-correct
+]
+
+
+def _mapped_road_cases():
+    """every spec with page-locked / pageable memory on either side, padded rows, a byte-misaligned source and a row range
+    that is not the whole image"""
+    for k, spec in enumerate(MAPPED_SPECS):
+        t_in, w_in, h_in, t_out, w_out, h_out, srgb = spec
+        bi, bo = H.bpp(t_in), H.bpp(t_out)
+        stride_in = w_in * bi + (0, 5, 16)[k % 3]
+        stride_out = w_out * bo + (0, 3, 32)[(k + 1) % 3]
+        raw = H.make_input(t_in, w_in, h_in, seed=20 + k, valid=bool(k & 1), stride=stride_in, pad=16)
+        want = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, srgb, stride_in=stride_in, stride_out=stride_out)
+        first = (0, h_out // 7)[k & 1]
+        n = h_out - first - (k % 3)
+        for pin_src in (False, True):
+            for pin_dst in (False, True):
+                mis = (k + pin_src) % 3
+                keep = []
+                if pin_src:
+                    a = sm.PinnedArray(raw.size + 8, register=bool(k & 1))
+                    keep.append(a)
+                    sbuf = a.array
+                else:
+                    sbuf = np.zeros(raw.size + 8, np.uint8)
+                sbuf[mis:mis + raw.size] = raw
+                if pin_dst:
+                    b = sm.PinnedArray(n * stride_out, register=not (k & 1))
+                    keep.append(b)
+                    dst = b.array
+                else:
+                    dst = np.zeros(n * stride_out, np.uint8)
+                dst[:] = 0xA5
+                ctx = sm.SmolScaleCtx(sbuf[mis:], t_in, w_in, h_in, stride_in, None, t_out, w_out, h_out, stride_out, srgb)
+                ctx.batch_full(dst, first, n)
+                ctx.destroy()
+                rb = w_out * bo
+                got = H.rows_view(dst, n, rb, stride_out)
+                ref = H.rows_view(want[first * stride_out:], n, rb, stride_out)
+                ok = bool(np.array_equal(got, ref))
+                if ok and stride_out > rb and n > 1:
+                    gaps = np.lib.stride_tricks.as_strided(dst[rb:], (n - 1, stride_out - rb), (stride_out, 1))
+                    ok = bool(np.all(gaps == 0xA5))
+                for p in keep:
+                    p.free()
+                yield spec, pin_src, pin_dst, ok
+
+
+def test_mapped_road_every_memory_combination():
+    """The road calls from host memory take since round 5 (strip_issue_locked, smol_rt_lanes.hip): the kernel reads and writes
+    page-locked host rows across PCIe -- the caller's own where page-locked, ring slots where pageable, in chunks."""
+    for spec, pin_src, pin_dst, ok in _mapped_road_cases():
+        assert ok, (spec, pin_src, pin_dst)
+
+
+def test_dma_road_still_serves_when_the_mapped_road_is_switched_off():
+    """SMOL_HIP_MAPPED=0 (a knob read once per process): the same cases over the DMA road of rounds 1-4."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_hip_multi as T\n"
+            "bad = [(s, a, b) for s, a, b, ok in T._mapped_road_cases() if not ok]\n"
+            "print('BAD', bad) if bad else print('ALL-OK')\n" % (H.ROOT, os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ, SMOL_HIP_MAPPED="0")
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert "ALL-OK" in run.stdout, (run.stdout[-2000:], run.stderr[-2000:])

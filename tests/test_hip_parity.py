@@ -843,7 +843,7 @@ def test_gamma_correct_24_bit_sources_three_channel_flavour():
     shapes = [(4000, 300, 1600, 120),      # ratio 2.5, 1 halving: wide tiles of 127 columns
               (3000, 210, 420, 30),        # ratio 7.1, 2 halvings: one-column flavour
               (1500, 200, 1000, 133),      # ratio 1.5, no halving
-              (480, 100, 1921, 401),       # magnified x4: stores dominate
+              (480, 100, 1601, 333),       # magnified x3.3: stores dominate (from x3.5 32-bit output is k_upg's)
               (1000, 64, 333, 200),        # H down, V up
               (257, 300, 1031, 75)]        # H up, V down
     lib = sm.lib()

@@ -1,7 +1,17 @@
-cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-echo "ramp on : $(tools/microbench/host_path 1 30 0 | tail -1)   16 callers: $(tools/microbench/host_path 16 8 0 | tail -1)"
-echo "ramp off: $(SMOL_HIP_RAMP=0 tools/microbench/host_path 1 30 0 | tail -1)   16 callers: $(SMOL_HIP_RAMP=0 tools/microbench/host_path 16 8 0 | tail -1)"
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+{
+for rep in 1 2 3; do
+ for ss in 1 0; do
+  for th in 1 16; do
+   echo "## C2 STREAM_STORES=$ss threads=$th"
+   SMOL_HIP_STREAM_STORES=$ss tools/microbench/host_path $th 40 0
+   echo "## 1080p STREAM_STORES=$ss threads=$th"
+   SMOL_HIP_STREAM_STORES=$ss tools/microbench/host_path $th 100 0 1920 1080 1280 720
+   echo "## up STREAM_STORES=$ss threads=$th"
+   SMOL_HIP_STREAM_STORES=$ss tools/microbench/host_path $th 100 0 1024 1024 2048 2048
+  done
+ done
 done
-echo "pinned  : $(tools/microbench/host_path 1 30 1 | tail -1)"
-SMOL_HIP_TRACE=1 tools/microbench/host_path 1 6 0 2>&1 | grep "strip rows" | tail -2
+} > gpurun_out/mapped_stream_stores.txt 2>&1
