@@ -844,6 +844,427 @@ fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
     return 0;
 }
 
+/* ---- the 128bpp class with SIMD (round 5) ---------------------------------------------------------------
+ * Four 32-bit lanes per pixel in the generic road's own order (R, G, B, alpha lane; its unpack_row () and pack_row () serve
+ * the last pixels of a row): the filters -- bilinear with halvings, box -- run on one pixel per 128-bit register, the
+ * vertical pass, the unpackers and the packers on two, table look-ups as gathers (the gamma tables from 32-bit copies),
+ * the 64-bit products of the inverse-alpha multiplies as even / odd 32 x 32 -> 64 multiplies. */
+
+/* horizontal bilinear: (((p - q) * F) >> 8) + q, masked, summed over the samples, halved */
+__attribute__ ((target ("avx2")))
+static void
+wide_hrow_bilinear_avx2 (const Ctx *c, const uint32_t *u, uint32_t *out)
+{
+    const SmolHipJob *j = c->job;
+    const uint32_t w_out = j->width_out, h = j->halvings_h, ns = 1u << h;
+    const uint32_t *ofs = c->h_ofs;
+    const uint16_t *f = c->h_f;
+    const __m128i mask = _mm_set1_epi32 ((int) c->mask);
+    const __m128i shift = _mm_cvtsi32_si128 ((int) h);
+    uint32_t x, s;
+
+    for (x = 0; x < w_out; x++, out += 4)
+    {
+        __m128i acc = _mm_setzero_si128 ();
+        for (s = 0; s < ns; s++, ofs++, f++)
+        {
+            const __m128i p = _mm_loadu_si128 ((const __m128i *) (u + (size_t) *ofs * 4));
+            const __m128i q = _mm_loadu_si128 ((const __m128i *) (u + (size_t) *ofs * 4 + 4));
+            const __m128i d = _mm_mullo_epi32 (_mm_sub_epi32 (p, q), _mm_set1_epi32 ((int) *f));
+            acc = _mm_add_epi32 (acc, _mm_and_si128 (_mm_add_epi32 (_mm_srai_epi32 (d, 8), q), mask));
+        }
+        _mm_storeu_si128 ((__m128i *) out, _mm_and_si128 (_mm_srl_epi32 (acc, shift), mask));
+    }
+}
+
+/* box_scale () of four 32-bit lanes: (acc * mul + 2^23) >> 24, masked to 16 bits (64-bit products) */
+__attribute__ ((target ("avx2")))
+static inline __m128i
+wide_box_scale4 (__m128i acc, __m256i vm)
+{
+    const __m256i half = _mm256_set1_epi64x (1ll << 23);
+    const __m256i w = _mm256_cvtepu32_epi64 (acc);
+    const __m256i r = _mm256_srli_epi64 (_mm256_add_epi64 (_mm256_mul_epu32 (w, vm), half), 24);
+    /* the low 32 bits of each 64-bit lane -> four 32-bit lanes */
+    const __m256i packed = _mm256_permutevar8x32_epi32 (r, _mm256_setr_epi32 (0, 2, 4, 6, 0, 2, 4, 6));
+    return _mm_and_si128 (_mm256_castsi256_si128 (packed), _mm_set1_epi32 (0xffff));
+}
+
+__attribute__ ((target ("avx2")))
+static void
+wide_hrow_box_avx2 (const Ctx *c, const uint32_t *u, uint32_t *out)
+{
+    const SmolHipJob *j = c->job;
+    const uint32_t w_out = j->width_out;
+    const __m128i mask = _mm_set1_epi32 ((int) c->mask);
+    const __m256i vm = _mm256_set1_epi64x ((long long) j->span_mul_x);
+    uint32_t x, s;
+
+    for (x = 0; x < w_out; x++, out += 4)
+    {
+        const uint32_t o0 = c->h_ofs [x], o1 = c->h_last [x];
+        __m128i acc = _mm_and_si128 (_mm_srli_epi32 (_mm_mullo_epi32 (_mm_loadu_si128 ((const __m128i *) (u + (size_t) o0 * 4)),
+                                                                      _mm_set1_epi32 (c->h_wl [x])), 8), mask);
+        if (o1 > o0)
+        {
+            __m128i a2 = _mm_setzero_si128 ();
+            for (s = o0 + 1; s + 1 < o1; s += 2)
+            {
+                acc = _mm_add_epi32 (acc, _mm_loadu_si128 ((const __m128i *) (u + (size_t) s * 4)));
+                a2 = _mm_add_epi32 (a2, _mm_loadu_si128 ((const __m128i *) (u + (size_t) s * 4 + 4)));
+            }
+            if (s < o1)
+                acc = _mm_add_epi32 (acc, _mm_loadu_si128 ((const __m128i *) (u + (size_t) s * 4)));
+            acc = _mm_add_epi32 (_mm_add_epi32 (acc, a2),
+                                 _mm_and_si128 (_mm_srli_epi32 (_mm_mullo_epi32 (_mm_loadu_si128 ((const __m128i *) (u + (size_t) o1 * 4)),
+                                                                                 _mm_set1_epi32 (c->h_fr [x])), 8), mask));
+        }
+        _mm_storeu_si128 ((__m128i *) out, wide_box_scale4 (acc, vm));
+    }
+}
+
+/* vertical bilinear over n 32-bit lanes: acc (+)= lerp (top, bot, F) */
+__attribute__ ((target ("avx2")))
+static void
+wide_vblend_avx2 (const uint32_t *top, const uint32_t *bot, uint32_t F, uint32_t lane_mask, uint32_t *acc, int first, size_t n)
+{
+    const __m256i vf = _mm256_set1_epi32 ((int) F), mask = _mm256_set1_epi32 ((int) lane_mask);
+    size_t i = 0;
+
+    for (; i + 8 <= n; i += 8)
+    {
+        const __m256i t = _mm256_loadu_si256 ((const __m256i *) (top + i));
+        const __m256i b = _mm256_loadu_si256 ((const __m256i *) (bot + i));
+        __m256i v = _mm256_and_si256 (_mm256_add_epi32 (_mm256_srai_epi32 (_mm256_mullo_epi32 (_mm256_sub_epi32 (t, b), vf), 8), b), mask);
+        if (!first)
+            v = _mm256_add_epi32 (v, _mm256_loadu_si256 ((const __m256i *) (acc + i)));
+        _mm256_storeu_si256 ((__m256i *) (acc + i), v);
+    }
+    for (; i < n; i++)
+    {
+        const uint32_t v = lerp (top [i], bot [i], F, lane_mask);
+        acc [i] = first ? v : acc [i] + v;
+    }
+}
+
+/* vertical box over n 32-bit lanes: acc (+)= (row * w) >> 8, masked (w = 256: the row itself) */
+__attribute__ ((target ("avx2")))
+static void
+wide_vbox_add_avx2 (const uint32_t *row, uint32_t w, uint32_t lane_mask, uint32_t *acc, int first, size_t n)
+{
+    const __m256i vw = _mm256_set1_epi32 ((int) w), mask = _mm256_set1_epi32 ((int) lane_mask);
+    size_t i = 0;
+
+    for (; i + 8 <= n; i += 8)
+    {
+        __m256i v = _mm256_loadu_si256 ((const __m256i *) (row + i));
+        if (w != 256u)
+            v = _mm256_and_si256 (_mm256_srli_epi32 (_mm256_mullo_epi32 (v, vw), 8), mask);
+        if (!first)
+            v = _mm256_add_epi32 (v, _mm256_loadu_si256 ((const __m256i *) (acc + i)));
+        _mm256_storeu_si256 ((__m256i *) (acc + i), v);
+    }
+    for (; i < n; i++)
+    {
+        const uint32_t v = w != 256u ? ((row [i] * w) >> 8) & lane_mask : row [i];
+        acc [i] = first ? v : acc [i] + v;
+    }
+}
+
+/* 32-bit copies of the two gamma tables: a gather reads four bytes per index */
+static uint32_t wide_from_srgb32 [256], wide_to_srgb32 [2048];
+
+__attribute__ ((constructor))
+static void
+wide_tables_init (void)
+{
+    uint32_t i;
+    for (i = 0; i < 256; i++)
+        wide_from_srgb32 [i] = smol_from_srgb_lut [i];
+    for (i = 0; i < 2048; i++)
+        wide_to_srgb32 [i] = smol_to_srgb_lut [i];
+}
+
+/* (x * y) >> sh per 32-bit lane with 64-bit products; the low 32 bits of each result */
+__attribute__ ((target ("avx2"), always_inline))
+static inline __m256i
+wide_mul_shr (__m256i x, __m256i y, const int sh)
+{
+    const __m256i ev = _mm256_srli_epi64 (_mm256_mul_epu32 (x, y), sh);
+    const __m256i od = _mm256_srli_epi64 (_mm256_mul_epu32 (_mm256_srli_epi64 (x, 32), _mm256_srli_epi64 (y, 32)), sh);
+    return _mm256_blend_epi32 (ev, _mm256_slli_epi64 (od, 32), 0xaa);
+}
+
+/* unpack_row () two pixels at a time, one specialisation per (bytes per pixel, alpha convention, storage form):
+ * the same formulas, lanes in the same order (R, G, B, alpha lane) */
+__attribute__ ((target ("avx2"), always_inline))
+static inline void
+wide_unpack_body (const Ctx *c, const uint8_t *src, uint32_t n, uint32_t *out,
+                  const uint32_t bpp, const int unassoc, const int p16, const int linear)
+{
+    const TypeInfo *ti = c->ti;
+    const uint8_t pa = bpp == 4 ? ti->pos [3] : 0x80;
+    const __m128i sel = _mm_setr_epi8 ((char) ti->pos [0], (char) ti->pos [1], (char) ti->pos [2], (char) pa,
+                                       (char) (bpp + ti->pos [0]), (char) (bpp + ti->pos [1]), (char) (bpp + ti->pos [2]),
+                                       (char) (bpp == 4 ? 4 + ti->pos [3] : 0x80),
+                                       -128, -128, -128, -128, -128, -128, -128, -128);
+    const __m128i opaque = bpp == 3 ? _mm_setr_epi8 (0, 0, 0, -1, 0, 0, 0, -1, 0, 0, 0, 0, 0, 0, 0, 0) : _mm_setzero_si128 ();
+    const __m256i alpha_lanes = _mm256_setr_epi32 (0, 0, 0, -1, 0, 0, 0, -1);
+    const __m256i ff = _mm256_set1_epi32 (0xff), one = _mm256_set1_epi32 (1);
+    uint32_t i;
+
+    /* (the 8-byte load of two 24-bit pixels reaches 2 bytes past them; keep those inside the row) */
+    for (i = 0; i + 2 + (bpp == 3 ? 1u : 0u) <= n; i += 2)
+    {
+        const __m128i raw = _mm_or_si128 (_mm_shuffle_epi8 (_mm_loadl_epi64 ((const __m128i *) (src + (size_t) i * bpp)), sel), opaque);
+        const __m256i v = _mm256_cvtepu8_epi32 (raw);
+        const __m256i a = _mm256_shuffle_epi32 (v, 0xff);
+        __m256i col, al;
+
+        if (p16)
+        {
+            col = linear ? _mm256_i32gather_epi32 ((const int *) wide_from_srgb32, v, 4) : v;
+            col = _mm256_mullo_epi32 (col, a);
+            al = _mm256_or_si256 (_mm256_slli_epi32 (a, 8), _mm256_set1_epi32 (0x80));
+        }
+        else if (linear)
+        {
+            __m256i x = v, l;
+            if (bpp == 4 && !unassoc)
+                x = _mm256_and_si256 (wide_mul_shr (v, _mm256_i32gather_epi32 ((const int *) smol_inv_p8_lut, a, 4), 13), ff);
+            else if (bpp == 3)
+                x = _mm256_and_si256 (wide_mul_shr (v, _mm256_set1_epi32 ((int) smol_inv_p8_lut [255]), 13), ff);
+            l = _mm256_i32gather_epi32 ((const int *) wide_from_srgb32, x, 4);
+            /* premul8l (): ((l + 1) * ((a << 3) + 1) - 1) >> 11, 11 bits */
+            col = _mm256_and_si256 (_mm256_srli_epi32 (_mm256_sub_epi32 (_mm256_mullo_epi32 (_mm256_add_epi32 (l, one),
+                                                                                              _mm256_add_epi32 (_mm256_slli_epi32 (a, 3), one)), one), 11),
+                                    _mm256_set1_epi32 (0x7ff));
+            al = a;
+        }
+        else
+        {
+            col = unassoc ? _mm256_and_si256 (_mm256_srli_epi32 (_mm256_sub_epi32 (_mm256_mullo_epi32 (_mm256_add_epi32 (v, one), _mm256_add_epi32 (a, one)), one), 8), ff)
+                          : v;
+            al = a;
+        }
+        _mm256_storeu_si256 ((__m256i *) (out + (size_t) i * 4), _mm256_blendv_epi8 (col, al, alpha_lanes));
+    }
+    if (i < n)
+        unpack_row (c, src + (size_t) i * bpp, n - i, out + (size_t) i * 4);
+}
+
+__attribute__ ((target ("avx2")))
+static void
+wide_unpack_avx2 (const Ctx *c, const uint8_t *src, uint32_t n, uint32_t *out)
+{
+    const int u = c->ti->unassoc;
+    if (c->ti->bpp == 3)
+    {
+        if (c->p16)          { if (c->linear) wide_unpack_body (c, src, n, out, 3, 0, 1, 1); else wide_unpack_body (c, src, n, out, 3, 0, 1, 0); }
+        else if (c->linear)  wide_unpack_body (c, src, n, out, 3, 0, 0, 1);
+        else                 wide_unpack_body (c, src, n, out, 3, 0, 0, 0);
+    }
+    else if (c->p16)         { if (c->linear) wide_unpack_body (c, src, n, out, 4, 1, 1, 1); else wide_unpack_body (c, src, n, out, 4, 1, 1, 0); }
+    else if (c->linear)      { if (u) wide_unpack_body (c, src, n, out, 4, 1, 0, 1); else wide_unpack_body (c, src, n, out, 4, 0, 0, 1); }
+    else                     { if (u) wide_unpack_body (c, src, n, out, 4, 1, 0, 0); else wide_unpack_body (c, src, n, out, 4, 0, 0, 0); }
+}
+
+/* pack_row () two pixels at a time, one specialisation per (bytes per pixel, alpha convention, storage form) */
+__attribute__ ((target ("avx2"), always_inline))
+static inline void
+wide_pack_body (const Ctx *c, const uint32_t *in, uint32_t n, uint8_t *dst,
+                const uint32_t bpp, const int unassoc, const int p16, const int linear)
+{
+    const TypeInfo *to = c->to;
+    const int quirk24 = c->quirk24;
+    const __m256i ff = _mm256_set1_epi32 (0xff), m11 = _mm256_set1_epi32 (0x7ff), one = _mm256_set1_epi32 (1);
+    uint8_t sel8 [16];
+    uint32_t i, k;
+    __m128i sel;
+
+    /* bytes R G B A | R G B A of two pixels -> the output type's order, 24-bit pixels back to back */
+    memset (sel8, 0x80, sizeof sel8);
+    for (k = 0; k < 2; k++)
+    {
+        uint32_t ch;
+        for (ch = 0; ch < bpp; ch++)
+            sel8 [k * bpp + to->pos [ch]] = (uint8_t) (4 * k + ch);
+    }
+    sel = _mm_loadu_si128 ((const __m128i *) sel8);
+
+    /* (the 8-byte store of two 24-bit pixels reaches 2 bytes past them; keep those inside the row) */
+    for (i = 0; i + 2 + (bpp == 3 ? 1u : 0u) <= n; i += 2)
+    {
+        const __m256i v = _mm256_loadu_si256 ((const __m256i *) (in + (size_t) i * 4));
+        const __m256i araw = _mm256_shuffle_epi32 (v, 0xff);
+        const __m256i a = _mm256_and_si256 (p16 ? _mm256_srli_epi32 (araw, 8) : araw, ff);
+        __m256i o;
+        __m128i b;
+
+        if (p16)
+        {
+            if (linear)
+            {
+                const __m256i t = _mm256_and_si256 (wide_mul_shr (v, _mm256_i32gather_epi32 ((const int *) smol_inv_p16l_lut, a, 4), 19), m11);
+                o = _mm256_i32gather_epi32 ((const int *) wide_to_srgb32, t, 4);
+            }
+            else
+                o = _mm256_and_si256 (wide_mul_shr (v, _mm256_i32gather_epi32 ((const int *) smol_inv_p16_lut, a, 4), 16), ff);
+        }
+        else if (linear)
+        {
+            const __m256i u = _mm256_and_si256 (wide_mul_shr (v, _mm256_i32gather_epi32 ((const int *) smol_inv_p8l_lut, a, 4), 10), m11);
+            if (bpp == 3)
+                o = _mm256_i32gather_epi32 ((const int *) wide_to_srgb32, quirk24 ? _mm256_and_si256 (v, m11) : u, 4);
+            else
+            {
+                o = _mm256_i32gather_epi32 ((const int *) wide_to_srgb32, u, 4);
+                if (!unassoc)
+                    o = _mm256_and_si256 (_mm256_srli_epi32 (_mm256_sub_epi32 (_mm256_mullo_epi32 (_mm256_add_epi32 (o, one), _mm256_add_epi32 (a, one)), one), 8), ff);
+            }
+        }
+        else
+            o = unassoc ? _mm256_and_si256 (wide_mul_shr (v, _mm256_i32gather_epi32 ((const int *) smol_inv_p8_lut, a, 4), 13), ff)
+                        : _mm256_and_si256 (v, ff);
+        o = _mm256_blend_epi32 (o, a, 0x88);            /* the alpha lanes */
+        o = _mm256_packus_epi32 (o, o);                 /* per half: four 16-bit values, twice */
+        o = _mm256_packus_epi16 (o, o);                 /* per half: four bytes, four times */
+        b = _mm_shuffle_epi8 (_mm_unpacklo_epi32 (_mm256_castsi256_si128 (o), _mm256_extracti128_si256 (o, 1)), sel);
+        _mm_storel_epi64 ((__m128i *) (dst + (size_t) i * bpp), b);
+    }
+    if (i < n)
+        pack_row (c, in + (size_t) i * 4, n - i, dst + (size_t) i * bpp);
+}
+
+__attribute__ ((target ("avx2")))
+static void
+wide_pack_avx2 (const Ctx *c, const uint32_t *in, uint32_t n, uint8_t *dst)
+{
+    const int u = c->to->unassoc;
+    if (c->to->bpp == 3)
+    {
+        if (c->p16)          { if (c->linear) wide_pack_body (c, in, n, dst, 3, 0, 1, 1); else wide_pack_body (c, in, n, dst, 3, 0, 1, 0); }
+        else if (c->linear)  wide_pack_body (c, in, n, dst, 3, 0, 0, 1);
+        else                 wide_pack_body (c, in, n, dst, 3, 0, 0, 0);
+    }
+    else if (c->p16)         { if (c->linear) wide_pack_body (c, in, n, dst, 4, 1, 1, 1); else wide_pack_body (c, in, n, dst, 4, 1, 1, 0); }
+    else if (c->linear)      { if (u) wide_pack_body (c, in, n, dst, 4, 1, 0, 1); else wide_pack_body (c, in, n, dst, 4, 0, 0, 1); }
+    else                     { if (u) wide_pack_body (c, in, n, dst, 4, 1, 0, 0); else wide_pack_body (c, in, n, dst, 4, 0, 0, 0); }
+}
+
+static int
+wide_class_ok (const Ctx *c)
+{
+    const SmolHipJob *j = c->job;
+    if (!c->wide || !__builtin_cpu_supports ("avx2"))
+        return 0;
+    return (j->filter_h == F_BILINEAR || j->filter_h == F_BOX) && (j->filter_v == F_BILINEAR || j->filter_v == F_BOX);
+}
+
+typedef struct
+{
+    const Ctx *c;
+    const uint8_t *src;
+    uint32_t stride;
+    uint32_t *urow, *hbuf [3];
+    uint32_t tag [3], next;
+}
+WideRows;
+
+static const uint32_t *
+wide_row_get (WideRows *wr, uint32_t r, const uint32_t *keep)
+{
+    const Ctx *c = wr->c;
+    uint32_t i, slot;
+
+    for (i = 0; i < 3; i++)
+        if (wr->tag [i] == r)
+            return wr->hbuf [i];
+    slot = wr->next;
+    if (wr->hbuf [slot] == keep)
+        slot = (slot + 1) % 3;
+    wr->next = (slot + 1) % 3;
+    wide_unpack_avx2 (c, wr->src + (size_t) r * wr->stride, c->job->width_in, wr->urow);
+    if (c->job->filter_h == F_BOX)
+        wide_hrow_box_avx2 (c, wr->urow, wr->hbuf [slot]);
+    else
+        wide_hrow_bilinear_avx2 (c, wr->urow, wr->hbuf [slot]);
+    wr->tag [slot] = r;
+    return wr->hbuf [slot];
+}
+
+__attribute__ ((target ("avx2")))
+static int
+wide_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *dest, uint32_t stride_out,
+                 uint32_t first_row, uint32_t n_rows)
+{
+    const SmolHipJob *j = c->job;
+    const uint32_t w_out = j->width_out, hv = j->halvings_v, nsy = 1u << hv;
+    const size_t lanes = (size_t) w_out * 4, lanes_in = (size_t) j->width_in * 4;
+    const __m256i vmy = _mm256_set1_epi64x ((long long) j->span_mul_y);
+    WideRows wr;
+    uint32_t *mem, *acc, *vout;
+    uint32_t y, k;
+    size_t i;
+
+    mem = malloc ((lanes_in + lanes * 5 + 32) * sizeof (uint32_t));
+    if (!mem)
+        return SMOL_HIP_E_INVALID;
+    wr.c = c; wr.src = src; wr.stride = stride_in; wr.next = 0;
+    wr.urow = mem;
+    for (k = 0; k < 3; k++)
+    {
+        wr.hbuf [k] = mem + lanes_in + 8 + lanes * k;
+        wr.tag [k] = UINT32_MAX;
+    }
+    acc = mem + lanes_in + 8 + lanes * 3;
+    vout = acc + lanes;
+
+    for (y = first_row; y < first_row + n_rows; y++, dest += stride_out)
+    {
+        if (j->filter_v == F_BOX)
+        {
+            /* 128bpp-class rows weight the last row by w2 - 1 and skip it when w2 == 0 (smolscale-generic.c:2236-2253) */
+            uint32_t y0, y1, w2, w1, r, last_w, y_end;
+
+            box_span (j->step_y, j->height_in, y, &y0, &y1, &w2, &w1);
+            last_w = w2 ? w2 - 1 : 0;
+            y_end = w2 == 0 ? y1 - 1 : y1;
+            if (y_end < y0 || y_end == UINT32_MAX)
+                memset (acc, 0, lanes * sizeof (uint32_t));
+            for (r = y0; r <= y_end && y_end != UINT32_MAX; r++)
+                wide_vbox_add_avx2 (wide_row_get (&wr, r, NULL), r == y0 ? w1 : r == y1 ? last_w : 256u, c->mask, acc, r == y0, lanes);
+            for (i = 0; i < lanes; i += 4)
+                _mm_storeu_si128 ((__m128i *) (vout + i), wide_box_scale4 (_mm_loadu_si128 ((const __m128i *) (acc + i)), vmy));
+        }
+        else
+        {
+            const __m256i mask = _mm256_set1_epi32 ((int) c->mask);
+            const __m128i shift = _mm_cvtsi32_si128 ((int) hv);
+            uint32_t s;
+
+            for (s = 0; s < nsy; s++)
+            {
+                const uint32_t *top, *bot;
+                uint32_t oy, F;
+
+                bilin_tap (j->frac0_y + (uint64_t) ((y << hv) + s) * j->step_y, j->height_in, &oy, &F);
+                top = wide_row_get (&wr, oy, NULL);
+                bot = wide_row_get (&wr, oy + 1, top);
+                wide_vblend_avx2 (top, bot, F, c->mask, acc, s == 0, lanes);
+            }
+            for (i = 0; i + 8 <= lanes; i += 8)
+                _mm256_storeu_si256 ((__m256i *) (vout + i),
+                                     _mm256_and_si256 (_mm256_srl_epi32 (_mm256_loadu_si256 ((const __m256i *) (acc + i)), shift), mask));
+            for (; i < lanes; i++)
+                vout [i] = (acc [i] >> hv) & c->mask;
+        }
+        wide_pack_avx2 (c, vout, w_out, dest);
+    }
+    free (mem);
+    return 0;
+}
+
 #endif /* SMOL_CPU_X86 */
 
 /* ---- tables ---------------------------------------------------------------------------------------- */
@@ -1005,6 +1426,8 @@ strip_scale_rows (const SmolCpuPlan *plan,
 #ifdef SMOL_CPU_X86
     if (fast_class_ok (cp))
         return fast_scale_rows (cp, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
+    if (wide_class_ok (cp))
+        return wide_scale_rows (cp, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
 #endif
 
     row_lanes_in = (size_t) job->width_in * 4;

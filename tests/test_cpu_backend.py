@@ -72,31 +72,33 @@ def test_cpu_backend_random_sweep_vs_oracle():
 
 
 def test_cpu_fast_class_every_channel_order_and_misalignment():
-    """The AVX2 / AVX-512 path (the 64bpp class with a bilinear filter on both axes: 3- and 4-byte pixels, either alpha
-    convention on either side; bilinear or box on either axis): all 100 type pairs (the pairs the planner sends to the 128bpp class run the generic path and are
-    checked all the same), 0-2 halvings per axis, magnification, widths that are not multiples of the vector width,
+    """The AVX2 / AVX-512 paths (the 64bpp class in packed 16-bit lanes, the 128bpp class in 32-bit lanes; 3- and 4-byte pixels,
+    either alpha convention on either side; bilinear or box on either axis, ratios above 255, with and without gamma):
+    all 100 type pairs, 0-2 halvings per axis, magnification, widths that are not multiples of the vector width,
     byte-misaligned rows, padded destination rows whose padding must stay untouched (24-bit rows are stored with 16-byte
     stores that overlap the next pixels)."""
     rng = random.Random(7)
     for t_in in range(10):
         for t_out in range(10):
             for (w_in, h_in, w_out, h_out) in ((64, 48, 32, 24), (203, 101, 51, 26), (333, 90, 47, 13), (40, 30, 97, 71), (77, 50, 50, 49),
-                                               (400, 300, 40, 30), (333, 200, 13, 7), (400, 60, 41, 40), (60, 400, 40, 39), (2000, 9, 8, 1)):
-                bi, bo = H.bpp(t_in), H.bpp(t_out)
-                sin = w_in * bi + rng.choice([0, 1, 3])
-                sout = w_out * bo + rng.choice([0, 0, 5, 16])
-                raw = H.make_input(t_in, w_in, h_in, seed=rng.randrange(1000), valid=bool(rng.getrandbits(1)), stride=sin, pad=32)
-                mis = rng.choice([0, 1, 2])
-                buf = np.zeros(raw.size + 8, np.uint8)
-                buf[mis:mis + raw.size] = raw
-                a = cpu_scale(buf[mis:], t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
-                b = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
-                rb = w_out * bo
-                assert np.array_equal(H.rows_view(a, h_out, rb, sout), H.rows_view(b, h_out, rb, sout)), \
-                    (t_in, t_out, w_in, h_in, w_out, h_out)
-                if sout > rb:
-                    gaps = np.lib.stride_tricks.as_strided(a[rb:], (h_out - 1, sout - rb), (sout, 1))
-                    assert np.all(gaps == 0xA5), (t_in, t_out, w_out)
+                                               (400, 300, 40, 30), (333, 200, 13, 7), (400, 60, 41, 40), (60, 400, 40, 39), (2000, 9, 8, 1),
+                                               (2100, 530, 8, 2)):
+                for srgb in (0, 1):
+                    bi, bo = H.bpp(t_in), H.bpp(t_out)
+                    sin = w_in * bi + rng.choice([0, 1, 3])
+                    sout = w_out * bo + rng.choice([0, 0, 5, 16])
+                    raw = H.make_input(t_in, w_in, h_in, seed=rng.randrange(1000), valid=bool(rng.getrandbits(1)), stride=sin, pad=32)
+                    mis = rng.choice([0, 1, 2])
+                    buf = np.zeros(raw.size + 8, np.uint8)
+                    buf[mis:mis + raw.size] = raw
+                    a = cpu_scale(buf[mis:], t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout)
+                    b = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, sout)
+                    rb = w_out * bo
+                    assert np.array_equal(H.rows_view(a, h_out, rb, sout), H.rows_view(b, h_out, rb, sout)), \
+                        (t_in, t_out, w_in, h_in, w_out, h_out, srgb)
+                    if sout > rb:
+                        gaps = np.lib.stride_tricks.as_strided(a[rb:], (h_out - 1, sout - rb), (sout, 1))
+                        assert np.all(gaps == 0xA5), (t_in, t_out, w_out)
 
 
 def test_cpu_backend_strips_and_threads():
