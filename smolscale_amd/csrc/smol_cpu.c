@@ -18,11 +18,13 @@
  * Shape: rows. A source row is unpacked to four lanes per pixel, filtered horizontally with
  * per-column tap tables built once per call from the closed-form sampling positions, and the
  * horizontally filtered rows meet in the vertical filter through a small row cache (bilinear) or an
- * accumulator (box). Two code paths:
- *   - generic: 32-bit lanes, every job (both storage classes, every pixel type, sRGB);
- *   - fast: the BASELINE class (32-bit premultiplied in and out, bilinear on both axes, 64bpp
- *     storage -- configs 1, 2 and 5) in packed 16-bit lanes with AVX2 / AVX-512BW intrinsics,
- *     selected at run time (__builtin_cpu_supports). */
+ * accumulator (box). Three code paths:
+ *   - generic: 32-bit lanes, every job (both storage classes, every pixel type, sRGB) -- what runs
+ *     without AVX2, under SMOL_CPU_SIMD=0 and on the last pixels of a row;
+ *   - fast_*: the 64bpp class (every pixel type and filter) in packed 16-bit lanes with AVX2 /
+ *     AVX-512BW intrinsics, selected at run time (__builtin_cpu_supports);
+ *   - wide_*: the 128bpp class in 32-bit lanes with AVX2 (round 5; rounds 3-4 had SIMD for 32-bit
+ *     premultiplied pixels under a bilinear filter on both axes only). */
 
 #include <stdint.h>
 #include <stdlib.h>
@@ -729,17 +731,34 @@ fast_vbox_add_avx2 (const uint16_t *row, uint32_t w, uint16_t *acc, int first, s
     }
 }
 
+/* SMOL_CPU_SIMD=0: every job down the generic 32-bit-lane road (what a CPU without AVX2 runs; the tests keep it honest) */
+static int
+simd_allowed (void)
+{
+    static int known = -1;
+    int k = __atomic_load_n (&known, __ATOMIC_RELAXED);
+    if (k < 0)
+    {
+        const char *e = getenv ("SMOL_CPU_SIMD");
+        k = !(e && *e == '0') && __builtin_cpu_supports ("avx2");
+        __atomic_store_n (&known, k, __ATOMIC_RELAXED);
+    }
+    return k;
+}
+
 static int
 fast_class_ok (const Ctx *c)
 {
     const SmolHipJob *j = c->job;
     /* the whole 64bpp class with a bilinear or a box filter on either axis: 3- and 4-byte pixels, either alpha convention
      * on either side (round 5; rounds 3-4: 32-bit premultiplied in and out, bilinear on both axes only) */
-    if (c->wide || !__builtin_cpu_supports ("avx2"))
+    if (c->wide || !simd_allowed ())
         return 0;
-    if (j->filter_h != F_BILINEAR && !(j->filter_h == F_BOX && j->step_x <= (255u << 16)))
+    if (j->filter_h == F_BOX && j->step_x > (255u << 16))
         return 0;
-    return j->filter_v == F_BILINEAR || (j->filter_v == F_BOX && j->step_y <= (255u << 16));
+    if (j->filter_h == F_COPY && j->width_out != j->width_in)
+        return 0;
+    return !(j->filter_v == F_BOX && j->step_y > (255u << 16));
 }
 
 typedef struct
@@ -768,8 +787,19 @@ fast_row_get (FastRows *fr, uint32_t r, const uint16_t *keep)
     fr->next = (slot + 1) % 3;
     if (fr->c->job->filter_h == F_BOX)
         fast_hbox_avx2 (fr->c, fr->src + (size_t) r * fr->stride, fr->urow, fr->sums, fr->hbuf [slot]);
-    else
+    else if (fr->c->job->filter_h == F_BILINEAR)
         fast_hrow_avx2 (fr->c, fr->src + (size_t) r * fr->stride, fr->hbuf [slot]);
+    else if (fr->c->job->filter_h == F_COPY)
+        fast_unpack_avx2 (fr->c, fr->src + (size_t) r * fr->stride, (uint64_t *) (void *) fr->hbuf [slot]);    /* width_out == width_in */
+    else
+    {
+        /* one source column: every output pixel is pixel 0 */
+        uint64_t *o = (uint64_t *) (void *) fr->hbuf [slot];
+        uint32_t x;
+        fast_unpack_avx2 (fr->c, fr->src + (size_t) r * fr->stride, fr->urow);
+        for (x = 0; x < fr->c->job->width_out; x++)
+            o [x] = fr->urow [0];
+    }
     fr->tag [slot] = r;
     return fr->hbuf [slot];
 }
@@ -781,7 +811,7 @@ fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
     const SmolHipJob *j = c->job;
     const uint32_t w_out = j->width_out, hv = j->halvings_v, nsy = 1u << hv;
     const size_t lanes = (size_t) w_out * 4;
-    const size_t box_words = j->filter_h == F_BOX ? (size_t) j->width_in + w_out : 0;
+    const size_t box_words = j->filter_h == F_BOX ? (size_t) j->width_in + w_out : j->filter_h == F_ONE ? (size_t) j->width_in : 0;
     const int use512 = __builtin_cpu_supports ("avx512bw");
     FastRows fr;
     uint16_t *acc, *vout;
@@ -823,6 +853,12 @@ fast_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
                 fast_vbox_add_avx2 (fast_row_get (&fr, r, NULL), r == y0 ? w1 : r == y1 ? w2 : 256u, acc, r == y0, lanes);
             fast_box_scale_avx2 (acc, j->span_mul_y, vout, lanes);
             fast_pack_avx2 (c, vout, 0, perm, w_out, dest);
+            continue;
+        }
+        if (j->filter_v != F_BILINEAR)
+        {
+            /* the same height (row y), or one source row (row 0) */
+            fast_pack_avx2 (c, fast_row_get (&fr, j->filter_v == F_ONE ? 0u : y, NULL), 0, perm, w_out, dest);
             continue;
         }
         for (uint32_t s = 0; s < nsy; s++)
@@ -1156,9 +1192,9 @@ static int
 wide_class_ok (const Ctx *c)
 {
     const SmolHipJob *j = c->job;
-    if (!c->wide || !__builtin_cpu_supports ("avx2"))
+    if (!c->wide || !simd_allowed ())
         return 0;
-    return (j->filter_h == F_BILINEAR || j->filter_h == F_BOX) && (j->filter_v == F_BILINEAR || j->filter_v == F_BOX);
+    return !(j->filter_h == F_COPY && j->width_out != j->width_in);
 }
 
 typedef struct
@@ -1187,8 +1223,16 @@ wide_row_get (WideRows *wr, uint32_t r, const uint32_t *keep)
     wide_unpack_avx2 (c, wr->src + (size_t) r * wr->stride, c->job->width_in, wr->urow);
     if (c->job->filter_h == F_BOX)
         wide_hrow_box_avx2 (c, wr->urow, wr->hbuf [slot]);
-    else
+    else if (c->job->filter_h == F_BILINEAR)
         wide_hrow_bilinear_avx2 (c, wr->urow, wr->hbuf [slot]);
+    else if (c->job->filter_h == F_COPY)
+        memcpy (wr->hbuf [slot], wr->urow, (size_t) c->job->width_out * 16);
+    else
+    {
+        uint32_t x;
+        for (x = 0; x < c->job->width_out; x++)
+            memcpy (wr->hbuf [slot] + (size_t) x * 4, wr->urow, 16);
+    }
     wr->tag [slot] = r;
     return wr->hbuf [slot];
 }
@@ -1236,6 +1280,12 @@ wide_scale_rows (const Ctx *c, const uint8_t *src, uint32_t stride_in, uint8_t *
                 wide_vbox_add_avx2 (wide_row_get (&wr, r, NULL), r == y0 ? w1 : r == y1 ? last_w : 256u, c->mask, acc, r == y0, lanes);
             for (i = 0; i < lanes; i += 4)
                 _mm_storeu_si128 ((__m128i *) (vout + i), wide_box_scale4 (_mm_loadu_si128 ((const __m128i *) (acc + i)), vmy));
+        }
+        else if (j->filter_v != F_BILINEAR)
+        {
+            /* the same height (row y), or one source row (row 0) */
+            wide_pack_avx2 (c, wide_row_get (&wr, j->filter_v == F_ONE ? 0u : y, NULL), w_out, dest);
+            continue;
         }
         else
         {

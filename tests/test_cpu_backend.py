@@ -73,7 +73,7 @@ def test_cpu_backend_random_sweep_vs_oracle():
 
 def test_cpu_fast_class_every_channel_order_and_misalignment():
     """The AVX2 / AVX-512 paths (the 64bpp class in packed 16-bit lanes, the 128bpp class in 32-bit lanes; 3- and 4-byte pixels,
-    either alpha convention on either side; bilinear or box on either axis, ratios above 255, with and without gamma):
+    either alpha convention on either side; bilinear, box, copy or one-pixel on either axis, ratios above 255, with and without gamma):
     all 100 type pairs, 0-2 halvings per axis, magnification, widths that are not multiples of the vector width,
     byte-misaligned rows, padded destination rows whose padding must stay untouched (24-bit rows are stored with 16-byte
     stores that overlap the next pixels)."""
@@ -82,7 +82,8 @@ def test_cpu_fast_class_every_channel_order_and_misalignment():
         for t_out in range(10):
             for (w_in, h_in, w_out, h_out) in ((64, 48, 32, 24), (203, 101, 51, 26), (333, 90, 47, 13), (40, 30, 97, 71), (77, 50, 50, 49),
                                                (400, 300, 40, 30), (333, 200, 13, 7), (400, 60, 41, 40), (60, 400, 40, 39), (2000, 9, 8, 1),
-                                               (2100, 530, 8, 2)):
+                                               (2100, 530, 8, 2), (64, 48, 64, 24), (67, 48, 31, 48), (1, 48, 10, 24), (64, 1, 32, 7),
+                                               (37, 11, 37, 11), (500, 30, 500, 3)):
                 for srgb in (0, 1):
                     bi, bo = H.bpp(t_in), H.bpp(t_out)
                     sin = w_in * bi + rng.choice([0, 1, 3])
@@ -99,6 +100,18 @@ def test_cpu_fast_class_every_channel_order_and_misalignment():
                     if sout > rb:
                         gaps = np.lib.stride_tricks.as_strided(a[rb:], (h_out - 1, sout - rb), (sout, 1))
                         assert np.all(gaps == 0xA5), (t_in, t_out, w_out)
+
+
+def test_generic_road_without_simd():
+    """SMOL_CPU_SIMD=0 (read once per process): what a CPU without AVX2 runs -- the golden vectors, the digests and the random
+    sweep once more, down the 32-bit-lane road that the SIMD classes otherwise leave to the last pixels of a row."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SMOL_CPU_SIMD="0")
+    run = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k",
+                          "golden_matrix or baseline_digests or random_sweep or plan_handle"],
+                         env=env, capture_output=True, text=True, timeout=1800, cwd=H.ROOT)
+    assert run.returncode == 0 and " passed" in run.stdout, (run.stdout[-2000:], run.stderr[-2000:])
 
 
 def test_cpu_backend_strips_and_threads():

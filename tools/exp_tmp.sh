@@ -2,16 +2,13 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 {
-for rep in 1 2 3; do
- for ss in 1 0; do
-  for th in 1 16; do
-   echo "## C2 STREAM_STORES=$ss threads=$th"
-   SMOL_HIP_STREAM_STORES=$ss tools/microbench/host_path $th 40 0
-   echo "## 1080p STREAM_STORES=$ss threads=$th"
-   SMOL_HIP_STREAM_STORES=$ss tools/microbench/host_path $th 100 0 1920 1080 1280 720
-   echo "## up STREAM_STORES=$ss threads=$th"
-   SMOL_HIP_STREAM_STORES=$ss tools/microbench/host_path $th 100 0 1024 1024 2048 2048
-  done
- done
-done
-} > gpurun_out/mapped_stream_stores.txt 2>&1
+echo "## CPU backend, SIMD off, 1 thread (the generic 32-bit-lane road: every class before round 5 except the first two rows)"
+SMOL_CPU_SIMD=0 SMOL_CPU_THREADS=1 tools/microbench/cpu_backend
+echo "## CPU backend, 1 thread"
+SMOL_CPU_THREADS=1 tools/microbench/cpu_backend
+echo "## CPU backend, 8 threads"
+SMOL_CPU_THREADS=8 tools/microbench/cpu_backend
+echo "## CPU backend, default threads (32)"
+tools/microbench/cpu_backend
+nproc; grep -m1 "model name" /proc/cpuinfo
+} > gpurun_out/cpu_backend_classes.txt 2>&1

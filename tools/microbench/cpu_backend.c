@@ -43,5 +43,8 @@ int main (int argc, char **argv)
     one ("RGB8 4000x3000 -> 400x300 (box)", 8, 4000, 3000, 8, 400, 300, 0);
     one ("RGBA8 premul 1024^2 -> 2048^2 (up)", 0, 1024, 1024, 0, 2048, 2048, 0);
     one ("RGBA8 unassoc sRGB 2048^2 -> 1365^2", 4, 2048, 2048, 4, 1365, 1365, 1);
+    one ("RGB8 sRGB 2000x1500 -> 800x600", 8, 2000, 1500, 8, 800, 600, 1);
+    one ("RGBA8 premul sRGB 4096^2 -> 448^2 (box)", 0, 4096, 4096, 0, 448, 448, 1);
+    one ("RGB8 65535x256 -> RGBA8 8192x256 (C4 rows)", 8, 65535, 256, 0, 8192, 256, 0);
     return 0;
 }
