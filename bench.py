@@ -470,8 +470,9 @@ def e2e_c4(w, local_rank, reps=3):
             hdst.free()
     plan.destroy()
     out["bytes_over_pcie"] = bytes_moved
-    out["what"] = ("this rank's strip (%d rows) from host memory: chunked H2D / kernels / D2H on three side streams "
-                   "(smol_hip_scale_rows_host), best of %d" % (n_rows, reps))
+    road = "DMA road: chunked H2D / kernels / D2H on three side streams" if os.environ.get("SMOL_HIP_MAPPED") == "0" else \
+        "mapped road: the kernel works on page-locked host rows across PCIe (the caller's own, or ring slots for pageable memory)"
+    out["what"] = ("this rank's strip (%d rows) from host memory, %s (smol_hip_scale_rows_host), best of %d" % (n_rows, road, reps))
     return out
 
 
@@ -595,7 +596,7 @@ def e2e_c2(local_rank, frame0, want0, reps=3, n_callers=16):
         import bench_rows_per_call
         out["rows_per_call"] = bench_rows_per_call.table(reps=2)
         out["rows_per_call"]["what"] = ("ms per image when ONE context is asked for its rows n at a time; x_whole = relative to "
-                                        "one call for the whole image; calls moving <= 256 KiB take the zero-copy road")
+                                        "one call for the whole image; small calls that continue each other are served from a validated read-ahead band")
     except Exception as e:                                          # noqa: BLE001
         out["rows_per_call"] = {"error": repr(e)}
     if old_aff is not None:
@@ -605,7 +606,8 @@ def e2e_c2(local_rank, frame0, want0, reps=3, n_callers=16):
             pass
     out["bytes_over_pcie_per_frame"] = moved
     out["what"] = ("4096x4096->1024x1024 RGBA8 premultiplied frames in HOST memory through smol_scale_new/batch/destroy "
-                   "(the drop-in API): source up and result down over the PCIe link on every call; best of %d" % reps)
+                   "(the drop-in API): source up and result down over the PCIe link on every call (%s); best of %d"
+                   % ("DMA road" if os.environ.get("SMOL_HIP_MAPPED") == "0" else "mapped road: kernels on page-locked host rows", reps))
     return out
 
 

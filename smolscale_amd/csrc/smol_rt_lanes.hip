@@ -12,6 +12,7 @@
  * hipPointerGetAttributes) keep the zero-copy road: their pointers go to hipMemcpyAsync directly. */
 
 #include "smol_rt.h"
+#include "smol_rt_chunks.h"
 
 #include <atomic>
 #include <chrono>
@@ -644,17 +645,25 @@ strip_issue_locked (Strip &st, Lane &ln)
      * and a 64-row call costs one launch and one wait. SMOL_HIP_MAPPED=0 brings the DMA road back. */
     void *map_src = nullptr, *map_dst = nullptr;
     bool mapped = knobs ().bounce && knobs ().mapped && !peer && !small;
-    if (mapped && !bounce_in
-        && (hipHostGetDevicePointer (&map_src, const_cast<uint8_t *> (src_first), 0) != hipSuccess || !map_src))
+    /* the device's address of a page-locked range; nullptr when it has none, or when the range (it may span several
+     * registrations that lie back to back on the host: host_range_is_pinned) is not ONE range on the device as well */
+    auto device_view = [] (const void *host, size_t bytes) -> void *
     {
-        (void) hipGetLastError ();      /* (page-locked but not mapped: the DMA road) */
+        void *first = nullptr, *last = nullptr;
+        uint8_t *h = const_cast<uint8_t *> (static_cast<const uint8_t *> (host));
+        if (hipHostGetDevicePointer (&first, h, 0) != hipSuccess || !first
+            || hipHostGetDevicePointer (&last, h + bytes - 1, 0) != hipSuccess
+            || static_cast<uint8_t *> (last) - static_cast<uint8_t *> (first) != (ptrdiff_t) (bytes - 1))
+        {
+            (void) hipGetLastError ();  /* (page-locked but not mapped: the DMA road) */
+            return nullptr;
+        }
+        return first;
+    };
+    if (mapped && !bounce_in && !(map_src = device_view (src_first, (n_in_rows - 1) * st.rowstride_in + in_row_bytes)))
         mapped = false;
-    }
-    if (mapped && !bounce_out && (hipHostGetDevicePointer (&map_dst, st.dest, 0) != hipSuccess || !map_dst))
-    {
-        (void) hipGetLastError ();
+    if (mapped && !bounce_out && !(map_dst = device_view (st.dest, (size_t) (st.n - 1) * st.rowstride_out + out_row_bytes)))
         mapped = false;
-    }
 
     /* How rows lie in the device slabs.
      * Direct road: rows that are (nearly) back to back on the host travel as ONE linear copy per chunk and keep
@@ -715,42 +724,21 @@ strip_issue_locked (Strip &st, Lane &ln)
     /* mapped road: chunks of output rows whose ring side(s) fit a slot; page-locked on both sides: one launch */
     uint32_t map_rows = st.n;           /* output rows per chunk */
     size_t map_in_max = 0, map_out_max = 0;
-    if (mapped && (bounce_in || bounce_out))
+    if (mapped)
     {
-        const size_t per_row = (n_in_rows * in_row_bytes + (size_t) st.n * out_row_bytes) / st.n + 1;
-        const size_t slot_max = knobs ().slot_bytes;
         /* box filters run as two kernels per chunk, or as tiles that want many rows: whole slots (4000 x 3000 -> 400 x 300:
          * 1.24 against 1.20 ms); everything else 4 MB (4096^2 -> 1024^2: 1.41 against 1.44 ms) */
         const bool boxy = job.filter_h == SMOL_HIP_FILTER_BOX || job.filter_v == SMOL_HIP_FILTER_BOX;
-        const size_t chunk = boxy && !knobs ().mapped_chunk_set ? slot_max : knobs ().mapped_chunk_bytes;
-        const size_t want = chunk < slot_max ? chunk : slot_max;
-        uint64_t rows = want / per_row;
-        map_rows = rows < 1 ? 1u : rows > st.n ? st.n : (uint32_t) rows;
-        for (;;)
+        const size_t chunk = boxy && !knobs ().mapped_chunk_set ? knobs ().slot_bytes : knobs ().mapped_chunk_bytes;
+        const MappedChunks mc = mapped_chunks (job, st.first, st.n, in_row_bytes, out_row_bytes, src_pitch, dst_pitch,
+                                                                                      bounce_in, bounce_out, chunk, knobs ().slot_bytes);
+        if (!mc.rows)
+            mapped = false;             /* (one output row reads more than a slot holds: the DMA road) */
+        else
         {
-            map_in_max = map_out_max = 0;
-            for (uint32_t y = 0; y < st.n && mapped; y += map_rows)
-            {
-                const uint32_t rows_here = st.n - y < map_rows ? st.n - y : map_rows;
-                uint32_t a = 0, b = 0;
-                if (smol_hip_input_row_range (&job, st.first + y, rows_here, &a, &b))
-                    mapped = false;
-                else
-                {
-                    const size_t in_b = bounce_in ? ((size_t) b - a + 1) * src_pitch : 0;
-                    const size_t out_b = bounce_out ? (size_t) rows_here * dst_pitch : 0;
-                    if (in_b > map_in_max) map_in_max = in_b;
-                    if (out_b > map_out_max) map_out_max = out_b;
-                }
-            }
-            if (!mapped || (map_in_max <= slot_max && map_out_max <= slot_max))
-                break;
-            if (map_rows == 1)
-            {
-                mapped = false;         /* (one output row reads more than a slot holds: the DMA road) */
-                break;
-            }
-            map_rows = (map_rows + 1) / 2;
+            map_rows = mc.rows;
+            map_in_max = mc.in_max;
+            map_out_max = mc.out_max;
         }
     }
 

@@ -42,6 +42,8 @@ __global__ void k_down_one (const JobDev J)
 #include <thread>
 #include <vector>
 
+#include "smol_rt_chunks.h"
+
 pthread_barrier_t emu_block_barrier;
 uint8_t *emu_dyn_lds_ptr;
 uint32_t emu_lane_xchg [64];
@@ -277,6 +279,42 @@ emu_strip_chunks_agree (const SmolHipJob *job, uint32_t src_pitch, uint32_t dst_
     if (flips)
         *flips = n_flips;
     return bad;
+}
+
+/* The mapped road's chunk plan (smol_rt_chunks.h), replayed without a GPU: returns the output rows per chunk (0: no plan) and
+ * checks what the road relies on -- every chunk's ring side(s) fit a slot, the chunks tile the row range, and every chunk's source
+ * rows lie inside the strip's. < 0: a violated property. */
+extern "C" int
+emu_mapped_chunks (const SmolHipJob *job, uint32_t first_row, uint32_t n_rows, uint32_t src_pitch, uint32_t dst_pitch,
+                   int ring_in, int ring_out, uint64_t want, uint64_t slot_max, uint64_t *in_max, uint64_t *out_max)
+{
+    const uint32_t bi = job->pixel_type_in >= 8 ? 3u : 4u, bo = job->pixel_type_out >= 8 ? 3u : 4u;
+    const smolrt::MappedChunks mc = smolrt::mapped_chunks (*job, first_row, n_rows, (size_t) job->width_in * bi, (size_t) job->width_out * bo,
+                                                           src_pitch, dst_pitch, ring_in != 0, ring_out != 0, want, slot_max);
+    uint32_t r0 = 0, r1 = 0;
+
+    if (in_max) *in_max = mc.in_max;
+    if (out_max) *out_max = mc.out_max;
+    if (!mc.rows)
+        return 0;
+    if (smol_hip_input_row_range (job, first_row, n_rows, &r0, &r1))
+        return -1;
+    if (!ring_in && !ring_out)
+        return mc.rows == n_rows ? (int) mc.rows : -2;
+    for (uint32_t y = 0; y < n_rows; y += mc.rows)
+    {
+        const uint32_t rows = n_rows - y < mc.rows ? n_rows - y : mc.rows;
+        uint32_t a = 0, b = 0;
+        if (smol_hip_input_row_range (job, first_row + y, rows, &a, &b))
+            return -3;
+        if (a < r0 || b > r1)
+            return -4;
+        if (ring_in && ((uint64_t) b - a + 1) * src_pitch > slot_max)
+            return -5;
+        if (ring_out && (uint64_t) rows * dst_pitch > slot_max)
+            return -6;
+    }
+    return (int) mc.rows;
 }
 
 extern "C" long

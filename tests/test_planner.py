@@ -193,3 +193,41 @@ def test_chunks_of_a_host_strip_take_the_road_the_strip_chose():
                 rc = emu.emu_strip_chunks_agree(ctypes.byref(job), sp, dp, first, n, rpc, 0, ctypes.byref(k), ctypes.byref(flips))
                 assert k.value == KC_TILE and rc != 0 and flips.value > 0
     assert seen == {KC_TILE, KC_BOX2}
+
+
+def test_mapped_road_chunks_fit_their_ring_slots():
+    """The mapped road (smol_rt_lanes.hip: kernels on page-locked host rows) cuts a strip with a pageable side into chunks whose source
+    rows / output rows pass through ONE ring slot each: the plan (smol_rt_chunks.h) replayed without a GPU over random jobs, row
+    ranges, slot sizes and chunk sizes -- every chunk fits, the chunks tile the range, nothing outside the strip's source rows is
+    read; page-locked on both sides is one launch; a row that cannot fit is reported (the caller takes the DMA road)."""
+    emu = H.emu()
+    u64 = ctypes.c_uint64
+    emu.emu_mapped_chunks.restype = ctypes.c_int
+    emu.emu_mapped_chunks.argtypes = [ctypes.POINTER(H.SmolHipJob)] + [ctypes.c_uint32] * 4 + [ctypes.c_int] * 2 + [u64, u64,
+                                                                                                          ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    rng = random.Random(99)
+    seen_plan = seen_none = 0
+    for it in range(3000):
+        t_in, t_out = rng.randrange(10), rng.randrange(10)
+        w_in, h_in = rng.choice([1, 2, 17, 640, 4000, 65535]), rng.choice([1, 2, 33, 480, 3000, 20000])
+        w_out, h_out = rng.choice([1, 3, 64, 333, 2048, 8192]), rng.choice([1, 2, 40, 299, 1024, 7000])
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, rng.randrange(2))
+        first = rng.randrange(h_out)
+        n = rng.randint(1, h_out - first)
+        sp = w_in * H.bpp(t_in) + rng.choice([0, 5, 16])
+        dp = w_out * H.bpp(t_out) + rng.choice([0, 3, 32])
+        ring_in, ring_out = rng.randrange(2), rng.randrange(2)
+        slot = rng.choice([64 << 10, 1 << 20, 8 << 20])
+        want = rng.choice([64 << 10, 4 << 20, 8 << 20, 64 << 20])
+        im, om = u64(), u64()
+        rows = emu.emu_mapped_chunks(ctypes.byref(job), first, n, sp, dp, ring_in, ring_out, want, slot, ctypes.byref(im), ctypes.byref(om))
+        assert rows >= 0, (rows, t_in, w_in, h_in, t_out, w_out, h_out, first, n, ring_in, ring_out, slot, want)
+        if not ring_in and not ring_out:
+            assert rows == n
+        if rows:
+            seen_plan += 1
+            assert im.value <= slot and om.value <= slot
+        else:
+            seen_none += 1
+            assert ring_in or ring_out          # only a row whose ring side exceeds the slot may be refused
+    assert seen_plan > 2000 and seen_none > 10
