@@ -764,7 +764,12 @@ lind_pick_width (const JobDev &d, bool fused = false)
 inline bool
 down_setup (JobDev &d)
 {
-    if (!d.wide || (!d.linear && !d.p16) || tune_env ("SMOL_NO_DOWN"))
+    /* ... and, since round 5, 24-bit rows of the 64bpp class behind one or two horizontal halvings (photographs: 4000 x 3000
+     * RGB8 -> 1600 x 1200): k_tile reads every tap of such a row as three LDS words, two byte alignments and four permutes;
+     * k_lind's three-channel flavour expands a source pixel once (lind3_body<.., FLAT>). */
+    const bool flat3 = !d.wide && d.bpp_in == 3 && d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR
+                       && !tune_env ("SMOL_NO_FLAT3") && (d.halv_h >= 1 || tune_env ("SMOL_FLAT3_ALL"));
+    if (!flat3 && (!d.wide || (!d.linear && !d.p16) || tune_env ("SMOL_NO_DOWN")))
         return false;                           /* (compressed 128bpp never meets a bilinear axis) */
     if (d.p16 && d.bpp_in != 4)
         return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */
@@ -825,7 +830,8 @@ inline uint32_t lind_waves (const JobDev &) { return 4u; }     /* waves (= tiles
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
-    return DOWN_LUT_BYTES + lind_waves (d) * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
+    /* the tables (128bpp class) + a row buffer per wave */
+    return (d.wide ? DOWN_LUT_BYTES : 0u) + lind_waves (d) * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;
 }
 
 /* host twin of the device box_span (smol_kernels.hip.h; closed form of smolscale.c's box precalc) */
