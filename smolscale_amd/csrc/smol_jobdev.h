@@ -764,12 +764,7 @@ lind_pick_width (const JobDev &d, bool fused = false)
 inline bool
 down_setup (JobDev &d)
 {
-    /* ... and, since round 5, 24-bit rows of the 64bpp class behind one or two horizontal halvings (photographs: 4000 x 3000
-     * RGB8 -> 1600 x 1200): k_tile reads every tap of such a row as three LDS words, two byte alignments and four permutes;
-     * k_lind's three-channel flavour expands a source pixel once (lind3_body<.., FLAT>). */
-    const bool flat3 = !d.wide && d.bpp_in == 3 && d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR
-                       && !tune_env ("SMOL_NO_FLAT3") && (d.halv_h >= 1 || tune_env ("SMOL_FLAT3_ALL"));
-    if (!flat3 && (!d.wide || (!d.linear && !d.p16) || tune_env ("SMOL_NO_DOWN")))
+    if (!d.wide || (!d.linear && !d.p16) || tune_env ("SMOL_NO_DOWN"))
         return false;                           /* (compressed 128bpp never meets a bilinear axis) */
     if (d.p16 && d.bpp_in != 4)
         return false;                           /* (premul16 storage only follows unassociated alpha, 4 bytes in) */
@@ -796,7 +791,10 @@ down_setup (JobDev &d)
 
     /* <= 128 vertical samples per tile. A magnifying vertical axis shares its source rows between output rows: tiles
      * tall enough to reach ~16 of them, so that the two halo rows a tile converts again stay a small share */
-    uint32_t th = t.halv_v ? 4u : 8u;
+    /* (behind two vertical halvings an output row already reads eight source rows: tiles of two -- gamma-correct 4000 x 3000
+     * RGB8 -> 571 x 428 102 -> 96 us, 4096^2 -> 683^2 98 -> 88; behind one halving 2 / 3 / 4 / 6 rows within 3 %, without
+     * halvings eight stay ahead of 2-6 by 2-25 %: profiles/r05_flat3_ab.txt, last table) */
+    uint32_t th = t.halv_v == 2 ? 2u : t.halv_v ? 4u : 8u;
     if (t.filter_v == F_BILINEAR && t.step_y < ((uint64_t) 1 << 32))
     {
         const uint64_t want = ((uint64_t) 14 << 32) / (t.step_y ? t.step_y : 1u);
@@ -830,8 +828,7 @@ inline uint32_t lind_waves (const JobDev &) { return 4u; }     /* waves (= tiles
 inline uint32_t
 down_lds_bytes (const JobDev &d)
 {
-    /* the tables (128bpp class) + a row buffer per wave */
-    return (d.wide ? DOWN_LUT_BYTES : 0u) + lind_waves (d) * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;
+    return DOWN_LUT_BYTES + lind_waves (d) * (64u * (lind_narrow (d) ? LIND_KMAX_NARROW_HOST : LIND_KMAX_HOST) * (d.p16 ? 16u : 8u)) + 16u;        /* the tables + a row buffer per wave */
 }
 
 /* host twin of the device box_span (smol_kernels.hip.h; closed form of smolscale.c's box precalc) */

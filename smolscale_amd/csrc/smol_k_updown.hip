@@ -14,8 +14,7 @@ using smolhip::JobDev;
 
 namespace {
 
-/* k_lind: one entry point per (horizontal halvings, input kind: 0 = 32-bit rows, 1 = 24-bit rows, 2 = premul16 + linear,
- * 3 = 24-bit rows of the 64bpp class) */
+/* k_lind: one entry point per (horizontal halvings, input kind: 0 = 32-bit rows, 1 = 24-bit rows, 2 = premul16 + linear) */
 template <int HX, int IN>
 void
 launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
@@ -93,9 +92,7 @@ down (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStr
 {
     const uint32_t wv = smolhip::dispatch::lind_waves (rep);
     grid.x = (grid.x + wv - 1) / wv;
-    if (!rep.wide)
-        launch_lind<3> (jobs_dev, rep, grid, lds, s);       /* 24-bit rows of the 64bpp class */
-    else if (rep.p16)
+    if (rep.p16)
         launch_lind<2> (jobs_dev, rep, grid, lds, s);
     else if (rep.bpp_in == 3)
         launch_lind<1> (jobs_dev, rep, grid, lds, s);

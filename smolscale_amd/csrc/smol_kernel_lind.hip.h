@@ -656,12 +656,7 @@ __device__ __forceinline__ uint32_t tap16_half (uint32_t p, uint32_t q, uint32_t
 #endif
 }
 
-/* FLAT: the same kernel for 24-bit rows of the 64bpp class (no gamma: k_tile's arithmetic, smolscale-generic.c:1290-1322 /
- * :1648-1682 on four 16-bit channels in two registers). k_tile reads every tap of a 24-bit row as three LDS words, two
- * byte alignments and four byte permutes; here a source pixel is expanded ONCE -- two permutes and a ds_write_b64 -- and
- * a tap is one 16-byte LDS read and six packed instructions ("a 24-bit tap reader that expands
- * once per lane instead of per tap"). No tables: the workgroup's LDS holds the four waves' row buffers only. */
-template <int HX, bool NARROW, bool FLAT = false>
+template <int HX, bool NARROW>
 __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                             const uint32_t lane, const uint32_t tile)
 {
@@ -684,7 +679,7 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
     /* ---- horizontal samples of this lane's columns ------------------------------------------------------------ */
     uint32_t xc [CPL];
     bool ok [CPL];
-    uint32_t tap_ofs [CPL][NSX], tap_w [CPL][NSX], tap_g [CPL][NSX];
+    uint32_t tap_ofs [CPL][NSX], tap_w [CPL][NSX];
 #pragma unroll
     for (int c = 0; c < CPL; c++)
     {
@@ -702,8 +697,7 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
                 tap_ofs [c][s] = 0;                                 /* (an axis of ONE pixel: lind_body) */
                 f = 256;
             }
-            tap_w [c][s] = FLAT ? f * 0x00010001u : f | ((256u - f) << 16);
-            tap_g [c][s] = (256u - f) * 0x00010001u;                /* (FLAT only) */
+            tap_w [c][s] = f | ((256u - f) << 16);
             pos += J.step_x;
         }
     }
@@ -801,16 +795,6 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
                 if ((uint32_t) k < n_rounds)
                     rawpx [k] = __builtin_amdgcn_alignbyte (0u, rawpx [k], (px_sh >> k) & 1u);
         }
-        if (FLAT)
-        {
-            /* bytes 0, 1, 2 -> 16-bit lanes {b0, b1}, {b2, -} (the fourth channel is the constant 255: not kept) */
-#pragma unroll
-            for (int k = 0; k < KMAX; k++)
-                if ((uint32_t) k < n_rounds)
-                    *reinterpret_cast<u32x2a8 *> (buf + ((uint32_t) k * 64u + lane) * 8u) =
-                        u32x2a8 { __builtin_amdgcn_perm (rawpx [k], rawpx [k], 0x0c010c00u), __builtin_amdgcn_perm (rawpx [k], rawpx [k], 0x0c0c0c02u) };
-            return;
-        }
         /* all look-ups of the row in flight together, then the stores (two passes over the rounds, each behind the
          * wave-uniform "does this round exist") */
         uint32_t t [KMAX][3];
@@ -842,101 +826,6 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
 #pragma unroll
     for (int c = 0; c < CPL; c++)
         q_full [c] = xc [c] - qj + 3u < xn;                         /* the quad's last pixel is inside the tile */
-    if constexpr (FLAT)
-    {
-        gbyte *out_row = gptr (J.dst) + (size_t) yrel0 * J.dst_stride;
-        uint32_t ks = 0, s_y = 0;
-        Px2 hp [CPL], acc [CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; c++)
-            hp [c].lo = hp [c].hi = acc [c].lo = acc [c].hi = 0;
-
-        load_row ();
-        for (uint32_t r = row_first; r <= row_last; r++)
-        {
-            Px2 h [CPL];
-            smol_wave_sync ();
-            convert_row ();
-            smol_wave_sync ();
-            if (r < row_last)
-                load_row ();
-
-#pragma unroll
-            for (int c = 0; c < CPL; c++)
-            {
-                Px2 hs = { 0, 0 };
-#pragma unroll
-                for (uint32_t s = 0; s < NSX; s++)
-                {
-                    const u32x4a8 pq = *reinterpret_cast<const u32x4a8 *> (buf + tap_ofs [c][s]);
-                    Px2 t;
-                    t.lo = as_u32 ((as_u16x2 (pq.x) * as_u16x2 (tap_w [c][s]) + as_u16x2 (pq.z) * as_u16x2 (tap_g [c][s])) >> 8);
-                    t.hi = as_u32 ((as_u16x2 (pq.y) * as_u16x2 (tap_w [c][s]) + as_u16x2 (pq.w) * as_u16x2 (tap_g [c][s])) >> 8);
-                    hs = s ? px2_add (hs, t) : t;
-                }
-                h [c] = HX ? px2_shr (hs, HX) : hs;
-            }
-
-            while (ks < n_samples && oy + vdue == r)
-            {
-#pragma unroll
-                for (int c = 0; c < CPL; c++)
-                {
-                    const Px2 t = tap2 (hp [c], h [c], Fy);
-                    acc [c] = s_y ? px2_add (acc [c], t) : t;
-                }
-                s_y++;
-                ks++;
-                if (s_y == nsy)
-                {
-#pragma unroll
-                    for (int c = 0; c < CPL; c++)
-                    {
-                        const Px2 v = hv ? px2_shr (acc [c], hv) : acc [c];
-                        /* the pixel's bytes in the source's memory order, alpha = 255 (selector 0x0d), then the output's order */
-                        uint32_t w = __builtin_amdgcn_perm (v.hi, v.lo, 0x0d040200u);
-                        w = __builtin_amdgcn_perm (w, w, J.out_perm);
-                        if (J.bpp_out == 3)
-                        {
-                            const uint32_t d = __builtin_amdgcn_perm (smol_quad_next (w), w, q_sel);
-                            if (q_full [c])
-                            {
-                                if (qj != 3u)
-                                {
-#ifdef SMOL_KERNEL_EMU
-                                    __builtin_memcpy (out_row + (size_t) xc [c] * 3 + qj, &d, 4);
-#else
-                                    *reinterpret_cast<SMOL_AS_GLOBAL u32a1 *> (out_row + (xc [c] * 3u + qj)) = d;
-#endif
-                                }
-                            }
-                            else if (ok [c])
-                                wide_store_word (J, out_row, xc [c], w);
-                        }
-                        else if (ok [c])
-                        {
-                            if (J.out_dword_ok)
-                                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;
-                            else
-                                wide_store_word (J, out_row, xc [c], w);
-                        }
-                    }
-                    s_y = 0;
-                    out_row += J.dst_stride;
-                }
-                if (ks < n_samples)
-                {
-                    e = (ks < 64u) ? smol_readlane (sched [0], ks) : smol_readlane (sched [1], ks - 64u);
-                    oy = e & 0xffffu;
-                    Fy = e >> 16;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CPL; c++)
-                hp [c] = h [c];
-        }
-        return;
-    }
     const LutLds lut (lut_lds, LUT_AT_LDS_0);
     const WidePack<WP_LIN_O> wp (Jp, lut);                          /* (its byte selectors; WP_LIN_Q's are the same) */
     const bool quirk = wide_pack_kind (J) == WP_LIN_Q;
@@ -1052,6 +941,12 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
     }
 }
 
+/* (A flavour of this body WITHOUT gamma for 24-bit rows of the 64bpp class -- a pixel expanded once, two permutes and a
+ * ds_write_b64, taps as one 16-byte LDS read and six packed instructions, no tables; "a 24-bit tap reader that expands once
+ * per lane instead of per tap" -- was built and measured in round 5: bit-exact, and equal to k_tile at best (4000 x 3000 RGB8
+ * -> 1600 x 1200: 118.7 against 117.8-120 us with tiles of two rows, 122-141 with taller ones; slower at every other ratio).
+ * profiles/r05_flat3_ab.txt, git 0cc225c.) */
+
 /* (The fused 2-D table L (c, a) for premultiplied sources -- 66 KB of LDS, 16-wave persistent workgroups -- was built and
  * measured in round 5: bit-exact and 1.5 x slower than the chain above, 0.39 -> 0.26 of the roofline; one workgroup per CU
  * costs more than the table saves. profiles/r05_lind_tri_ab.txt, git 3f9fcfe.) */
@@ -1065,20 +960,9 @@ __device__ __forceinline__ uint32_t lind_wave_lds (bool w32, bool narrow = false
 /* 4 waves per workgroup share one LDS copy of the tables, each wave works on its own tile in its own LDS region */
 /* NARROW: the one-column flavour, a kernel of its own (k_lind_batch<HX, IN, true>; as a second body inside the common
  * kernel it cost the wide tiles 3-4 %, as k_boxh's 64-lane flavour did); the host picks it per job: dispatch::lind_narrow */
-template <int HX, bool IN24, bool W32, bool NARROW = false, bool FLAT = false>
+template <int HX, bool IN24, bool W32, bool NARROW = false>
 __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 {
-    if constexpr (FLAT)
-    {
-        /* 24-bit rows of the 64bpp class: no tables, the four waves' row buffers from the start of the workgroup's LDS */
-#ifdef SMOL_KERNEL_EMU
-        lind3_body<HX, NARROW, true> (J, lds, lds, threadIdx.x, blockIdx.x);
-#else
-        const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6));
-        lind3_body<HX, NARROW, true> (J, lds + wave * lind_wave_lds (false, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
-#endif
-        return;
-    }
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
@@ -1184,21 +1068,20 @@ __device__ __forceinline__ void linv_dispatch (const JobDev &J, uint8_t *lds)
 }
 
 #ifndef SMOL_KERNEL_EMU
-/* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels);
- * 3 = 24-bit rows of the 64bpp class (no gamma, no tables) */
+/* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels) */
 template <int HX, int IN, bool NARROW = false>
 __global__ void __launch_bounds__ (256)
 k_lind_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    lind_entry<HX, IN == 1 || IN == 3, IN == 2, NARROW, IN == 3> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW> (J, smol_dyn_lds);
 }
 
 template <int HX, int IN, bool NARROW = false>
 __global__ void __launch_bounds__ (256)
 k_lind_one (const JobDev J)
 {
-    lind_entry<HX, IN == 1 || IN == 3, IN == 2, NARROW, IN == 3> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW> (J, smol_dyn_lds);
 }
 
 /* (pass 1: jobs along blockIdx.z like k_boxh; pass 2: along blockIdx.y like k_boxv) */

@@ -11,17 +11,6 @@ namespace smolhip {
 __global__ void k_down_one (const JobDev J)
 {
     const int in = J.p16 ? 2 : J.bpp_in == 3 ? 1 : 0;
-    if (!J.wide)                                /* 24-bit rows of the 64bpp class: no tables */
-    {
-        const bool narrow = dispatch::lind_narrow (J);
-        switch (J.halv_h)
-        {
-            case 0:  lind_entry<0, true, false, false, true> (J, smol_dyn_lds); break;
-            case 1:  if (narrow) lind_entry<1, true, false, true, true> (J, smol_dyn_lds); else lind_entry<1, true, false, false, true> (J, smol_dyn_lds); break;
-            default: if (narrow) lind_entry<2, true, false, true, true> (J, smol_dyn_lds); else lind_entry<2, true, false, false, true> (J, smol_dyn_lds); break;
-        }
-        return;
-    }
     if (dispatch::lind_narrow (J))              /* tiles of at most 64 columns: the one-column flavour */
     {
         switch (J.halv_h * 3 + in)

@@ -452,41 +452,3 @@ def test_dispatcher_keeps_proportional_resizes_off_the_backstops():
     assert sm.kernel_name(sm.plan_job(4, 300, 4000, 4, 900, 200, 1)).startswith("k_linh_batch (vertical box sums")   # premul16 + sRGB: no backstop any more
     assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 2731, 2731, 1)) == "k_lind_batch"
     assert sm.kernel_name(sm.plan_job(8, 4000, 3000, 8, 1600, 1200, 1)) == "k_lind_batch"
-
-
-def test_emulated_down_kernel_flat_24_bit_rows():
-    """k_lind's three-channel flavour without gamma (lind3_body<.., FLAT>): 24-bit rows of the 64bpp class behind one or two
-    horizontal halvings, every output type, wide and one-column tiles, odd strides, row ranges; the emulation library is a
-    tuning build, so SMOL_FLAT3_ALL also sends the no-halving, magnified and mixed-axis jobs of the class through it."""
-    import os
-    rng = random.Random(2024)
-    seen = 0
-    for all_jobs in (0, 1):
-        if all_jobs:
-            os.environ["SMOL_FLAT3_ALL"] = "1"
-        try:
-            for it in range(120):
-                w_out = rng.choice([1, 2, 7, 40, 64, 65, 130, 256, 257, 300, 515])
-                h_out = rng.choice([1, 2, 5, 17, 33])
-                rx = rng.uniform(2.01, 7.99) if not all_jobs else rng.choice([rng.uniform(0.2, 0.99), rng.uniform(1.01, 7.99)])
-                ry = rng.choice([rng.uniform(0.3, 0.99), rng.uniform(1.01, 7.99)]) if all_jobs else rng.uniform(1.01, 7.99)
-                w_in = max(2, min(int(w_out * rx) + rng.randint(0, 1), 8 * w_out - 1))
-                h_in = max(2, min(int(h_out * ry) + rng.randint(0, 1), 8 * h_out - 1))
-                if w_in == w_out or h_in == h_out:
-                    continue
-                t_in, t_out = rng.choice([8, 9]), rng.randrange(10)
-                sin = w_in * 3 + rng.choice([0, 0, 4, 1, 3])
-                sout = w_out * H.bpp(t_out) + rng.choice([0, 0, 1, 4])
-                job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
-                if job.wide or job.filter_h != 2 or job.filter_v != 2:
-                    continue
-                src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
-                first = rng.randint(0, h_out - 1)
-                n = rng.randint(1, h_out - first)
-                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
-                got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
-                seen += k == 9
-                assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k, all_jobs)
-        finally:
-            os.environ.pop("SMOL_FLAT3_ALL", None)
-    assert seen >= 60
