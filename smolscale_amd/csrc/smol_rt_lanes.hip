@@ -727,9 +727,12 @@ strip_issue_locked (Strip &st, Lane &ln)
     if (mapped)
     {
         /* box filters run as two kernels per chunk, or as tiles that want many rows: whole slots (4000 x 3000 -> 400 x 300:
-         * 1.24 against 1.20 ms); everything else 4 MB (4096^2 -> 1024^2: 1.41 against 1.44 ms) */
+         * 1.24 against 1.20 ms); so do strips of more than 128 MB, where the per-chunk costs add up and nothing is left of
+         * the early start (65535 x 4096 RGB8 -> 8192 x 4096, 940 MB: 17.7-18.1 ms with 4 MB chunks, 16.7 with whole slots,
+         * the DMA road 16.6); everything else 4 MB (4096^2 -> 1024^2: 1.41 against 1.44 ms; profiles/r05_mapped_road.txt) */
         const bool boxy = job.filter_h == SMOL_HIP_FILTER_BOX || job.filter_v == SMOL_HIP_FILTER_BOX;
-        const size_t chunk = boxy && !knobs ().mapped_chunk_set ? knobs ().slot_bytes : knobs ().mapped_chunk_bytes;
+        const bool large = n_in_rows * in_row_bytes + (size_t) st.n * out_row_bytes > ((size_t) 128 << 20);
+        const size_t chunk = (boxy || large) && !knobs ().mapped_chunk_set ? knobs ().slot_bytes : knobs ().mapped_chunk_bytes;
         const MappedChunks mc = mapped_chunks (job, st.first, st.n, in_row_bytes, out_row_bytes, src_pitch, dst_pitch,
                                                                                       bounce_in, bounce_out, chunk, knobs ().slot_bytes);
         if (!mc.rows)

@@ -1,12 +1,24 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
-export SMOLSCALE_AMD_LIB=$PWD/smolscale_amd/libsmolscale_amd_tuning.so
-f() { python tests/bench_configs_checked.py --configs $1 --iters 20 2>/dev/null | python -c "
-import sys,json
-print(' '.join('%s=%.1f(%.3f)%s' % (d['config'][:26], d['step_us'], d['frac_of_8TBps'], '' if d.get('bit_exact_first_rows_vs_oracle') else '!!') for d in map(json.loads, sys.stdin)))"; }
-G=SRGBR6,SRGBR7RGB,G:4:4096:4096:4:683:683:4,G:4:4096:4096:5:585:585:4:srgb,G:8:4000:3000:8:571:428:8:srgb,G:0:1000:4000:0:2000:600:4:srgb,G:4:4096:4096:0:900:900:4:srgb,G:9:4000:3000:0:800:600:8:srgb
-for rep in 1 2; do
-echo "rows=4 (round 4)  $(SMOL_DOWN_ROWS=4 f $G)"
-echo "rows=2 (now)      $(f $G)"
-echo "rows=3            $(SMOL_DOWN_ROWS=3 f $G)"
-echo "rows=1            $(SMOL_DOWN_ROWS=1 f $G)"
+p() { python3 -c "
+import json,sys
+d=json.load(open(sys.argv[1])); e=d['e2e']
+print(sys.argv[2], {k:(v['ms'],v['GBps_over_pcie']) for k,v in e.items() if isinstance(v,dict)})" $1 "$2"; }
+python3 bench.py --config c4 --steps 5 --warmup 2 > gpurun_out/c4_a.json 2>/dev/null; p gpurun_out/c4_a.json "c4 mapped 4MB"
+SMOL_HIP_MAPPED_CHUNK_KB=8192 python3 bench.py --config c4 --steps 5 --warmup 2 > gpurun_out/c4_b.json 2>/dev/null; p gpurun_out/c4_b.json "c4 mapped 8MB"
+SMOL_HIP_MAPPED=0 python3 bench.py --config c4 --steps 5 --warmup 2 > gpurun_out/c4_c.json 2>/dev/null; p gpurun_out/c4_c.json "c4 DMA"
+python3 bench.py --config c4 --steps 5 --warmup 2 > gpurun_out/c4_a.json 2>/dev/null; p gpurun_out/c4_a.json "c4 mapped 4MB"
+SMOL_HIP_MAPPED=0 python3 bench.py --config c4 --steps 5 --warmup 2 > gpurun_out/c4_c.json 2>/dev/null; p gpurun_out/c4_c.json "c4 DMA"
+for g in "8 65535 512 0 8192 512" "8 65535 1024 0 8192 1024" "8 65535 2048 0 8192 2048" "0 8192 8192 0 2048 2048" "0 16384 8192 0 4096 2048"; do
+ for m in 1 0; do
+  echo "MAPPED=$m $g: $(SMOL_HIP_MAPPED=$m python3 - $g <<'PY'
+import sys
+sys.path.insert(0,'tools'); sys.path.insert(0,'.')
+import bench_rows_per_call as B
+g=tuple(int(x) for x in sys.argv[1:7])
+r=B.measure(g, False, 0, reps=4)
+mb=(g[1]*g[2]*(3 if g[0]>=8 else 4)+g[4]*g[5]*(3 if g[3]>=8 else 4))/1e6
+print("%.3f ms %.1f GB/s ok=%s"%(r['ms_per_image'], mb/r['ms_per_image'], r['equal_to_whole_image_call']))
+PY
+)"
+ done
 done
