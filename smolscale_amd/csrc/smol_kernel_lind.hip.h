@@ -29,7 +29,6 @@ namespace smolhip {
 
 constexpr int LIND_KMAX = 5;            /* conversion rounds per source row: spans of at most 320 pixels */
 constexpr int LIND_KMAX_NARROW = 8;     /* the one-column flavour (NARROW: half the registers per lane): 512 pixels, 64 columns up to a ratio of 8 */
-typedef uint32_t u32a1 __attribute__ ((aligned (1)));
 
 /* one tap on a 32-bit channel of at most 19 bits: (p * F + q * (256 - F)) >> 8, below 2^28 before the shift */
 __device__ __forceinline__ uint32_t tap32 (uint32_t p, uint32_t q, uint32_t F, uint32_t G)

@@ -1202,6 +1202,8 @@ struct Pow2Cfg
 
 typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 typedef u32x4 u32x4a4 __attribute__ ((aligned (4)));       /* a 16-byte load unit on a 4-byte boundary (cropped images) */
+typedef uint32_t u32a1 __attribute__ ((aligned (1)));      /* a dword at any byte address (global memory needs no alignment on gfx950) */
+typedef uint32_t u32x2a1 __attribute__ ((ext_vector_type (2), aligned (1)));
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
 
 /* 16-byte NON-TEMPORAL output store on a dword-aligned address (k_up, bound by its stores: aligned rows 92 us

@@ -452,3 +452,29 @@ def test_dispatcher_keeps_proportional_resizes_off_the_backstops():
     assert sm.kernel_name(sm.plan_job(4, 300, 4000, 4, 900, 200, 1)).startswith("k_linh_batch (vertical box sums")   # premul16 + sRGB: no backstop any more
     assert sm.kernel_name(sm.plan_job(0, 4096, 4096, 0, 2731, 2731, 1)) == "k_lind_batch"
     assert sm.kernel_name(sm.plan_job(8, 4000, 3000, 8, 1600, 1200, 1)) == "k_lind_batch"
+
+
+def test_emulated_up_kernel_24_bit_output_as_shipped():
+    """k_up with 24-bit output (round 5: twelve bytes per lane) under the shipped rule (from x2.6): every 64bpp-class source
+    type into RGB8 / BGR8, full and partial tiles, padded rows, row ranges."""
+    rng = random.Random(4242)
+    hits = 0
+    for it in range(90):
+        w_in = rng.choice([3, 17, 64, 100, 130])
+        h_in = rng.choice([2, 4, 9, 30])
+        mag = rng.uniform(2.65, 8.0)
+        w_out, h_out = min(int(w_in * mag) + rng.randint(0, 2), 1100), min(int(h_in * rng.uniform(2.65, 8.0)) + rng.randint(0, 2), 200)
+        t_in, t_out = rng.randrange(10), rng.choice([8, 9])
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+        if job.wide:
+            continue
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 1, 3, 4, 16])
+        sout = w_out * 3 + rng.choice([0, 0, 1, 4, 16])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        hits += (k == 8)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
+    assert hits >= 60

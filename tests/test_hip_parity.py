@@ -866,3 +866,38 @@ def test_gamma_correct_24_bit_sources_three_channel_flavour():
                 got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 1, sin, sout, first, n,
                                          src_misalign=k % 4, dst_misalign=(k // 2) % 4)
                 assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "device")
+
+
+def test_magnification_into_24_bit_rows_through_k_up():
+    """Round 5: k_up with 24-bit output -- the lane's four pixels leave as twelve bytes (an 8-byte and a 4-byte store at the
+    pixels' own address) -- from x2.6, every 64bpp-class source type into RGB8 / BGR8: aligned and odd widths, padded and
+    byte-misaligned rows, partial tiles at the right edge (k_tile's column stores), row ranges."""
+    shapes = [(480, 270, 1920, 1080),      # x4: 7.5 tiles of 256 columns
+              (333, 100, 1000, 301),       # x3, odd everything
+              (100, 40, 261, 105),         # x2.61: one full tile and five columns
+              (64, 20, 512, 161),          # x8
+              (700, 20, 1900, 60)]         # x2.7, wide
+    k = 0
+    seen = 0
+    for (w_in, h_in, w_out, h_out) in shapes:
+        for t_in in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+            for t_out in (8, 9):
+                k += 1
+                if (k % 2) and w_in * h_in > 60_000:
+                    continue
+                job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+                if job.wide:
+                    continue
+                seen += sm.kernel_name(job) == "k_up_batch"
+                sin = w_in * H.bpp(t_in) + (k % 4)
+                sout = w_out * 3 + (k % 3)
+                src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                rb = w_out * 3
+                assert np.array_equal(H.rows_view(got, h_out, rb, sout), H.rows_view(want, h_out, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "host")
+                first, n = h_out // 3, max(1, h_out // 2)
+                got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first=first, n=n,
+                                         src_misalign=k % 3, dst_misalign=(k + 1) % 4)
+                assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "device")
+    assert seen >= 40
