@@ -609,9 +609,10 @@ up_setup (JobDev &d)
          * RGB8 -> RGB8 179 / 120 us, RGBA -> RGB8 154 / 113, premultiplied -> unassociated 230 / 153; 3840x2160 -> x2, 6 frames,
          * 401 / 185, 287 / 184, 561 / 241; x8 151 / 101, 178 / 125 (profiles/r04_up_vs_lind.txt). 24-bit sources into
          * premultiplied 32-bit: k_up from x2.6 (x2 243 / 181, x2.6 118 / 117, x3 116 / 141, x4 91 / 99) */
-        /* (round 5: 24-bit output leaves k_up as the lane's twelve bytes -- an 8-byte and a 4-byte store -- from x2.6: RGBA ->
-         * RGB8 x2.25 equal, x2.6 66 -> 54 us, x3 68 -> 63, x4 111 -> 97, x8 100 -> 93, unassociated -> BGR8 x4 on an odd width
-         * 158 -> 112; RGB8 -> RGB8 x2.6 67 -> 62, x3 73 -> 69, x4 equal, x4 odd 140 -> 123, x8 100 -> 96: profiles/r05_up_rgb8.txt) */
+        /* (round 5: 24-bit output leaves k_up as the lane's twelve bytes -- an 8-byte and a 4-byte streaming store -- from x2.6:
+         * RGBA -> RGB8 x2.25 equal, x2.6 66 -> 55 us, x3 68 -> 62, x4 111 -> 86, x8 100 -> 75, unassociated -> BGR8 x4 on an odd
+         * width 158 -> 100; RGB8 -> RGB8 x2.6 67 -> 65, x3 73 -> 63, x4 110 -> 87, x4 odd 140 -> 100, x8 100 -> 75:
+         * profiles/r05_up_rgb8.txt) */
         const bool out24 = d.out3_ok && !tune_env ("SMOL_NO_UP_P3");
         if ((d.tile_variant & 3u) != 0 && !out24)
             return false;

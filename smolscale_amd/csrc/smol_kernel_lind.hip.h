@@ -621,16 +621,6 @@ __device__ __forceinline__ uint32_t smol_tab8 (uint32_t a, const uint8_t *lut_ld
 #endif
 }
 
-/* value of `v' in the NEXT lane of this lane's quad (lane 3 of a quad: its own): one DPP move */
-__device__ __forceinline__ uint32_t smol_quad_next (uint32_t v)
-{
-#ifdef SMOL_KERNEL_EMU
-    return smol_shfl_idx (v, (threadIdx.x & 3u) == 3u ? threadIdx.x : threadIdx.x + 1u);
-#else
-    return (uint32_t) __builtin_amdgcn_mov_dpp ((int) v, 0xF9 /* quad_perm:[1,2,3,3] */, 0xf, 0xf, true);
-#endif
-}
-
 /* one tap on a 16-bit half (HI: the upper one) of packed pixels p and q, weights W = F | (256 - F) << 16:
  * p * F + q * (256 - F), not yet shifted (below 2^19 for 11-bit values) */
 template <int HI>

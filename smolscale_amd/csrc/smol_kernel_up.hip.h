@@ -269,25 +269,20 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
             {
                 /* 24-bit output (round 5): the lane's four pixels are twelve consecutive bytes -- three permutes cut the
                  * three dwords out of the four pixel words, an 8-byte and a 4-byte store at the pixels' own address (global
-                 * stores need no alignment on gfx950), the wave's 768 bytes back to back. Write-back: rows of 3 * w bytes
-                 * start anywhere in a line (see the note on partial lines above). 1920 x 1080 RGBA -> RGB8 x4: k_tile's shifted
-                 * dword stores 111 us, this 97; x2.6 66 -> 54; unassociated -> BGR8 x4 on an odd width 158 -> 112; RGB8 sources
-                 * x2.6 67 -> 62, x4 equal, x4 odd 140 -> 123 (profiles/r05_up_rgb8.txt). */
+                 * stores need no alignment on gfx950), the wave's 768 bytes back to back. 1920 x 1080 RGBA -> RGB8 x4: k_tile's shifted
+                 * dword stores 111 us, this 86; x2.6 66 -> 55; unassociated -> BGR8 x4 on an odd width 158 -> 100; RGB8 sources
+                 * x2.6 67 -> 65, x4 110 -> 87, x4 odd 140 -> 100, x8 100 -> 75 (profiles/r05_up_rgb8.txt). */
                 const uint32_t w0 = __builtin_amdgcn_perm (hi [0], lo [0], J.up_perm), w1 = __builtin_amdgcn_perm (hi [1], lo [1], J.up_perm);
                 const uint32_t w2 = __builtin_amdgcn_perm (hi [2], lo [2], J.up_perm), w3 = __builtin_amdgcn_perm (hi [3], lo [3], J.up_perm);
                 const uint32_t d0 = __builtin_amdgcn_perm (w1, w0, 0x04020100u);
                 const uint32_t d1 = __builtin_amdgcn_perm (w2, w1, 0x05040201u);
                 const uint32_t d2 = __builtin_amdgcn_perm (w3, w2, 0x06050402u);
-                gbyte *o3 = gptr (out_row) + (size_t) xl * 3;
-#ifdef SMOL_KERNEL_EMU
-                const uint32_t d [3] = { d0, d1, d2 };
-                __builtin_memcpy (o3, d, 12);
-#else
-                /* (through the wave's LDS, so that the 768 bytes leave as ONE 16-byte store on 48 lanes: slower -- x4 107
-                 * against 97 us, RGB8 sources 124 against 110; profiles/r05_up_rgb8.txt) */
-                *reinterpret_cast<SMOL_AS_GLOBAL u32x2a1 *> (o3) = u32x2a1 { d0, d1 };
-                *reinterpret_cast<SMOL_AS_GLOBAL u32a1 *> (o3 + 8) = d2;
-#endif
+                /* streaming stores: the kernel is bound by them (x4: 111 us write-back, 86 streaming; x8 92 -> 75; x3 66 ->
+                 * 62; x2.6 on an odd width 62 -> 65). Tried and not kept: write-back for the lanes that touch the run's first
+                 * or last 128-byte line, as the 16-byte form above does (99-103 us at x4); 16-byte stores instead -- through
+                 * the wave's LDS on 48 lanes (107 against 97 write-back), or within each quad of lanes by three DPP moves
+                 * (128 against 97); one unaligned dword load per 24-bit source pixel (no difference) */
+                store_out96_nt (gptr (out_row) + (size_t) xl * 3, d0, d1, d2);
             }
             else
             {

@@ -1204,6 +1204,17 @@ typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 typedef u32x4 u32x4a4 __attribute__ ((aligned (4)));       /* a 16-byte load unit on a 4-byte boundary (cropped images) */
 typedef uint32_t u32a1 __attribute__ ((aligned (1)));      /* a dword at any byte address (global memory needs no alignment on gfx950) */
 typedef uint32_t u32x2a1 __attribute__ ((ext_vector_type (2), aligned (1)));
+
+/* value of `v' in the NEXT lane of this lane's quad (lane 3 of a quad: its own): one DPP move */
+__device__ __forceinline__ uint32_t smol_quad_next (uint32_t v)
+{
+#ifdef SMOL_KERNEL_EMU
+    return smol_shfl_idx (v, (threadIdx.x & 3u) == 3u ? threadIdx.x : threadIdx.x + 1u);
+#else
+    return (uint32_t) __builtin_amdgcn_mov_dpp ((int) v, 0xF9 /* quad_perm:[1,2,3,3] */, 0xf, 0xf, true);
+#endif
+}
+
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
 
 /* 16-byte NON-TEMPORAL output store on a dword-aligned address (k_up, bound by its stores: aligned rows 92 us
@@ -1240,6 +1251,21 @@ __device__ __forceinline__ void store_out128_nt (gbyte *p, u32x4 v)
     __builtin_memcpy (p, &v, 16);
 #else
     asm volatile ("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v" (p), "v" (v) : "memory");
+#endif
+}
+
+/* twelve bytes at any address as an 8-byte and a 4-byte NON-TEMPORAL store (k_up's 24-bit rows). The builtin, not an asm
+ * statement: the compiler then addresses the row as scalar base + 32-bit lane offset, which the asm forms (a 64-bit
+ * address per lane) lose 5-10 % to (profiles/r05_up_rgb8.txt). Never beside a plain store on the other side of a branch
+ * (see store_nt128). */
+__device__ __forceinline__ void store_out96_nt (gbyte *p, uint32_t d0, uint32_t d1, uint32_t d2)
+{
+#if defined (SMOL_KERNEL_EMU)
+    const uint32_t d [3] = { d0, d1, d2 };
+    __builtin_memcpy (p, d, 12);
+#else
+    __builtin_nontemporal_store (u32x2a1 { d0, d1 }, reinterpret_cast<SMOL_AS_GLOBAL u32x2a1 *> (p));
+    __builtin_nontemporal_store (d2, reinterpret_cast<SMOL_AS_GLOBAL u32a1 *> (p + 8));
 #endif
 }
 
