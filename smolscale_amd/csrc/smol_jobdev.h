@@ -723,6 +723,15 @@ lind_span (const JobDev &d, uint32_t w)
 
 inline bool lind_narrow (const JobDev &d) { return d.halv_h >= 1 && d.group_rows <= 64; }
 
+/* k_lind with streaming stores (a kernel of its own: smol_kernel_lind.hip.h, lind3_body): bilinear magnification on both axes
+ * into rows that start on 64-byte boundaries */
+inline bool
+lind_nt (const JobDev &d)
+{
+    return d.out_wt && d.halv_h == 0 && d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR
+           && d.step_x < ((uint64_t) 1 << 32) && d.step_y < ((uint64_t) 1 << 32) && !tune_env ("SMOL_NO_LIND_NT");
+}
+
 inline uint32_t
 lind_pick_width (const JobDev &d, bool fused = false)
 {

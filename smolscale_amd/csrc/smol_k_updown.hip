@@ -29,6 +29,15 @@ launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
             hipLaunchKernelGGL ((smolhip::k_lind_one<HX, IN, HX >= 1>), grid, block, lds, s, rep);
         return;
     }
+    /* magnification on both axes into rows that start on 64-byte boundaries: the kernel with streaming stores */
+    if (HX == 0 && smolhip::dispatch::lind_nt (rep))
+    {
+        if (jobs_dev)
+            hipLaunchKernelGGL ((smolhip::k_lind_batch<0, IN, false, true>), grid, block, lds, s, jobs_dev);
+        else
+            hipLaunchKernelGGL ((smolhip::k_lind_one<0, IN, false, true>), grid, block, lds, s, rep);
+        return;
+    }
     if (jobs_dev)
         hipLaunchKernelGGL ((smolhip::k_lind_batch<HX, IN>), grid, block, lds, s, jobs_dev);
     else

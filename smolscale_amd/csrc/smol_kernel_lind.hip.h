@@ -49,7 +49,7 @@ enum : int { LIND_FUSED = 0, LIND_H = 1, LIND_V = 2 };
 /* TMP8 (passes of the W32 flavour only): the intermediate pixel is 8 bytes of 16-bit channels -- what k_boxh writes and
  * k_boxv reads (premul16 without sRGB: every value fits 16 bits) -- instead of four 32-bit channels (16 bytes) */
 /* NARROW (chosen per job at the entry, one or two halvings): tiles of at most 64 columns */
-template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false>
+template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false, bool NT = false>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
 {
@@ -144,6 +144,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * PXB;          /* byte offset in the LDS row */
 
     /* ---- vertical schedule: sample k of the tile in lane k & 63 of sched [k >> 6] --- */
+    constexpr bool nt_out = NT;                                     /* (streaming stores: a kernel of its own, see lind3_body) */
     const uint32_t hv = J.halv_v;
     const uint32_t nsy = 1u << hv;
     const uint32_t jy0 = (J.first_row + yrel0) << hv;
@@ -511,7 +512,12 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                         if (ok [c])
                         {
                             if (J.bpp_out == 4 && J.out_dword_ok)
-                                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;     /* (plain: the kernel is bound by its arithmetic) */
+                            {
+                                if (nt_out)
+                                    store_nt32_at (out_row, xc [c] * 4u, w);
+                                else
+                                    *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;
+                            }
                             else
                                 wide_store_word (J, out_row, xc [c], w);
                         }
@@ -645,7 +651,7 @@ __device__ __forceinline__ uint32_t tap16_half (uint32_t p, uint32_t q, uint32_t
 #endif
 }
 
-template <int HX, bool NARROW>
+template <int HX, bool NARROW, bool NT = false>
 __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                             const uint32_t lane, const uint32_t tile)
 {
@@ -815,6 +821,12 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
 #pragma unroll
     for (int c = 0; c < CPL; c++)
         q_full [c] = xc [c] - qj + 3u < xn;                         /* the quad's last pixel is inside the tile */
+    /* NT: streaming stores, for magnifications on both axes whose output rows start on 64-byte boundaries (dispatch::lind_nt):
+     * gamma-correct x2 358 -> 334 us, x1.1 151 -> 138, RGB8 x4 167 -> 158. A kernel of its own: minifications gain nothing
+     * (within 1 %), rows that start anywhere lose (x2.6 on an odd width 99 -> 104: the partial lines at both ends of every
+     * row), and as a run-time choice in the common kernel the branch alone cost the arithmetic-bound rows 1-5 %
+     * (profiles/r05_lind_nt.txt). */
+    constexpr bool nt_out = NT;
     const LutLds lut (lut_lds, LUT_AT_LDS_0);
     const WidePack<WP_LIN_O> wp (Jp, lut);                          /* (its byte selectors; WP_LIN_Q's are the same) */
     const bool quirk = wide_pack_kind (J) == WP_LIN_Q;
@@ -897,7 +909,10 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
 #ifdef SMOL_KERNEL_EMU
                                 __builtin_memcpy (out_row + (size_t) xc [c] * 3 + qj, &d, 4);
 #else
-                                *reinterpret_cast<SMOL_AS_GLOBAL u32a1 *> (out_row + (xc [c] * 3u + qj)) = d;
+                                if (nt_out)
+                                    store_nt32_at (out_row, xc [c] * 3u + qj, d);
+                                else
+                                    *reinterpret_cast<SMOL_AS_GLOBAL u32a1 *> (out_row + (xc [c] * 3u + qj)) = d;
 #endif
                             }
                         }
@@ -907,7 +922,12 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
                     else if (ok [c])
                     {
                         if (J.out_dword_ok)
-                            *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;
+                        {
+                            if (nt_out)
+                                store_nt32_at (out_row, xc [c] * 4u, w);
+                            else
+                                *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;
+                        }
                         else
                             wide_store_word (J, out_row, xc [c], w);
                     }
@@ -949,16 +969,16 @@ __device__ __forceinline__ uint32_t lind_wave_lds (bool w32, bool narrow = false
 /* 4 waves per workgroup share one LDS copy of the tables, each wave works on its own tile in its own LDS region */
 /* NARROW: the one-column flavour, a kernel of its own (k_lind_batch<HX, IN, true>; as a second body inside the common
  * kernel it cost the wide tiles 3-4 %, as k_boxh's 64-lane flavour did); the host picks it per job: dispatch::lind_narrow */
-template <int HX, bool IN24, bool W32, bool NARROW = false>
+template <int HX, bool IN24, bool W32, bool NARROW = false, bool NT = false>
 __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 {
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
     if (IN24 && !W32)
-        lind3_body<HX, NARROW> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+        lind3_body<HX, NARROW, NT> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
     else
-        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW, NT> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     /* (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same on every lane of a wave, and
      * without it everything derived from the tile index -- every loop bound, every "is this round needed" test --
@@ -970,10 +990,10 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
     uint8_t *tab_end = lds + ((LUT_LDS_BYTES + 15u) & ~15u);       /* (the host sizes the workgroup's LDS by the flavour too: down_lds_bytes) */
     if (IN24 && !W32)
     {
-        lind3_body<HX, NARROW> (J, tab_end + wave * lind_wave_lds (false, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+        lind3_body<HX, NARROW, NT> (J, tab_end + wave * lind_wave_lds (false, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
     }
     else
-        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW> (J, tab_end + wave * lind_wave_lds (W32, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW, NT> (J, tab_end + wave * lind_wave_lds (W32, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
 }
 
@@ -1058,19 +1078,19 @@ __device__ __forceinline__ void linv_dispatch (const JobDev &J, uint8_t *lds)
 
 #ifndef SMOL_KERNEL_EMU
 /* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels) */
-template <int HX, int IN, bool NARROW = false>
+template <int HX, int IN, bool NARROW = false, bool NT = false>
 __global__ void __launch_bounds__ (256)
 k_lind_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    lind_entry<HX, IN == 1, IN == 2, NARROW> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW, NT> (J, smol_dyn_lds);
 }
 
-template <int HX, int IN, bool NARROW = false>
+template <int HX, int IN, bool NARROW = false, bool NT = false>
 __global__ void __launch_bounds__ (256)
 k_lind_one (const JobDev J)
 {
-    lind_entry<HX, IN == 1, IN == 2, NARROW> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW, NT> (J, smol_dyn_lds);
 }
 
 /* (pass 1: jobs along blockIdx.z like k_boxh; pass 2: along blockIdx.y like k_boxv) */

@@ -1269,6 +1269,17 @@ __device__ __forceinline__ void store_out96_nt (gbyte *p, uint32_t d0, uint32_t 
 #endif
 }
 
+/* one dword at row + off (any byte offset), non-temporal. Only where the choice is a compile-time one (k_lind's NT
+ * flavour): beside a plain store on the other side of a run-time branch the compiler merges the two into one plain store. */
+__device__ __forceinline__ void store_nt32_at (gbyte *row, uint32_t off, uint32_t w)
+{
+#if defined (SMOL_KERNEL_EMU)
+    __builtin_memcpy (row + off, &w, 4);
+#else
+    __builtin_nontemporal_store (w, reinterpret_cast<SMOL_AS_GLOBAL u32a1 *> (row + off));
+#endif
+}
+
 /* workgroup -> (x, y, job) under the XCD-aware order (smol_jobdev.h: TileSwz) */
 __device__ __forceinline__ void tile_coords (const TileSwz &S, uint32_t &bx, uint32_t &by, uint32_t &bz)
 {

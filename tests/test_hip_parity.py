@@ -901,3 +901,25 @@ def test_magnification_into_24_bit_rows_through_k_up():
                                          src_misalign=k % 3, dst_misalign=(k + 1) % 4)
                 assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "device")
     assert seen >= 40
+
+
+def test_k_lind_streaming_store_flavour_on_aligned_magnified_rows():
+    """Round 5: magnification on both axes into rows that start on 64-byte boundaries runs k_lind's flavour with streaming
+    stores (k_lind_batch<0, IN, false, true>; dispatch::lind_nt): gamma-correct 32-bit and 24-bit sources, premul16 + gamma,
+    premul16 below x1.2, into 32-bit and 24-bit rows whose strides are multiples of 64 bytes -- host road, and device buffers
+    on 64-byte boundaries, whole images and row ranges."""
+    cases = [(0, 640, 360, 0, 1280, 720, 1), (8, 640, 360, 0, 1280, 720, 1), (8, 640, 360, 8, 1280, 720, 1), (9, 500, 300, 8, 1024, 411, 1),
+             (4, 640, 360, 4, 1280, 720, 1), (5, 500, 100, 6, 1008, 199, 1), (4, 1000, 400, 4, 1152, 461, 0), (0, 700, 300, 1, 768, 333, 1),
+             (1, 320, 200, 9, 1024, 801, 1)]
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in enumerate(cases):
+        assert (w_out * H.bpp(t_out)) % 64 == 0
+        assert sm.kernel_name(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)) == "k_lind_batch", (t_in, w_in, t_out, w_out)
+        sin = w_in * H.bpp(t_in) + (k % 3)
+        src = H.make_input(t_in, w_in, h_in, seed=70 + k, valid=bool(k & 1), stride=sin, pad=0)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin)
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, "host")
+        first, n = h_out // 4, h_out // 2
+        rb = w_out * H.bpp(t_out)
+        got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, first=first, n=n, src_misalign=k % 4, dst_misalign=0)
+        assert np.array_equal(got, want[first * rb:(first + n) * rb]), (t_in, w_in, h_in, t_out, w_out, h_out, "device")
