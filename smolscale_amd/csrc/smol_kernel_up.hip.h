@@ -74,6 +74,32 @@ __device__ __forceinline__ uint32_t up_mad (uint32_t d, uint32_t F2, uint32_t b)
     return as_u32 (as_u16x2 (d) * as_u16x2 (F2) + as_u16x2 (b));
 }
 
+/* the lane's four 32-bit pixels as one 16-byte store, the wave's kilobyte back to back (k_up, its premul16 flavour, k_upg).
+ * Rows that start on 64-byte boundaries: streaming. Rows that start anywhere in a 128-byte line: the lanes whose 16 bytes
+ * touch the run's first or last line store write-back, so that the two parts of a line -- the other comes from the
+ * neighbouring tile at another time -- meet in the L2, the whole lines in between keep streaming (the comment in up_body). */
+__device__ __forceinline__ void up_store16 (const JobDev &J, gbyte *out_row, uint32_t xl, uint32_t lane, u32x4 v)
+{
+    if (!J.out_wt)
+    {
+        const uint32_t a = (uint32_t) (uintptr_t) out_row + xl * 4u;
+        const uint32_t run = a - lane * 16u;
+        const uint32_t lo_b = (run + 127u) & ~127u, hi_b = (run + 1024u) & ~127u;
+        if (a < lo_b || a + 16u > hi_b)
+        {
+#ifdef SMOL_KERNEL_EMU
+            __builtin_memcpy (out_row + (size_t) xl * 4, &v, 16);
+#else
+            *reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (out_row + (size_t) xl * 4) = v;
+#endif
+        }
+        else
+            store_out128_nt (out_row + (size_t) xl * 4, v);
+    }
+    else
+        store_nt128 (out_row + (size_t) xl * 4, v);
+}
+
 template <int INK, int OUT>
 __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
 {
@@ -246,24 +272,7 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
                  * x3 149 -> 120, x4 268 -> 231; every lane write-back 123 / 141 / 174 / 282, write-through 147 / 164 / 206 / 390
                  * (profiles/r05_up_handover.txt). Distinct instructions -- an asm store and a plain one: the compiler
                  * merges two C stores that differ only in their cache policy. */
-                if (!J.out_wt)
-                {
-                    const uint32_t a = (uint32_t) (uintptr_t) out_row + xl * 4u;
-                    const uint32_t run = a - lane * 16u;
-                    const uint32_t lo_b = (run + 127u) & ~127u, hi_b = (run + 1024u) & ~127u;
-                    if (a < lo_b || a + 16u > hi_b)
-                    {
-#ifdef SMOL_KERNEL_EMU
-                        __builtin_memcpy (gptr (out_row) + (size_t) xl * 4, &v, 16);
-#else
-                        *reinterpret_cast<SMOL_AS_GLOBAL u32x4a4 *> (gptr (out_row) + (size_t) xl * 4) = v;
-#endif
-                    }
-                    else
-                        store_out128_nt (gptr (out_row) + (size_t) xl * 4, v);
-                }
-                else
-                store_nt128 (gptr (out_row) + (size_t) xl * 4, v);
+                up_store16 (J, gptr (out_row), xl, lane, v);
             }
             else if (OUT == OUT_ANY && full24 && UP_CPL == 4)
             {
@@ -492,7 +501,9 @@ __device__ __forceinline__ void up16_body (const JobDev &J, uint8_t *lds)
             if (fast)
             {
                 const u32x4 v = { o [0], o [1], o [2], o [3] };
-                store_nt128 (out_row + (size_t) xl * 4, v);
+                /* (round 5: write-back at the run's ends on rows that start anywhere -- premul16 x3 on an odd width 86 -> 75 us,
+                 * x4 76 -> 62, aligned rows and x2.6 unchanged: profiles/r05_up_rgb8.txt) */
+                up_store16 (J, out_row, xl, lane, v);
             }
             else
             {
@@ -783,6 +794,8 @@ __device__ __forceinline__ void upg_body (const JobDev &J, uint8_t *lds, const u
                 if (CPL == 4)
                 {
                     const u32x4 v4 = { wv [0], wv [1 % CPL], wv [2 % CPL], wv [3 % CPL] };
+                    /* (up_store16's write-back at the run's ends costs this flavour 6 % on aligned rows -- it lives at 127
+                     * registers --: 95 -> 101 us, profiles/r05_up_rgb8.txt) */
                     store_nt128 (gptr (out_row) + (size_t) xl * 4, v4);
                 }
                 else
