@@ -128,16 +128,18 @@ int smol_hip_plan_reserve (SmolHipPlan *plan, uint32_t images_in_flight);
  * between rows are left untouched). Thread-safe on one plan. Synchronous.
  *
  * ANY host memory works, as with the reference (smolscale-generic.c:1613-1642 reads and writes
- * the caller's rows with plain loads and stores). The strip is cut into chunks of output rows
- * that flow through three side streams of a staging lane -- H2D of chunk k+1, the kernels of
- * chunk k and D2H of chunk k-1 run concurrently (events order them; nothing else synchronises
- * until the end). Page-locked memory (smol_hip_host_alloc, smol_hip_host_register, hipHostMalloc)
- * is handed to the DMA engines in place. PAGEABLE memory is never shown to the HIP runtime: the
- * library's copy threads move it through a ring of page-locked buffers owned by the lane (in and
- * out), so no page of the caller's heap is ever pinned or touched by the GPU. A call that moves
- * at most SMOL_HIP_ZEROCOPY_KB (default 256) KiB skips the DMA engines altogether: the kernel
- * reads and writes the ring across PCIe -- one launch and one wait per call, for callers that
- * ask for their rows a few at a time (the reference's own outer loop, smolscale.c:507-546). */
+ * the caller's rows with plain loads and stores). Since round 5 the kernel works on page-locked
+ * HOST rows across PCIe (the "mapped road"; no DMA engine): page-locked memory (smol_hip_host_alloc,
+ * smol_hip_host_register, hipHostMalloc) is read and written IN PLACE by one launch over the whole
+ * strip; PAGEABLE memory is never shown to the HIP runtime -- the library's copy threads move it
+ * through a ring of page-locked buffers owned by the lane (in and out), in chunks of about 4 MB
+ * whose kernels follow one another on one stream, so no page of the caller's heap is ever pinned or
+ * touched by the GPU. Either side on its own. SMOL_HIP_MAPPED=0 brings back the road of rounds
+ * 1-4: chunks of output rows through three side streams of a staging lane -- H2D of chunk k+1, the
+ * kernels of chunk k and D2H of chunk k-1 concurrently, page-locked memory handed to the DMA engines
+ * in place. A call that moves at most SMOL_HIP_ZEROCOPY_KB (default 256) KiB goes through ONE ring
+ * slot whatever its memory is -- one launch and one wait per call, for callers that ask for their
+ * rows a few at a time (the reference's own outer loop, smolscale.c:507-546). */
 int smol_hip_scale_rows_host (SmolHipPlan *plan,
                               const void *pixels_in_host, uint32_t rowstride_in,
                               void *dest_host, uint32_t rowstride_out,
@@ -185,7 +187,7 @@ int smol_hip_host_unregister (void *host_ptr);
  * get buffers that take the zero-copy road. */
 int smol_hip_host_alloc (uint64_t n_bytes, void **host_ptr_out);
 int smol_hip_host_free (void *host_ptr);
-/* 1 when EVERY byte of the range is page-locked (so that the host entries hand it to the DMA engines in place), 0
+/* 1 when EVERY byte of the range is page-locked (so that the host entries let the kernel work on it in place), 0
  * when any part of it is pageable or cannot be told (it then travels through the library's rings). The range is
  * walked allocation by allocation -- two registrations with a pageable gap between them are pageable. */
 int smol_hip_host_range_is_pinned (const void *host_ptr, uint64_t n_bytes);
