@@ -614,7 +614,14 @@ up_setup (JobDev &d)
          * width 158 -> 100; RGB8 -> RGB8 x2.6 67 -> 65, x3 73 -> 63, x4 110 -> 87, x4 odd 140 -> 100, x8 100 -> 75:
          * profiles/r05_up_rgb8.txt) */
         const bool out24 = d.out3_ok && !tune_env ("SMOL_NO_UP_P3");
-        if ((d.tile_variant & 3u) != 0 && !out24)
+        /* (... and unassociated 32-bit output un-premultiplied in registers through an LDS copy of the inverse table, in the
+         * 16-byte store form, from x3.5: the multiplies make it arithmetic-bound -- premultiplied -> unassociated x2.25 58 ->
+         * 66 us and x2.6 74 -> 85 (k_tile stays), x3 equal, x4 154 -> 135, x4 on an odd width 166 -> 143, x8 129 -> 125:
+         * profiles/r05_up_rgb8.txt) */
+        const bool out_u4 = (d.tile_variant & 3u) == 1u /* OUT_U4 */ && d.out_vec16_ok && !tune_env ("SMOL_NO_UP_U4");
+        if ((d.tile_variant & 3u) != 0 && !out24 && !out_u4)
+            return false;
+        if (out_u4 && !tune_env ("SMOL_UP_ALWAYS") && (d.step_x > ((uint64_t) 2 << 32) / 7 || d.step_y > ((uint64_t) 2 << 32) / 7))
             return false;
         if (out24 && (d.step_x > ((uint64_t) 5 << 32) / 13 || d.step_y > ((uint64_t) 5 << 32) / 13))
             return false;
@@ -692,7 +699,8 @@ up_lds_bytes (const JobDev &d)
         return DOWN_LUT_BYTES_FWD + 4u * ((UPG_NSRC_HOST * d.span_px * (d.up_wide == 3 ? 16u : 8u) + 15u) & ~15u) + 16u;
     if (d.up_wide)
         return UP_NSRC_W_HOST * d.span_px * 8u + 1024u + 16u;       /* + the inverse table */
-    return UP_NSRC_HOST * d.span_px * 8u + 16u;
+    /* (unassociated output: + the inverse table behind the staged rows) */
+    return ((UP_NSRC_HOST * d.span_px * 8u + 15u) & ~15u) + (d.unassoc_out ? 1024u : 0u) + 16u;
 }
 
 /* tiles of the job, rounded up to a multiple of 8 (flavours 2-3 launch one workgroup per 4 tiles) */

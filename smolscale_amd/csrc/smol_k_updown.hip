@@ -86,9 +86,11 @@ launch_up_in (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds
         default:              launch_up_k<INK, smolhip::OUT_ANY> (jobs_dev, rep, grid, lds, s); break;
     }
 #else
-    /* (the shipped library: the 16-byte form, and 24-bit output as twelve bytes per lane) */
+    /* (the shipped library: the 16-byte form -- premultiplied or unassociated --, and 24-bit output as twelve bytes per lane) */
     if ((rep.tile_variant & 3u) == smolhip::OUT_ANY)
         launch_up_k<INK, smolhip::OUT_ANY> (jobs_dev, rep, grid, lds, s);
+    else if ((rep.tile_variant & 3u) == smolhip::OUT_U4)
+        launch_up_k<INK, smolhip::OUT_U4> (jobs_dev, rep, grid, lds, s);
     else
         launch_up_k<INK, smolhip::OUT_P4> (jobs_dev, rep, grid, lds, s);
 #endif

@@ -187,6 +187,15 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
             }
         }
     }
+    /* unassociated output (round 5): the inverse-alpha table behind the staged rows -- a look-up in global memory makes the
+     * compiler drain every store in flight in front of each row (k_tile's finding, smol_kernel_tile.hip.h tile_pack) */
+    uint32_t *inv_lds = reinterpret_cast<uint32_t *> (lds + ((UP_NSRC * J.span_px * 8u + 15u) & ~15u));
+    if (OUT == OUT_U4)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            inv_lds [i * 64 + lane] = smol_inv_p8_lut [i * 64 + lane];
+    }
     smol_wave_sync ();                                  /* one wave: LDS operations complete in order */
 
     /* ---- H: horizontal result of every (source row, column), one word each -------
@@ -274,6 +283,22 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
                  * merges two C stores that differ only in their cache policy. */
                 up_store16 (J, gptr (out_row), xl, lane, v);
             }
+            else if (OUT == OUT_U4 && interior)
+            {
+                /* unassociated 32-bit output: un-premultiplied in registers through the LDS copy of the table, then the
+                 * 16-byte store form */
+                uint32_t w [UP_CPL];
+#pragma unroll
+                for (int c = 0; c < UP_CPL; c++)
+                {
+                    Px2 o;
+                    o.lo = (lo [c] >> 8) & PAIR_MASK;
+                    o.hi = (hi [c] >> 8) & PAIR_MASK;
+                    w [c] = tile_pack<OUT_U4> (J, o, inv_lds);
+                }
+                const u32x4 v = { w [0], w [1], w [2], w [3] };
+                up_store16 (J, gptr (out_row), xl, lane, v);
+            }
             else if (OUT == OUT_ANY && full24 && UP_CPL == 4)
             {
                 /* 24-bit output (round 5): the lane's four pixels are twelve consecutive bytes -- three permutes cut the
@@ -302,7 +327,7 @@ __device__ __forceinline__ void up_body (const JobDev &J, uint8_t *lds)
                     o [c].lo = (lo [c] >> 8) & PAIR_MASK;
                     o [c].hi = (hi [c] >> 8) & PAIR_MASK;
                 }
-                tile_store_cols<OUT, UP_CPL, true> (J, out_row, xl, xn, interior, full24, o);
+                tile_store_cols<OUT, UP_CPL, true> (J, out_row, xl, xn, interior, full24, o, OUT == OUT_U4 ? inv_lds : smol_inv_p8_lut);
             }
             out_row += J.dst_stride;
             r++;

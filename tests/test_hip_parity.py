@@ -923,3 +923,33 @@ def test_k_lind_streaming_store_flavour_on_aligned_magnified_rows():
         rb = w_out * H.bpp(t_out)
         got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, first=first, n=n, src_misalign=k % 4, dst_misalign=0)
         assert np.array_equal(got, want[first * rb:(first + n) * rb]), (t_in, w_in, h_in, t_out, w_out, h_out, "device")
+
+
+def test_magnification_into_unassociated_rows_through_k_up():
+    """Round 5: k_up with unassociated 32-bit output from x3.5 -- un-premultiplied in registers through an LDS copy of the
+    inverse table, the lane's four pixels as one 16-byte store: premultiplied and 24-bit sources into all four unassociated
+    orders, aligned and odd widths, padded rows, partial tiles, row ranges, translucent and zero alpha."""
+    shapes = [(480, 270, 1920, 1080), (333, 100, 1201, 361), (100, 40, 357, 143), (64, 20, 512, 161)]
+    k = seen = 0
+    for (w_in, h_in, w_out, h_out) in shapes:
+        for t_in in (0, 1, 2, 3, 8, 9):
+            for t_out in (4, 5, 6, 7):
+                k += 1
+                if (k % 2) and w_in * h_in > 60_000:
+                    continue
+                job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+                assert not job.wide
+                seen += sm.kernel_name(job) == "k_up_batch"
+                sin = w_in * H.bpp(t_in) + 4 * (k % 3)
+                sout = w_out * 4 + 4 * (k % 2)
+                src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+                if t_in < 4 and k % 3 == 0:
+                    src[::7] = 0                                   # patches of zero bytes: alpha 0 among them
+                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                rb = w_out * 4
+                assert np.array_equal(H.rows_view(got, h_out, rb, sout), H.rows_view(want, h_out, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "host")
+                first, n = h_out // 3, max(1, h_out // 2)
+                got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first=first, n=n)
+                assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "device")
+    assert seen >= 40
