@@ -625,3 +625,38 @@ def test_dma_road_still_serves_when_the_mapped_road_is_switched_off():
     env = dict(os.environ, SMOL_HIP_MAPPED="0")
     run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert "ALL-OK" in run.stdout, (run.stdout[-2000:], run.stderr[-2000:])
+
+
+def test_resident_source_bands_in_flight_for_page_locked_sources():
+    """Under the resident-source promise a page-locked source is read ahead ASYNCHRONOUSLY: two bands, the next one computed in
+    place on the caller's rows (one launch left in flight) while calls are served from the current one. Callers with a constant
+    step, with steps that change from call to call (calls that straddle the seam of two bands), that jump back, that stop early
+    and destroy the plan with a band still in flight -- every row must equal the oracle's."""
+    rng = random.Random(31)
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in ((0, 1920, 1080, 0, 1280, 720, 0), (8, 1500, 900, 9, 700, 420, 1),
+                                                           (4, 800, 500, 5, 1600, 1000, 0), (0, 2048, 2048, 2, 200, 200, 0)):
+        bi, bo = H.bpp(t_in), H.bpp(t_out)
+        raw = H.make_input(t_in, w_in, h_in, seed=5, valid=True, pad=16)
+        want = H.oracle_scale(raw, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        pin = sm.PinnedArray(raw.size)
+        pin.array[:] = raw
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        rb = w_out * bo
+        for mode in ("constant 1", "constant 64", "random steps", "jump back", "stop early"):
+            plan = sm.HipPlan(job, 0)
+            plan.resident_source(True)
+            dst = np.zeros(h_out * rb, np.uint8)
+            y = 0
+            jumped = False
+            while y < h_out:
+                n = {"constant 1": 1, "constant 64": 64}.get(mode, rng.choice([1, 2, 7, 13, 40, 64, 100]))
+                n = min(n, h_out - y)
+                plan.scale_rows_host(pin.array, w_in * bi, dst[y * rb:], rb, y, n)
+                assert np.array_equal(dst[y * rb:(y + n) * rb], want[y * rb:(y + n) * rb]), (mode, t_in, w_out, y, n)
+                y += n
+                if mode == "jump back" and not jumped and y > h_out // 2:
+                    y, jumped = h_out // 5, True
+                if mode == "stop early" and y > h_out // 3:
+                    break
+            plan.destroy()                                  # (a band may still be in flight)
+        pin.free()
