@@ -1458,9 +1458,8 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
     {
         if (!c->valid || c->src != src || c->rowstride_in != rowstride_in || first < c->first || first + n > c->first + c->n)
             return false;
-        if (!resident
-            && !rows_equal (src + (size_t) a * rowstride_in, rowstride_in, c->host + (size_t) (a - c->r0) * c->src_pitch, c->src_pitch,
-                            in_row, b - a + 1))
+        if (!rows_equal (src + (size_t) a * rowstride_in, rowstride_in, c->host + (size_t) (a - c->r0) * c->src_pitch, c->src_pitch,
+                         in_row, b - a + 1))
         {
             c->valid = false;           /* the caller rewrote its source: what was computed ahead is stale */
             return false;
@@ -1493,7 +1492,7 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
 
     /* a band of the rows from `first' on */
     const size_t per_out_row = moved / n + 1;
-    const size_t want = resident ? kn.band_bytes_resident : kn.band_bytes;
+    const size_t want = kn.band_bytes;                  /* (the promise's bands: read_ahead_resident) */
     uint64_t rows = want / per_out_row;
     if (rows < 2ull * n)
         return 0;                       /* rows so fat that a band is hardly more than the call itself */
@@ -1504,9 +1503,8 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
     uint32_t r0 = 0, r1 = 0;
     if (smol_hip_input_row_range (&job, first, (uint32_t) rows, &r0, &r1))
         return 0;
-    /* (under the promise nothing is ever compared: the band is computed from the caller's rows where they are) */
     const size_t src_pitch = align_up (in_row, 16), out_pitch = out_row;
-    const size_t src_bytes = resident ? 0 : ((size_t) r1 - r0 + 1) * src_pitch + 256, out_bytes = (size_t) rows * out_pitch + 256;
+    const size_t src_bytes = ((size_t) r1 - r0 + 1) * src_pitch + 256, out_bytes = (size_t) rows * out_pitch + 256;
     if (c->host_bytes < src_bytes + out_bytes)
     {
         if (hipSetDevice (plan->device) != hipSuccess)
@@ -1520,13 +1518,12 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
         }
     }
     c->valid = false;
-    if (!resident)
-        copy_rows (RowCopy { c->host, src_pitch, src + (size_t) r0 * rowstride_in, rowstride_in, in_row, r1 - r0 + 1, true });
+    copy_rows (RowCopy { c->host, src_pitch, src + (size_t) r0 * rowstride_in, rowstride_in, in_row, r1 - r0 + 1, true });
 
     Strip st;
     st.plan = plan;
-    st.src = resident ? src : c->host - (size_t) r0 * src_pitch;    /* (row 0 of the virtual image; only rows r0 .. r1 are ever read) */
-    st.rowstride_in = resident ? rowstride_in : (uint32_t) src_pitch;
+    st.src = c->host - (size_t) r0 * src_pitch;     /* (row 0 of the virtual image; only rows r0 .. r1 are ever read) */
+    st.rowstride_in = (uint32_t) src_pitch;
     st.dest = c->host + src_bytes;
     st.rowstride_out = (uint32_t) out_pitch;
     st.first = first;
