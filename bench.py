@@ -120,7 +120,7 @@ def cpu_baseline(seconds_budget=12.0):
                 fn(ctypes.byref(job), src.ctypes.data, W_IN * 4, d2.ctypes.data, W_OUT * 4, 0, H_OUT)
                 k += 1
             info["library_cpu_backend"] = {"Mpix_s": round(k * W_OUT * H_OUT / (time.perf_counter() - t0) / 1e6, 1),
-                                           "threads": min(32, n_threads), "bit_exact_vs_reference": bool(np.array_equal(d2[:W_OUT * H_OUT * 4], want))}
+                                           "threads": min(24, n_threads), "bit_exact_vs_reference": bool(np.array_equal(d2[:W_OUT * H_OUT * 4], want))}
         except Exception as e:                      # noqa: BLE001
             info["library_cpu_backend"] = {"error": repr(e)}
     else:

@@ -3,7 +3,7 @@
  * AVX2 / AVX-512BW (chosen at run time) in every job class -- the 64bpp class in packed 16-bit lanes (the reference's
  * AVX2 speed per thread in the BASELINE class), the 128bpp class in 32-bit lanes --, plain 32-bit-lane code on CPUs
  * without AVX2 and under SMOL_CPU_SIMD=0; a call of enough rows is cut into strips of output rows over
- * the host cores (SMOL_CPU_THREADS, default the online cores up to 32; 1 = stay on the calling thread). It is what
+ * the host cores (SMOL_CPU_THREADS, default the online cores up to 24; 1 = stay on the calling thread). It is what
  * smol_scale_*() runs on when the caller selects it with SMOL_BACKEND=cpu (or SMOL_BACKEND=auto on a machine without
  * a usable GPU); the default backend stays HIP, and a missing GPU then stays a loud failure. */
 

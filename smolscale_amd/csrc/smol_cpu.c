@@ -1560,7 +1560,7 @@ strip_scale_rows (const SmolCpuPlan *plan,
 /* ---- a call's rows over the host cores ------------------------------------------------------------------
  * Output rows are independent given the source (the reference's own harness cuts an image into one strip per
  * worker: test.c:838-883): a call of enough rows is cut into strips that run on a small persistent pool, the
- * calling thread taking its share. SMOL_CPU_THREADS = threads per call (default: the online cores, at most 32;
+ * calling thread taking its share. SMOL_CPU_THREADS = threads per call (default: the online cores, at most 24;
  * 1 = never leave the calling thread). Each strip re-filters the one or two source rows it shares with its
  * neighbour -- a bilinear halo -- and nothing else is shared. */
 #include <pthread.h>
@@ -1633,8 +1633,10 @@ cpu_threads_wanted (void)
         long v = e && *e ? strtol (e, NULL, 10) : 0;
         if (v <= 0)
         {
+            /* (on the GPU box's 256 hardware threads: 24 threads 0.48 ms per 4096^2 -> 1024^2 frame, 32: 0.54, 64: 1.31,
+             * 128: 1.76 -- waking helpers costs more than they carry; profiles/r05_cpu_backend_classes.txt) */
             v = sysconf (_SC_NPROCESSORS_ONLN);
-            if (v > 32) v = 32;
+            if (v > 24) v = 24;
         }
         if (v < 1) v = 1;
         if (v > 256) v = 256;
@@ -1666,6 +1668,9 @@ smol_cpu_plan_scale_rows (const SmolCpuPlan *plan,
     want = cpu_threads_wanted ();
     if (want > n_rows / 4)
         want = n_rows / 4;
+    /* at least 128 K pixels of work per thread (640 x 480 -> 320 x 240: 3 threads 0.04 ms, 32 threads 0.12) */
+    if ((uint64_t) want > work / 131072u)
+        want = (uint32_t) (work / 131072u);
     if (want < 2 || work < 262144)
         return strip_scale_rows (plan, pixels_in, rowstride_in, dest, rowstride_out, first_row, n_rows);
 
