@@ -659,7 +659,10 @@ up_setup (JobDev &d)
      * flavours are bound by arithmetic per tile and keep the tall tiles. */
     /* (... below x2.75 twelve: a tile's two halo rows of horizontal work are shared by more output rows -- x2.4 83 -> 77 us,
      * x2.6 91 -> 88, odd widths 95 -> 87 and 99 -> 97; from x2.8 eight rows are ahead, 95 against 98: profiles/r05_up_handover.txt) */
-    const uint64_t flat_rows = (flavour == 0 && d.step_y > ((uint64_t) 4 << 32) / 11) ? 12 : 8;
+    /* (unassociated output is bound by its multiplies, not by its stores, and copies the inverse table into LDS once per tile:
+     * twenty rows -- x4 128 -> 115 us, on an odd width 138 -> 127, x8 118 -> 105: profiles/r05_up_rgb8.txt) */
+    const uint64_t flat_rows = (flavour == 0 && (d.tile_variant & 3u) == 1u /* OUT_U4 */) ? 20
+                             : (flavour == 0 && d.step_y > ((uint64_t) 4 << 32) / 11) ? 12 : 8;
     if (flavour == 0 && tr > flat_rows)
         tr = flat_rows;
     if (flavour != 0 && tr > 16)
