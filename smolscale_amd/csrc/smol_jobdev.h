@@ -615,13 +615,13 @@ up_setup (JobDev &d)
          * profiles/r05_up_rgb8.txt) */
         const bool out24 = d.out3_ok && !tune_env ("SMOL_NO_UP_P3");
         /* (... and unassociated 32-bit output un-premultiplied in registers through an LDS copy of the inverse table, in the
-         * 16-byte store form, from x3.5: the multiplies make it arithmetic-bound -- premultiplied -> unassociated x2.25 58 ->
-         * 66 us and x2.6 74 -> 85 (k_tile stays), x3 equal, x4 154 -> 135, x4 on an odd width 166 -> 143, x8 129 -> 125:
-         * profiles/r05_up_rgb8.txt) */
+         * 16-byte store form, from x3.2: the multiplies make it arithmetic-bound -- premultiplied -> unassociated x2.25 58 ->
+         * 67 us and x2.6 77 -> 83 (k_tile stays), x3 equal, x3.3 108 -> 92, x4 154 -> 115, x4 on an odd width 166 -> 127,
+         * x8 129 -> 105: profiles/r05_up_rgb8.txt) */
         const bool out_u4 = (d.tile_variant & 3u) == 1u /* OUT_U4 */ && d.out_vec16_ok && !tune_env ("SMOL_NO_UP_U4");
         if ((d.tile_variant & 3u) != 0 && !out24 && !out_u4)
             return false;
-        if (out_u4 && !tune_env ("SMOL_UP_ALWAYS") && (d.step_x > ((uint64_t) 2 << 32) / 7 || d.step_y > ((uint64_t) 2 << 32) / 7))
+        if (out_u4 && !tune_env ("SMOL_UP_ALWAYS") && (d.step_x > ((uint64_t) 5 << 32) / 16 || d.step_y > ((uint64_t) 5 << 32) / 16))
             return false;
         if (out24 && (d.step_x > ((uint64_t) 5 << 32) / 13 || d.step_y > ((uint64_t) 5 << 32) / 13))
             return false;

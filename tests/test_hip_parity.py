@@ -926,7 +926,7 @@ def test_k_lind_streaming_store_flavour_on_aligned_magnified_rows():
 
 
 def test_magnification_into_unassociated_rows_through_k_up():
-    """Round 5: k_up with unassociated 32-bit output from x3.5 -- un-premultiplied in registers through an LDS copy of the
+    """Round 5: k_up with unassociated 32-bit output from x3.2 -- un-premultiplied in registers through an LDS copy of the
     inverse table, the lane's four pixels as one 16-byte store: premultiplied and 24-bit sources into all four unassociated
     orders, aligned and odd widths, padded rows, partial tiles, row ranges, translucent and zero alpha."""
     shapes = [(480, 270, 1920, 1080), (333, 100, 1201, 361), (100, 40, 357, 143), (64, 20, 512, 161)]
