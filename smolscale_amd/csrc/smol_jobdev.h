@@ -609,8 +609,8 @@ up_setup (JobDev &d)
          * RGB8 -> RGB8 179 / 120 us, RGBA -> RGB8 154 / 113, premultiplied -> unassociated 230 / 153; 3840x2160 -> x2, 6 frames,
          * 401 / 185, 287 / 184, 561 / 241; x8 151 / 101, 178 / 125 (profiles/r04_up_vs_lind.txt). 24-bit sources into
          * premultiplied 32-bit: k_up from x2.6 (x2 243 / 181, x2.6 118 / 117, x3 116 / 141, x4 91 / 99) */
-        /* (round 5: 24-bit output leaves k_up as the lane's twelve bytes -- an 8-byte and a 4-byte streaming store -- from x2.6:
-         * RGBA -> RGB8 x2.25 equal, x2.6 66 -> 55 us, x3 68 -> 62, x4 111 -> 86, x8 100 -> 75, unassociated -> BGR8 x4 on an odd
+        /* (round 5: 24-bit output leaves k_up as the lane's twelve bytes -- an 8-byte and a 4-byte streaming store:
+         * RGBA -> RGB8 x2.25 equal, x2.4 odd 58 -> 49, x2.6 66 -> 55 us, x3 68 -> 62, x4 111 -> 86, x8 100 -> 75, unassociated -> BGR8 x4 on an odd
          * width 158 -> 100; RGB8 -> RGB8 x2.6 67 -> 65, x3 73 -> 63, x4 110 -> 87, x4 odd 140 -> 100, x8 100 -> 75:
          * profiles/r05_up_rgb8.txt) */
         const bool out24 = d.out3_ok && !tune_env ("SMOL_NO_UP_P3");
@@ -623,8 +623,8 @@ up_setup (JobDev &d)
             return false;
         if (out_u4 && !tune_env ("SMOL_UP_ALWAYS") && (d.step_x > ((uint64_t) 5 << 32) / 16 || d.step_y > ((uint64_t) 5 << 32) / 16))
             return false;
-        if (out24 && (d.step_x > ((uint64_t) 5 << 32) / 13 || d.step_y > ((uint64_t) 5 << 32) / 13))
-            return false;
+        /* (24-bit sources keep their own handover at x2.6, below; 32-bit sources into 24-bit rows take k_up from x2.25 like
+         * everything else: x2.25 on an aligned width equal (46 us), x2.4 on an odd one 58 -> 49) */
         if (d.bpp_in == 3 && (d.step_x > ((uint64_t) 5 << 32) / 13 || d.step_y > ((uint64_t) 5 << 32) / 13))
             return false;
     }
