@@ -66,7 +66,7 @@ struct JobDev
     /* k_tile geometry (filled by tile_setup) */
     uint8_t tile_aligned4;         /* every staged pixel sits on a 4-byte LDS boundary   */
     uint8_t tile_variant;          /* tapsel << 4 | HM << 2 | OUT (smol_kernel_tile.hip.h) */
-    uint8_t tile_cpl;              /* adjacent output columns per lane (1 or 4)          */
+    uint8_t tile_cpl;              /* adjacent output columns per lane (1, 2 or 4)       */
     uint8_t tile_lpc;              /* lanes per output column (box: 1 or 8; k_boxh 128bpp class: also 16, 64) */
     uint8_t tile_band;             /* k_tile: deal tiles out in XCD bands (very wide images) */
     uint8_t tile_vm;               /* k_tile: vertical specialisation (TILE_VM_*): 0 decided at run time, 1 copy, 2 bilinear, 3 box */
@@ -211,9 +211,26 @@ tile_setup (JobDev &d)
         && d.bpp_out == 4 && ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0 && d.w_out >= 256
         && d.step_x < ((uint64_t) 115 << 32) / 100)                 /* per-sample step: ratio < 2.3 */
         d.tile_cpl = 4;
+    /* 24-bit sources behind one horizontal halving into dword-aligned 32-bit rows (a photograph into an RGBA buffer): TWO
+     * columns per lane and row groups of 3 KB -- the row loop's bookkeeping (42 of 118 us at ratio 2.5 by ablation:
+     * profiles/r05_tile_cpl2.txt) is shared by twice the pixels, and the smaller buffers keep 26 instead of 20 waves on a
+     * CU: 4000 x 3000 RGB8 -> RGBA ratio 2.1 156 -> 125 us, 2.5 125 -> 104, 3 96 -> 93, 3.8 92 -> 87. (32-bit sources:
+     * ratio 2.5 equal, 3 -2 %, 3.5 and beyond +4 %, unassociated sources +8 %: they keep one column.) */
+    bool two_cols = !d.wide && d.tile_cpl == 1 && d.bpp_in == 3 && d.filter_h == F_BILINEAR && d.halv_h == 1
+                    && d.filter_v == F_BILINEAR && d.bpp_out == 4 && d.out_dword_ok && d.w_out >= 128
+                    && !tune_env ("SMOL_NO_TILE_CPL2") && !tune_env ("SMOL_NO_TILE_VM");
+    if (two_cols)
+        d.tile_cpl = 2;
     if (const char *e = tune_env ("SMOL_TILE_CPL"))
         if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX)
+        {
+            two_cols = false;
             d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
+            /* two columns per lane exist for bilinear x bilinear into dword-aligned 32-bit rows */
+            if (atoi (e) == 2 && d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR && d.bpp_out == 4 && d.out_dword_ok
+                && d.w_out >= 128 && !tune_env ("SMOL_NO_TILE_VM"))
+                d.tile_cpl = 2;
+        }
     uint64_t cols = 64u * d.tile_cpl;
     uint32_t box_lpc = 1;
 
@@ -243,7 +260,7 @@ tile_setup (JobDev &d)
 
     d.span_px = (uint32_t) span_px;
     d.tile_single = 0;
-    uint32_t budget = TILE_LDS_BUDGET;
+    uint32_t budget = two_cols ? 3072u : TILE_LDS_BUDGET;
     if (const char *e = tune_env ("SMOL_TILE_LDS_BUDGET"))
         budget = (uint32_t) atoi (e);
 #ifdef SMOL_TUNING

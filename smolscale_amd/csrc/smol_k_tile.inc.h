@@ -89,6 +89,17 @@ launch_tile_ts (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t l
 
     using namespace smolhip;
 
+    if (rep.tile_cpl == 2)
+    {
+        /* two columns per lane (round 5): bilinear on both axes only (tile_setup) */
+        switch (hm)
+        {
+            case 1:  launch_tile_kv<TS, 1, 2, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+            case 2:  launch_tile_kv<TS, 2, 2, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+            default: launch_tile_kv<TS, 3, 2, TILE_VM_PAIR> (jobs_dev, rep, grid, lds, s); break;
+        }
+        return;
+    }
     if (rep.tile_cpl == 4 && rep.tile_vm == TILE_VM_PAIR)
     {
         switch (hm)

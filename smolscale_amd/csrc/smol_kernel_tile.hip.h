@@ -510,7 +510,21 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             return;
         }
     }
-    if (OUT == OUT_ANY && full24)
+    if (CPL == 2 && OUT != OUT_ANY)
+    {
+        /* two columns per lane (round 5): the pair as one 8-byte store on any dword-aligned row */
+        if (xl + 2 <= xn)
+        {
+            const u32x2 v = { tile_pack<OUT> (J, o [0], inv_tab), tile_pack<OUT> (J, o [1 % CPL], inv_tab) };
+#ifdef SMOL_KERNEL_EMU
+            __builtin_memcpy (gptr (rowp) + (size_t) xl * 4, &v, 8);
+#else
+            *reinterpret_cast<SMOL_AS_GLOBAL u32x2a4 *> (gptr (rowp) + (size_t) xl * 4) = v;
+#endif
+            return;
+        }
+    }
+    if (OUT == OUT_ANY && full24 && CPL != 2)
     {
         /* A full-width tile of 24-bit pixels is one run of 64 * CPL * 3 bytes. It leaves as whole ALIGNED dwords
          * whatever byte the row starts on: m = (address of the run) & 3 is the same for every lane, the lanes cut the
@@ -1327,6 +1341,16 @@ __device__ __forceinline__ void tile_dispatch_hm (const JobDev &J, uint8_t *sbuf
     const uint32_t hm = (J.tile_variant >> 2) & 7u;
 
     /* (host emulation only: the GPU build has one entry point per combination) */
+    if (J.tile_cpl == 2)
+    {
+        switch (hm)
+        {
+            case 1:  tile_dispatch_out<TAP, 1, STAGE, 2, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
+            case 2:  tile_dispatch_out<TAP, 2, STAGE, 2, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
+            default: tile_dispatch_out<TAP, 3, STAGE, 2, TILE_VM_PAIR> (J, sbuf, blockIdx.x, blockIdx.y); break;
+        }
+        return;
+    }
     if (J.tile_cpl == 4)
     {
         if (J.tile_vm == TILE_VM_PAIR)

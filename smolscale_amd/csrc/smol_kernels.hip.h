@@ -1216,6 +1216,7 @@ __device__ __forceinline__ uint32_t smol_quad_next (uint32_t v)
 }
 
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+typedef u32x2 u32x2a4 __attribute__ ((aligned (4)));       /* an 8-byte store unit on a 4-byte boundary */
 
 /* 16-byte NON-TEMPORAL output store on a dword-aligned address (k_up, bound by its stores: aligned rows 92 us
  * against 120 us with plain stores on config 3, rows that start anywhere 106 against 111; profiles/r04_store_policy_ab.txt).

@@ -478,3 +478,42 @@ def test_emulated_up_kernel_24_bit_output_as_shipped():
         hits += (k == 8)
         assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
     assert hits >= 60
+
+
+def test_emulated_tile_kernel_two_columns_per_lane():
+    """k_tile with TWO columns per lane (round 5): 24-bit sources behind one horizontal halving into dword-aligned 32-bit rows,
+    as shipped; and, through the tuning knob of the emulation build, every bilinear x bilinear job of the 64bpp class into
+    32-bit rows -- every source type, 0-2 halvings, vertical magnification, partial tiles, padded rows, row ranges."""
+    import os
+    rng = random.Random(77)
+    seen = 0
+    for forced in (0, 1):
+        if forced:
+            os.environ["SMOL_TILE_CPL"] = "2"
+        try:
+            for it in range(110):
+                w_out = rng.choice([128, 130, 200, 256, 257, 300, 515, 700])
+                h_out = rng.choice([1, 2, 5, 17, 33])
+                rx = rng.uniform(2.01, 3.99) if not forced else rng.uniform(1.01, 7.99)
+                ry = rng.choice([rng.uniform(1.01, 7.99), rng.uniform(0.3, 0.99)])
+                w_in = max(2, min(int(w_out * rx) + rng.randint(0, 1), 8 * w_out - 1))
+                h_in = max(2, min(int(h_out * ry) + rng.randint(0, 1), 8 * h_out - 1))
+                if w_in == w_out or h_in == h_out:
+                    continue
+                t_in = rng.choice([8, 9]) if not forced else rng.choice([0, 1, 2, 3, 4, 5, 8, 9])
+                t_out = rng.choice([0, 1, 2, 3, 4, 5, 6, 7])
+                job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+                if job.wide or job.filter_h != 2 or job.filter_v != 2:
+                    continue
+                sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 4, 1, 3])
+                sout = w_out * 4 + rng.choice([0, 0, 4, 8])
+                src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+                first = rng.randint(0, h_out - 1)
+                n = rng.randint(1, h_out - first)
+                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+                got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+                seen += k == 3
+                assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k, forced)
+        finally:
+            os.environ.pop("SMOL_TILE_CPL", None)
+    assert seen >= 100

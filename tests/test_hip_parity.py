@@ -953,3 +953,31 @@ def test_magnification_into_unassociated_rows_through_k_up():
                 got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first=first, n=n)
                 assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "device")
     assert seen >= 40
+
+
+def test_24_bit_sources_into_32_bit_rows_two_columns_per_lane():
+    """Round 5: k_tile takes two columns per lane for 24-bit sources behind one horizontal halving into dword-aligned 32-bit rows
+    (a photograph into an RGBA buffer): both 24-bit orders into all eight 32-bit types at ratios 2-4, vertical minification and
+    magnification, odd widths, padded rows, partial tiles; device buffers on dword boundaries and -- the one-column form -- off them."""
+    shapes = [(4000, 300, 1600, 120), (3000, 200, 1421, 95), (1000, 64, 333, 200), (2000, 150, 515, 40), (700, 90, 260, 31)]
+    k = 0
+    for (w_in, h_in, w_out, h_out) in shapes:
+        for t_in in (8, 9):
+            for t_out in range(8):
+                k += 1
+                if (k % 3) and w_in * h_in > 500_000:
+                    continue
+                job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+                assert not job.wide and sm.kernel_name(job) == "k_tile_batch"
+                sin = w_in * 3 + (k % 4)
+                sout = w_out * 4 + 4 * (k % 3)
+                src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                rb = w_out * 4
+                assert np.array_equal(H.rows_view(got, h_out, rb, sout), H.rows_view(want, h_out, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "host")
+                first, n = h_out // 3, max(1, h_out // 2)
+                for dmis in (0, 1 + k % 3):
+                    got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first=first, n=n,
+                                             src_misalign=k % 3, dst_misalign=dmis)
+                    assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, dmis)
