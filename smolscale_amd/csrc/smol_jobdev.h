@@ -260,7 +260,13 @@ tile_setup (JobDev &d)
 
     d.span_px = (uint32_t) span_px;
     d.tile_single = 0;
-    uint32_t budget = two_cols ? 3072u : TILE_LDS_BUDGET;
+    /* unassociated 32-bit sources that are premultiplied group by group in LDS (tapsel 4 below) take 3 KB too: 4096^2 rgbA ->
+     * premultiplied ratio 1.1 100 -> 95 us, 2.1 181 -> 157, 3 137 -> 129, 3.9 125 -> 121, ratios 1.3-1.95 and 2.5 within 2 %
+     * (profiles/r05_tile_cpl2.txt) */
+    const bool lds_premul = !d.wide && d.bpp_in == 4 && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0 && d.unassoc_in
+                            && d.filter_h == F_BILINEAR && d.step_x >= ((uint64_t) 1 << 32)
+                            && !tune_env ("SMOL_TILE_PREMUL_STAGE") && !tune_env ("SMOL_TILE_NO_LDS_PREMUL");
+    uint32_t budget = (two_cols || lds_premul) ? 3072u : TILE_LDS_BUDGET;
     if (const char *e = tune_env ("SMOL_TILE_LDS_BUDGET"))
         budget = (uint32_t) atoi (e);
 #ifdef SMOL_TUNING
