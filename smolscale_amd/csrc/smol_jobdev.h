@@ -188,6 +188,18 @@ tile_setup (JobDev &d)
     if (!d.wide && d.out3_ok && d.w_out >= 256 && d.filter_v != F_BOX
         && d.filter_h == F_BILINEAR && d.halv_h <= 1)
         d.tile_cpl = 4;
+    /* ... and back to ONE column with row groups of 3 KB behind one halving on both axes where the 8 taps of four columns
+     * stop sharing pixels or the source is premultiplied in LDS (4000 x 3000 -> 24-bit rows, profiles/r05_tile_cpl2.txt):
+     * unassociated 32-bit sources at every ratio (2.1 169 -> 166 us, 2.5 152 -> 131, 3 150 -> 125, 3.8 150 -> 111),
+     * premultiplied ones from ratio 3 (107 -> 103, 3.5 101 -> 93, 3.8 102 -> 92; at 2.1 four columns lead 123 : 138),
+     * 24-bit ones from ratio 3.7 (3.5 equal, 3.8 104 -> 93, 3.99 95 -> 89) */
+    bool one_col24 = !d.wide && d.tile_cpl == 4 && d.out3_ok && d.filter_h == F_BILINEAR && d.halv_h == 1
+                           && d.filter_v == F_BILINEAR && d.halv_v == 1 && !tune_env ("SMOL_NO_TILE_CPL1_24")
+                           && (d.bpp_in == 4 ? (d.unassoc_in ? ((((uintptr_t) d.src) | d.src_stride) & 3) == 0
+                                                              : d.step_x >= ((uint64_t) 3 << 31))
+                                             : d.step_x >= ((uint64_t) 185 << 32) / 100);
+    if (one_col24)
+        d.tile_cpl = 1;
     /* ... but not for a plain 32-bit premultiplied source shrunk by less than ~1.75 on this axis: once the
      * row loop's scalar work was cut (r02p), one column per lane is faster there (4096^2 -> 2731^2 123 -> 108 us,
      * -> 3413^2 174 -> 153, H down / V up 113 -> 82; at ratio 1.9, from 24-bit or unassociated sources 4 columns
@@ -224,7 +236,7 @@ tile_setup (JobDev &d)
     if (const char *e = tune_env ("SMOL_TILE_CPL"))
         if (!d.wide && d.filter_h != F_BOX && d.filter_v != F_BOX)
         {
-            two_cols = false;
+            two_cols = one_col24 = false;
             d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
             /* two columns per lane exist for bilinear x bilinear into dword-aligned 32-bit rows */
             if (atoi (e) == 2 && d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR && d.bpp_out == 4 && d.out_dword_ok
@@ -266,7 +278,7 @@ tile_setup (JobDev &d)
     const bool lds_premul = !d.wide && d.bpp_in == 4 && ((((uintptr_t) d.src) | d.src_stride) & 3) == 0 && d.unassoc_in
                             && d.filter_h == F_BILINEAR && d.step_x >= ((uint64_t) 1 << 32)
                             && !tune_env ("SMOL_TILE_PREMUL_STAGE") && !tune_env ("SMOL_TILE_NO_LDS_PREMUL");
-    uint32_t budget = (two_cols || lds_premul) ? 3072u : TILE_LDS_BUDGET;
+    uint32_t budget = (two_cols || lds_premul || one_col24) ? 3072u : TILE_LDS_BUDGET;
     if (const char *e = tune_env ("SMOL_TILE_LDS_BUDGET"))
         budget = (uint32_t) atoi (e);
 #ifdef SMOL_TUNING

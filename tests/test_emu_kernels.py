@@ -517,3 +517,32 @@ def test_emulated_tile_kernel_two_columns_per_lane():
         finally:
             os.environ.pop("SMOL_TILE_CPL", None)
     assert seen >= 100
+
+
+def test_emulated_tile_kernel_one_column_into_24_bit_rows_behind_one_halving():
+    """k_tile into 24-bit rows behind one halving on both axes (round 5): one column per lane and row groups of 3 KB for
+    unassociated sources, premultiplied ones from ratio 3 and 24-bit ones from ratio 3.7, four columns below -- both sides of
+    each threshold, every source type, partial tiles, padded rows, row ranges."""
+    rng = random.Random(78)
+    seen = 0
+    for it in range(120):
+        w_out = rng.choice([256, 257, 300, 515, 700])
+        h_out = rng.choice([2, 5, 17, 33])
+        r = rng.uniform(2.01, 3.99)
+        w_in = max(2, min(int(w_out * r) + rng.randint(0, 1), 4 * w_out - 1))
+        h_in = max(2, min(int(h_out * rng.uniform(2.01, 3.99)) + rng.randint(0, 1), 4 * h_out - 1))
+        t_in = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+        t_out = rng.choice([8, 9])
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+        if job.wide or job.filter_h != 2 or job.filter_v != 2:
+            continue
+        sin = w_in * H.bpp(t_in) + rng.choice([0, 0, 4, 1, 3] if H.bpp(t_in) == 3 else [0, 4])
+        sout = w_out * 3 + rng.choice([0, 1, 3, 4])
+        src = H.make_input(t_in, w_in, h_in, seed=it, valid=bool(it & 1), stride=sin, pad=0)
+        first = rng.randint(0, h_out - 1)
+        n = rng.randint(1, h_out - first)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        got, k = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first, n)
+        seen += k == 3
+        assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
+    assert seen >= 100

@@ -981,3 +981,33 @@ def test_24_bit_sources_into_32_bit_rows_two_columns_per_lane():
                     got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first=first, n=n,
                                              src_misalign=k % 3, dst_misalign=dmis)
                     assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, dmis)
+
+
+def test_24_bit_rows_behind_one_halving_one_column_per_lane():
+    """Round 5: into 24-bit rows k_tile goes back from four columns per lane to one (row groups of 3 KB) behind one halving on both
+    axes for unassociated 32-bit sources, for premultiplied ones from ratio 3 and for 24-bit ones from ratio 3.7. Both sides of each
+    threshold, every source class into both 24-bit orders, odd widths, padded rows, row ranges, misaligned device buffers."""
+    shapes = [(4000, 300, 1600, 120), (4000, 300, 1300, 98), (4000, 300, 1053, 79), (3001, 200, 1421, 95), (2000, 150, 515, 40),
+              (1900, 120, 611, 39)]
+    k = 0
+    for (w_in, h_in, w_out, h_out) in shapes:
+        for t_in in (0, 1, 4, 5, 6, 8, 9):
+            for t_out in (8, 9):
+                k += 1
+                if (k % 3) and w_in * h_in > 700_000:
+                    continue
+                bpp = 3 if t_in >= 8 else 4
+                job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+                assert not job.wide and sm.kernel_name(job) == "k_tile_batch"
+                sin = w_in * bpp + (k % 4 if bpp == 3 else 4 * (k % 2))
+                sout = w_out * 3 + (k % 5)
+                src = H.make_input(t_in, w_in, h_in, seed=k, valid=True, stride=sin, pad=0)
+                want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout)
+                rb = w_out * 3
+                assert np.array_equal(H.rows_view(got, h_out, rb, sout), H.rows_view(want, h_out, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, "host")
+                first, n = h_out // 3, max(1, h_out // 2)
+                for dmis in (0, 1 + k % 3):
+                    got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, 0, sin, sout, first=first, n=n,
+                                             src_misalign=(k % 3) if bpp == 3 else 0, dst_misalign=dmis)
+                    assert np.array_equal(H.rows_view(got, n, rb, sout), H.rows_view(want[first * sout:], n, rb, sout)), (w_in, h_in, w_out, h_out, t_in, t_out, dmis)
