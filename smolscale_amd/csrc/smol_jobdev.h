@@ -239,8 +239,8 @@ tile_setup (JobDev &d)
             two_cols = one_col24 = false;
             d.tile_cpl = (uint8_t) (atoi (e) == 4 ? 4 : 1);
             /* two columns per lane exist for bilinear x bilinear into dword-aligned 32-bit rows */
-            if (atoi (e) == 2 && d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR
-                && ((d.bpp_out == 4 && d.out_dword_ok) || d.out3_ok) && d.w_out >= 128 && !tune_env ("SMOL_NO_TILE_VM"))
+            if (atoi (e) == 2 && d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR && d.bpp_out == 4 && d.out_dword_ok
+                && d.w_out >= 128 && !tune_env ("SMOL_NO_TILE_VM"))
                 d.tile_cpl = 2;
         }
     uint64_t cols = 64u * d.tile_cpl;

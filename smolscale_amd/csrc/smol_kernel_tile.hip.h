@@ -524,7 +524,7 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
             return;
         }
     }
-    if (OUT == OUT_ANY && full24)
+    if (OUT == OUT_ANY && full24 && CPL != 2)
     {
         /* A full-width tile of 24-bit pixels is one run of 64 * CPL * 3 bytes. It leaves as whole ALIGNED dwords
          * whatever byte the row starts on: m = (address of the run) & 3 is the same for every lane, the lanes cut the
@@ -580,54 +580,6 @@ __device__ __forceinline__ void tile_store_cols (const JobDev &J, uint8_t *rowp,
                 gbyte *tail = reinterpret_cast<gbyte *> (aligned + 192u);
                 for (uint32_t b = 0; b < m; b++)
                     tail [b] = (uint8_t) (d2 >> (8u * (sh + b)));
-            }
-        }
-        else if (CPL == 2)
-        {
-            /* two pixels per lane (round 5): the run is 384 bytes, six per lane. Lanes 0..47 each store TWO dwords of the aligned
-             * stream -- run bytes 8j - m .. 8j - m + 7, which sit in two neighbouring lanes (8 bytes starting at byte s <= 4 of a
-             * 6-byte record end before byte 12; s == 5, odd m only, takes one byte of a third) -- fetched with four or five
-             * in-wave shuffles. Lane 0 of a misaligned run
-             * stores its first 4 - m bytes one by one and the second dword only; lane 63 adds the run's last m bytes. */
-            const uint32_t w0 = tile_pack<OUT> (J, o [0], inv_tab) & 0x00ffffffu;
-            const uint32_t w1 = tile_pack<OUT> (J, o [1 % CPL], inv_tab) & 0x00ffffffu;
-            const uint32_t lo = w0 | (w1 << 24), hi = w1 >> 8;          /* this lane's six bytes */
-            const bool head = (m != 0u) && (j == 0u);
-            const uint32_t S = head ? 4u - m : j * 8u - m;              /* run offset of the first byte this lane stores as dwords */
-            const uint32_t a = (S * 43691u) >> 18;                      /* S / 6 for S < 512 */
-            const uint32_t sh = 8u * (S - 6u * a);
-            const uint32_t la = a & 63u, lb = (a + 1u) & 63u;
-            const uint64_t A = (uint64_t) smol_shfl_idx (lo, la) | ((uint64_t) smol_shfl_idx (hi, la) << 32);
-            const uint64_t B = (uint64_t) smol_shfl_idx (lo, lb) | ((uint64_t) smol_shfl_idx (hi, lb) << 32);
-            uint64_t r = (A >> sh) | (B << (48u - sh));
-            if (m & 1u)
-            {
-                /* odd m: a lane whose 8 bytes start at byte 5 of a record reaches byte 0 of the record after the next */
-                const uint32_t c = smol_shfl_idx (lo, (a + 2u) & 63u);
-                if (sh == 40u)
-                    r |= (uint64_t) c << 56;
-            }
-            if (head)
-            {
-                for (uint32_t b = 0; b < 4u - m; b++)
-                    run [b] = (uint8_t) (lo >> (8u * b));
-                aligned [1] = (uint32_t) r;
-            }
-            else if (j < 48u)
-            {
-                const u32x2 v = { (uint32_t) r, (uint32_t) (r >> 32) };
-#ifdef SMOL_KERNEL_EMU
-                __builtin_memcpy (aligned + j * 2u, &v, 8);
-#else
-                *reinterpret_cast<SMOL_AS_GLOBAL u32x2a4 *> (aligned + j * 2u) = v;
-#endif
-            }
-            if (m != 0u && j == 63u)
-            {
-                gbyte *tail = reinterpret_cast<gbyte *> (aligned + 96u);
-                const uint64_t six = (uint64_t) lo | ((uint64_t) hi << 32);
-                for (uint32_t b = 0; b < m; b++)
-                    tail [b] = (uint8_t) (six >> (8u * (6u - m + b)));
             }
         }
         else
