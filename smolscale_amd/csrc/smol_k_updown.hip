@@ -19,6 +19,15 @@ template <int HX, int IN>
 void
 launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s)
 {
+#ifdef SMOL_TUNING
+    /* timing ablations (tuning builds only): the switch word of smol_kernel_lind.hip.h, once per process */
+    static const bool dbg_set = [] {
+        const char *e = getenv ("SMOL_LIND_DBG");
+        const uint32_t v = e ? (uint32_t) atoi (e) : 0u;
+        return hipMemcpyToSymbol (HIP_SYMBOL (smolhip::smol_lind_dbg_dev), &v, sizeof v) == hipSuccess;
+    } ();
+    (void) dbg_set;
+#endif
     /* tiles of at most 64 columns (one or two halvings): the one-column flavour, a kernel of its own */
     const dim3 block (64u * smolhip::dispatch::lind_waves (rep));
     if (HX >= 1 && smolhip::dispatch::lind_narrow (rep))

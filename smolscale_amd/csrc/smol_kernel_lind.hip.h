@@ -49,6 +49,15 @@ enum : int { LIND_FUSED = 0, LIND_H = 1, LIND_V = 2 };
 /* TMP8 (passes of the W32 flavour only): the intermediate pixel is 8 bytes of 16-bit channels -- what k_boxh writes and
  * k_boxv reads (premul16 without sRGB: every value fits 16 bits) -- instead of four 32-bit channels (16 bytes) */
 /* NARROW (chosen per job at the entry, one or two halvings): tiles of at most 64 columns */
+#if defined (SMOL_TUNING) && !defined (SMOL_KERNEL_EMU)
+/* timing ablations, -DSMOL_TUNING builds only (env SMOL_LIND_DBG, set by the launcher): 1 no taps, 2 no loads, 4 no stores,
+ * 8 source table look-ups replaced by shifts, 16 output table look-ups replaced by shifts, 32 no conversion at all */
+static __device__ uint32_t smol_lind_dbg_dev;    /* (one per translation unit; the fused kernels live in smol_k_updown.hip) */
+#define SMOL_LIND_DBG() (smol_lind_dbg_dev)
+#else
+#define SMOL_LIND_DBG() 0u
+#endif
+
 template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false, bool NT = false>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
@@ -66,6 +75,7 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
     constexpr int ncols = NARROW ? 1 : CPL;
     constexpr int KMAX = NARROW ? LIND_KMAX_NARROW : LIND_KMAX;
 
+    const uint32_t dbg = PASS == LIND_FUSED ? SMOL_LIND_DBG () : 0u;   /* (constant 0 in the shipped library) */
     const uint32_t tiles_x = (J.w_out + W - 1) / W;
     const uint32_t tx = tile % tiles_x;
     const uint32_t ty = tile / tiles_x;
@@ -202,6 +212,11 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             px_off [k] = x * 4u;
     }
     uint32_t rawpx [KMAX];                                     /* the pixels of the row in flight */
+#ifdef SMOL_TUNING
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        rawpx [k] = lane * 0x01030507u + (uint32_t) k;             /* (ablation without loads: defined values) */
+#endif
     /* LIND_V: the lane's two intermediate pixels of the row in flight */
     uint32_t tmp_in [CPL][NCH];
 #pragma unroll
@@ -262,6 +277,8 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
             trow += (size_t) J.w_out * TPX;
             return;
         }
+        if (dbg & 2u)
+            return;
 #pragma unroll
         for (int k = 0; k < KMAX; k++)
             if ((uint32_t) k * 64u < npx)                           /* wave-uniform */
@@ -313,6 +330,13 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                             = u32x2a8 { ch [0] | (ch [1] << 16), ch [2] | (ch [3] << 16) };
                 }
         };
+        if (dbg & 32u)
+            return;
+        if (dbg & 8u)
+        {
+            conv ([] (uint32_t w, uint32_t (&ch) [4]) { ch [0] = (w & 0xffu) << 3; ch [1] = ((w >> 8) & 0xffu) << 3; ch [2] = ((w >> 16) & 0xffu) << 3; ch [3] = w >> 24; });
+            return;
+        }
         if (W32)
         {
             if (J.linear)
@@ -380,6 +404,13 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         {
             if (c >= ncols)
                 continue;
+            if (dbg & 1u)
+            {
+#pragma unroll
+                for (int i = 0; i < NCH; i++)
+                    h [c][i] = (tap_ofs [c][0] + r + (uint32_t) i) & 0x07ff07ffu;
+                continue;
+            }
             uint32_t hs [NCH];
 #pragma unroll
             for (uint32_t s = 0; s < NSX; s++)
@@ -508,8 +539,9 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                     {
                         if (c >= ncols)
                             continue;
-                        const uint32_t w = pack (v [c]);
-                        if (ok [c])
+                        const uint32_t w = (dbg & 16u) ? ((v [c][0] >> 3) & 0xffu) | ((v [c][1] << 5) & 0xff00u) | ((v [c][2] << 13) & 0xff0000u) | (v [c][3] << 24)
+                                                       : pack (v [c]);
+                        if (ok [c] && !(dbg & 4u))
                         {
                             if (J.bpp_out == 4 && J.out_dword_ok)
                             {
