@@ -283,6 +283,12 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
         for (int k = 0; k < KMAX; k++)
             if ((uint32_t) k * 64u < npx)                           /* wave-uniform */
             {
+#ifndef SMOL_KERNEL_EMU
+                /* keep the offset a 32-bit value INSIDE the loop: hoisted out of it, its zero-extension becomes a 64-bit register
+                 * pair and every load a 64-bit vector add + global_load ... off; as it stands the load is scalar row base +
+                 * 32-bit lane offset with no vector instruction at all */
+                asm volatile ("" : "+v" (px_off [k]));
+#endif
                 if (IN24)
                 {
 #ifdef SMOL_KERNEL_EMU
@@ -548,7 +554,13 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
                                 if (nt_out)
                                     store_nt32_at (out_row, xc [c] * 4u, w);
                                 else
-                                    *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + (size_t) xc [c] * 4) = w;
+                                {
+                                    uint32_t so = xc [c] * 4u;
+#ifndef SMOL_KERNEL_EMU
+                                    asm volatile ("" : "+v" (so));      /* (scalar row base + 32-bit lane offset: load_row) */
+#endif
+                                    *reinterpret_cast<SMOL_AS_GLOBAL uint32_t *> (out_row + so) = w;
+                                }
                             }
                             else
                                 wide_store_word (J, out_row, xc [c], w);
