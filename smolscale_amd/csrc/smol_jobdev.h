@@ -778,6 +778,9 @@ lind_nt (const JobDev &d)
            && d.step_x < ((uint64_t) 1 << 32) && d.step_y < ((uint64_t) 1 << 32) && !tune_env ("SMOL_NO_LIND_NT");
 }
 
+/* k_lind with the vertical sample count compiled in: no halving on either axis (the streaming flavour above has it too) */
+inline bool lind_hv0 (const JobDev &d) { return d.halv_h == 0 && d.halv_v == 0 && !tune_env ("SMOL_NO_LIND_HV0"); }
+
 inline uint32_t
 lind_pick_width (const JobDev &d, bool fused = false)
 {

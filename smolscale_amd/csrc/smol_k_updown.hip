@@ -39,12 +39,21 @@ launch_lind_k (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t ld
         return;
     }
     /* magnification on both axes into rows that start on 64-byte boundaries: the kernel with streaming stores */
-    if (HX == 0 && smolhip::dispatch::lind_nt (rep))
+    if (HX == 0 && smolhip::dispatch::lind_nt (rep) && rep.halv_v == 0)     /* (a per-sample step below 1 never comes with a halving) */
     {
         if (jobs_dev)
             hipLaunchKernelGGL ((smolhip::k_lind_batch<0, IN, false, true>), grid, block, lds, s, jobs_dev);
         else
             hipLaunchKernelGGL ((smolhip::k_lind_one<0, IN, false, true>), grid, block, lds, s, rep);
+        return;
+    }
+    /* no halving on either axis (ratios 1-2, magnifications into rows that start anywhere): the vertical sample count compiled in */
+    if (HX == 0 && smolhip::dispatch::lind_hv0 (rep))
+    {
+        if (jobs_dev)
+            hipLaunchKernelGGL ((smolhip::k_lind_batch<0, IN, false, false, true>), grid, block, lds, s, jobs_dev);
+        else
+            hipLaunchKernelGGL ((smolhip::k_lind_one<0, IN, false, false, true>), grid, block, lds, s, rep);
         return;
     }
     if (jobs_dev)

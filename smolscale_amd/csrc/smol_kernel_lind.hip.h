@@ -58,7 +58,7 @@ static __device__ uint32_t smol_lind_dbg_dev;    /* (one per translation unit; t
 #define SMOL_LIND_DBG() 0u
 #endif
 
-template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false, bool NT = false>
+template <int HX, bool IN24, bool W32, int PASS = LIND_FUSED, bool TMP8 = false, bool NARROW = false, bool NT = false, bool HV0 = false>
 __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                            const uint32_t lane, const uint32_t tile)
 {
@@ -155,7 +155,10 @@ __device__ __forceinline__ void lind_body (const JobDev &J, uint8_t *buf, const 
 
     /* ---- vertical schedule: sample k of the tile in lane k & 63 of sched [k >> 6] --- */
     constexpr bool nt_out = NT;                                     /* (streaming stores: a kernel of its own, see lind3_body) */
-    const uint32_t hv = J.halv_v;
+    /* HV0 (and NT, a magnification on both axes): no vertical halving, ONE sample per output row, known at compile time -- no
+     * shifts by zero, no sums of one term (gamma-correct x2 331 -> 310 us, 24-bit rows x4 158 -> 137: profiles/r05_lind_hv0.txt).
+     * The launcher picks the flavour by the job's halv_v. */
+    const uint32_t hv = (NT || HV0) ? 0u : J.halv_v;
     const uint32_t nsy = 1u << hv;
     const uint32_t jy0 = (J.first_row + yrel0) << hv;
     const uint32_t n_samples = PASS == LIND_H ? 1u : (yrel1 - yrel0) << hv;     /* <= 128 (lind_setup) */
@@ -695,7 +698,7 @@ __device__ __forceinline__ uint32_t tap16_half (uint32_t p, uint32_t q, uint32_t
 #endif
 }
 
-template <int HX, bool NARROW, bool NT = false>
+template <int HX, bool NARROW, bool NT = false, bool HV0 = false>
 __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const uint8_t *lut_lds,
                                             const uint32_t lane, const uint32_t tile)
 {
@@ -754,7 +757,10 @@ __device__ __forceinline__ void lind3_body (const JobDev &J, uint8_t *buf, const
             tap_ofs [c][s] = (tap_ofs [c][s] - sx0) * 8u;
 
     /* ---- vertical schedule (lind_body's) ------------------------------------------------------------------------ */
-    const uint32_t hv = J.halv_v;
+    /* HV0 (and NT, a magnification on both axes): no vertical halving, ONE sample per output row, known at compile time -- no
+     * shifts by zero, no sums of one term (gamma-correct x2 331 -> 310 us, 24-bit rows x4 158 -> 137: profiles/r05_lind_hv0.txt).
+     * The launcher picks the flavour by the job's halv_v. */
+    const uint32_t hv = (NT || HV0) ? 0u : J.halv_v;
     const uint32_t nsy = 1u << hv;
     const uint32_t jy0 = (J.first_row + yrel0) << hv;
     const uint32_t n_samples = (yrel1 - yrel0) << hv;
@@ -1013,16 +1019,16 @@ __device__ __forceinline__ uint32_t lind_wave_lds (bool w32, bool narrow = false
 /* 4 waves per workgroup share one LDS copy of the tables, each wave works on its own tile in its own LDS region */
 /* NARROW: the one-column flavour, a kernel of its own (k_lind_batch<HX, IN, true>; as a second body inside the common
  * kernel it cost the wide tiles 3-4 %, as k_boxh's 64-lane flavour did); the host picks it per job: dispatch::lind_narrow */
-template <int HX, bool IN24, bool W32, bool NARROW = false, bool NT = false>
+template <int HX, bool IN24, bool W32, bool NARROW = false, bool NT = false, bool HV0 = false>
 __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
 {
 #ifdef SMOL_KERNEL_EMU
     static uint8_t lut_lds [LUT_LDS_BYTES];
     lut_fill_lds (lut_lds, 0, 1);                       /* emulated: one wave per block */
     if (IN24 && !W32)
-        lind3_body<HX, NARROW, NT> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+        lind3_body<HX, NARROW, NT, HV0> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
     else
-        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW, NT> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
+        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW, NT, HV0> (J, lds, lut_lds, threadIdx.x, blockIdx.x);
 #else
     /* (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same on every lane of a wave, and
      * without it everything derived from the tile index -- every loop bound, every "is this round needed" test --
@@ -1034,10 +1040,10 @@ __device__ __forceinline__ void lind_entry (const JobDev &J, uint8_t *lds)
     uint8_t *tab_end = lds + ((LUT_LDS_BYTES + 15u) & ~15u);       /* (the host sizes the workgroup's LDS by the flavour too: down_lds_bytes) */
     if (IN24 && !W32)
     {
-        lind3_body<HX, NARROW, NT> (J, tab_end + wave * lind_wave_lds (false, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+        lind3_body<HX, NARROW, NT, HV0> (J, tab_end + wave * lind_wave_lds (false, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
     }
     else
-        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW, NT> (J, tab_end + wave * lind_wave_lds (W32, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
+        lind_body<HX, IN24, W32, LIND_FUSED, false, NARROW, NT, HV0> (J, tab_end + wave * lind_wave_lds (W32, NARROW), lds, threadIdx.x & 63u, blockIdx.x * 4u + wave);
 #endif
 }
 
@@ -1122,19 +1128,19 @@ __device__ __forceinline__ void linv_dispatch (const JobDev &J, uint8_t *lds)
 
 #ifndef SMOL_KERNEL_EMU
 /* IN: 0 = 32-bit rows, 11-bit channels; 1 = 24-bit rows; 2 = 32-bit rows, premul16 + linear (19-bit channels) */
-template <int HX, int IN, bool NARROW = false, bool NT = false>
+template <int HX, int IN, bool NARROW = false, bool NT = false, bool HV0 = false>
 __global__ void __launch_bounds__ (256)
 k_lind_batch (const JobDev *__restrict__ jobs)
 {
     const JobDev J = load_job (jobs, blockIdx.y);
-    lind_entry<HX, IN == 1, IN == 2, NARROW, NT> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW, NT, HV0> (J, smol_dyn_lds);
 }
 
-template <int HX, int IN, bool NARROW = false, bool NT = false>
+template <int HX, int IN, bool NARROW = false, bool NT = false, bool HV0 = false>
 __global__ void __launch_bounds__ (256)
 k_lind_one (const JobDev J)
 {
-    lind_entry<HX, IN == 1, IN == 2, NARROW, NT> (J, smol_dyn_lds);
+    lind_entry<HX, IN == 1, IN == 2, NARROW, NT, HV0> (J, smol_dyn_lds);
 }
 
 /* (pass 1: jobs along blockIdx.z like k_boxh; pass 2: along blockIdx.y like k_boxv) */

@@ -158,7 +158,7 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                                     || (!g.rep.px_mixed && jobs [j].px_kind != g.rep.px_kind)))
                 continue;
             if (g.k == KC_DOWN && (jobs [j].halv_h != g.rep.halv_h || jobs [j].bpp_in != g.rep.bpp_in || jobs [j].p16 != g.rep.p16
-                                   || lind_narrow (jobs [j]) != lind_narrow (g.rep) || lind_nt (jobs [j]) != lind_nt (g.rep)))
+                                   || lind_narrow (jobs [j]) != lind_narrow (g.rep) || lind_nt (jobs [j]) != lind_nt (g.rep) || lind_hv0 (jobs [j]) != lind_hv0 (g.rep)))
                 continue;
             if (g.k == KC_UP && (jobs [j].tile_aligned4 != g.rep.tile_aligned4 || jobs [j].up_wide != g.rep.up_wide
                                  || (jobs [j].tile_variant & 3u) != (g.rep.tile_variant & 3u)))

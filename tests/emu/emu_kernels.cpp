@@ -26,9 +26,10 @@ __global__ void k_down_one (const JobDev J)
     }
     switch (J.halv_h * 3 + in)
     {
-        case 0: lind_entry<0, false, false> (J, smol_dyn_lds); break;
-        case 1: lind_entry<0, true, false> (J, smol_dyn_lds); break;
-        case 2: lind_entry<0, false, true> (J, smol_dyn_lds); break;
+        /* (no vertical halving: the flavour with the sample count compiled in, as the launcher picks it) */
+        case 0: if (dispatch::lind_hv0 (J)) lind_entry<0, false, false, false, false, true> (J, smol_dyn_lds); else lind_entry<0, false, false> (J, smol_dyn_lds); break;
+        case 1: if (dispatch::lind_hv0 (J)) lind_entry<0, true, false, false, false, true> (J, smol_dyn_lds); else lind_entry<0, true, false> (J, smol_dyn_lds); break;
+        case 2: if (dispatch::lind_hv0 (J)) lind_entry<0, false, true, false, false, true> (J, smol_dyn_lds); else lind_entry<0, false, true> (J, smol_dyn_lds); break;
         case 3: lind_entry<1, false, false> (J, smol_dyn_lds); break;
         case 4: lind_entry<1, true, false> (J, smol_dyn_lds); break;
         case 5: lind_entry<1, false, true> (J, smol_dyn_lds); break;
