@@ -153,7 +153,12 @@ int smol_hip_scale_rows_host (SmolHipPlan *plan,
  * the band was computed from (a memcmp of two or three rows on a bilinear axis; calls that move more than 256 KiB
  * take the ordinary road). smol_hip_plan_resident_source (plan, 1) -- or SMOL_HIP_RESIDENT_SRC=1 in the
  * environment -- is the caller's promise that the source does not change while the plan lives: no comparison,
- * read-ahead for calls of any size, bands of 8 MB. SMOL_HIP_READAHEAD=0 turns read-ahead off. */
+ * read-ahead for calls of any size, bands of 8 MB. SMOL_HIP_READAHEAD=0 turns read-ahead off.
+ * The environment variable is a promise about EVERY plan of the process, including the contexts behind smolscale.h, whose
+ * contract lets a caller rewrite pixels_in between calls: set it only for a process that never does; the per-plan call
+ * is the safe form. Changing the setting of a plan drops everything computed ahead for it (bands in flight are waited
+ * for), so a caller may take the promise back, rewrite its source and promise again. A call that finds the plan's
+ * read-ahead state busy in another thread takes the ordinary road instead of waiting for it. */
 int smol_hip_plan_resident_source (SmolHipPlan *plan, int resident);
 
 /* The same over several devices: rows [first_row, first_row+n_rows) are cut into one

@@ -88,7 +88,9 @@ struct JobDev
     uint16_t launch_src_mb;        /* batches: source megabytes of ALL the batch's images (0: a call of its own); host side only, box2_setup */
     uint8_t box_force;             /* host side only, box2_setup: 64bpp-class box x box -- 0 decide by the launch's bytes, 1 single pass (k_tile), 2 two passes.
                                     * A strip that is cut into chunks decides ONCE and hands the verdict down */
-    uint8_t reserved1;
+    uint8_t hbox_force;            /* host side only, twopass_setup: bilinear x tall box (box2 == 3) -- 0 pick the splits of an output row's span from this
+                                    * call's rows, n use n splits. A strip cut into chunks decides ONCE (its intermediate image is sized for the
+                                    * strip's splits; a chunk of fewer rows would pick more: ADVICE round 5) */
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
     uint32_t span_chunks_inv;      /* floor(2^32 / span_chunks) + 1                      */
     uint32_t box_nmax;             /* horizontal box: most interior pixels any column has */
@@ -1075,7 +1077,16 @@ inline size_t
 box2_tmp_offset (const JobDev &d)
 {
     if (twopass_hbox (d))
-        return (size_t) d.first_row * hbox_splits (d) * d.w_out * 16u;
+    {
+        /* the splits follow the call's row count (twopass_setup), so strips of one image may differ in theirs: rows are
+         * placed by the most splits ANY row range of this job takes -- min (64, span / 32) -- and disjoint row ranges stay
+         * disjoint in the buffer whatever each of them picked (h_out * span / 32 * 16 bytes <= h_in / 2 per column: inside
+         * the plan's h_in * w_out * 8) */
+        uint32_t m = (uint32_t) (d.step_y >> 16) / 32u;
+        if (m > 64u) m = 64u;
+        if (m < hbox_splits (d)) m = hbox_splits (d);       /* (tuning builds: SMOL_HBOX_SPLITS) */
+        return (size_t) d.first_row * m * d.w_out * 16u;
+    }
     return (size_t) d.tmp_row0 * d.w_out * box2_tmp_px (d);
 }
 
@@ -1259,6 +1270,8 @@ twopass_setup (JobDev &d)
         if (const char *e = tune_env ("SMOL_HBOX_SPLITS"))
             sp = (uint32_t) atoi (e);
         if (sp > 64u) sp = 64u;                 /* (64 x 60000 -> 100 x 4: 64 splits 161 us, 128 157, 256 183) */
+        if (t.hbox_force)
+            sp = t.hbox_force;                  /* (the strip's choice: strip_classify) */
         while (sp > 1u && (uint64_t) t.n_rows * sp > 4u * 65535u)
             sp--;
         if (sp < 1u) sp = 1u;
@@ -1343,19 +1356,32 @@ classify (JobDev &d)
  * whole strip. 64bpp-class box x box picks the single pass or the two passes by the bytes a launch reads (box2_setup);
  * a chunk classified on its own rows would take the two passes where the strip's probe said k_tile and had sized no
  * intermediate image (8000 x 6000 -> 800 x 600). The verdict travels to the chunks as
- * JobDev::box_force; tmp_bytes is what the strip's intermediate image needs (0: none), an upper bound of any chunk's. */
+ * JobDev::box_force; tmp_bytes is what the strip's intermediate image needs (0: none), an upper bound of any chunk's.
+ * Likewise the splits of the bilinear x tall-box road (box2 == 3): twopass_setup takes more splits the fewer rows a call
+ * has, so a chunk on its own would need more partial sums per row than the strip's probe sized (96 x 32768
+ * -> 400 x 512 gamma-correct from pageable memory, 1 split for the strip, 2 for its 320-row chunks). The strip's count
+ * travels as JobDev::hbox_force; rows x splits x w_out x 16 then bounds every chunk. */
 struct StripClass
 {
     KClass k;
     size_t tmp_bytes;
     uint8_t box_force;
+    uint8_t hbox_force;
 };
+
+/* hand a strip's verdicts to one of its chunks */
+inline void
+strip_force (JobDev &jd, const StripClass &sc)
+{
+    jd.box_force = sc.box_force;
+    jd.hbox_force = sc.hbox_force;
+}
 
 inline StripClass
 strip_classify (const SmolHipJob &job, uint32_t src_pitch, uint32_t dst_pitch, uint32_t first_row, uint32_t n_rows)
 {
     JobDev probe;
-    StripClass sc = { KC_GENERAL, 0, 0 };
+    StripClass sc = { KC_GENERAL, 0, 0, 0 };
 
     fill_jobdev (probe, job, reinterpret_cast<const void *> (uintptr_t (16)), src_pitch,
                  reinterpret_cast<void *> (uintptr_t (16)), dst_pitch, first_row, n_rows);
@@ -1364,6 +1390,8 @@ strip_classify (const SmolHipJob &job, uint32_t src_pitch, uint32_t dst_pitch, u
         sc.tmp_bytes = box2_tmp_bytes (probe);
     if (!probe.wide && probe.filter_h == F_BOX && probe.filter_v == F_BOX)
         sc.box_force = sc.k == KC_BOX2 ? 2 : 1;
+    if (sc.k == KC_BOX2 && twopass_hbox (probe))
+        sc.hbox_force = (uint8_t) hbox_splits (probe);      /* (1 .. 64) */
     return sc;
 }
 

@@ -165,8 +165,11 @@ smol_hip_batch_create (const SmolHipImage *images, uint32_t n_images, int device
                 continue;
             if (g.k == KC_BOX2 && (jobs [j].wide != g.rep.wide || jobs [j].box2_ygroup != g.rep.box2_ygroup || jobs [j].box2 != g.rep.box2
                                    || (jobs [j].tile_lpc >= 16) != (g.rep.tile_lpc >= 16)
+                                   /* k_linh / k_linv take their KIND (11-bit, 24-bit rows, 19-bit, premul16) from the group's
+                                    * representative: everything lin_pass_kind () reads is part of the key */
                                    || (g.rep.box2 >= 2 && (jobs [j].filter_h != g.rep.filter_h || jobs [j].filter_v != g.rep.filter_v
-                                                           || jobs [j].halv_h != g.rep.halv_h || jobs [j].bpp_in != g.rep.bpp_in))))
+                                                           || jobs [j].halv_h != g.rep.halv_h || jobs [j].bpp_in != g.rep.bpp_in
+                                                           || jobs [j].p16 != g.rep.p16 || jobs [j].linear != g.rep.linear))))
                 continue;
             if (g.k == KC_HSPAN && (jobs [j].bpp_in != g.rep.bpp_in || jobs [j].halv_h != g.rep.halv_h))
                 continue;

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace smolhip::dispatch;
@@ -759,7 +760,6 @@ strip_issue_locked (Strip &st, Lane &ln)
      * (8000 x 6000 -> 800 x 600 failed on a fresh lane, wrote past a smaller scratch on a used one) */
     const StripClass sc = strip_classify (job, (uint32_t) src_pitch, (uint32_t) dst_pitch, st.first, st.n);
     const size_t tmp_need = sc.tmp_bytes ? sc.tmp_bytes + 64 : 0;
-    const uint8_t box_force = sc.box_force;
     rc = lane_prepare (ln, zero_copy || mapped ? 0 : src_bytes + 64 + 16, zero_copy || mapped ? 0 : dst_bytes + 64 + 16, tmp_need);
     if (!rc && (bounce_in || zero_copy))
         rc = ring_prepare (ln.in, mapped ? map_in_max : src_bytes, src_pitch);
@@ -835,7 +835,7 @@ strip_issue_locked (Strip &st, Lane &ln)
             uint8_t *out = bounce_out ? ln.out.buf (slot) : static_cast<uint8_t *> (map_dst) + (size_t) i * map_rows * dst_pitch;
 
             fill_jobdev (jd, job, virt, (uint32_t) src_pitch, out, (uint32_t) dst_pitch, first, rows);
-            jd.box_force = box_force;
+            strip_force (jd, sc);
             auto t = tick ();
             /* (ONE stream: a stream per ring slot, so that one chunk's head overlaps the tail of the one before, was
              * measured and is 10-30 % slower -- kernels that share the link finish later each, and the copy pool waits
@@ -867,7 +867,7 @@ strip_issue_locked (Strip &st, Lane &ln)
         copy_rows (RowCopy { hin, src_pitch, src_first, st.rowstride_in, in_row_bytes, (uint32_t) n_in_rows, knobs ().stream_stores });
         fill_jobdev (jd, job, hin - (size_t) r0 * src_pitch, (uint32_t) src_pitch, hout, (uint32_t) dst_pitch,
                      st.first, st.n);
-        jd.box_force = box_force;
+        strip_force (jd, sc);
         hipError_t e = launch_single (jd, ln.s_k, ln.tmp_buf, ln.tmp_cap);
         if (e == hipSuccess)
             e = hipStreamSynchronize (ln.s_k);
@@ -990,7 +990,7 @@ strip_issue_locked (Strip &st, Lane &ln)
         uint8_t *dchunk = static_cast<uint8_t *> (ln.dst_buf) + dst_skew + (size_t) done * dst_pitch;
         JobDev jd;
         fill_jobdev (jd, job, virt_src, (uint32_t) src_pitch, dchunk, (uint32_t) dst_pitch, st.first + done, rows);
-        jd.box_force = box_force;
+        strip_force (jd, sc);
         if ((e = launch_single (jd, ln.s_k, ln.tmp_buf, ln.tmp_cap)) != hipSuccess) break;
         if (!one_stream)
         {
@@ -1144,6 +1144,7 @@ struct SmolRowCache
     /* the pattern: where the last call on this plan ended */
     const uint8_t *last_src = nullptr;
     uint32_t last_end = 0;
+    std::thread::id last_thread;        /* ... and who made it */
     int resident = -1;                  /* -1: the environment decides */
     /* under the resident-source promise: two bands of output rows, the one calls are served from and the one after it,
      * computed while the caller consumes the first (asynchronously when the source is page-locked) */
@@ -1437,7 +1438,13 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
     if (smol_hip_input_row_range (&job, first, n, &a, &b))
         return 0;
 
-    std::lock_guard<std::mutex> guard (plan->rc_mtx);
+    /* Callers that thread themselves over ONE context with small row batches (the reference's own worker pattern, test.c:838-883)
+     * must not queue up behind a band another thread is computing under this lock (staging copy, launch, wait: up to 2-8 MB):
+     * a contended lock means "not this road" (ADVICE round 5). And the pattern is per calling thread: a call from another
+     * thread than the last one starts a new sequence instead of continuing -- or breaking -- somebody else's. */
+    std::unique_lock<std::mutex> guard (plan->rc_mtx, std::try_to_lock);
+    if (!guard.owns_lock ())
+        return 0;
     SmolRowCache *c = plan->rc;
     const bool resident = c && c->resident >= 0 ? c->resident != 0 : kn.resident;
     const size_t moved = ((size_t) b - a + 1) * in_row + (size_t) n * out_row;
@@ -1473,9 +1480,11 @@ read_ahead (SmolHipPlan *plan, const uint8_t *src, uint32_t rowstride_in, uint8_
         return true;
     };
 
-    const bool continues = c->last_src == src && c->last_end == first;
+    const std::thread::id me = std::this_thread::get_id ();
+    const bool continues = c->last_src == src && c->last_end == first && c->last_thread == me;
     c->last_src = src;
     c->last_end = first + n;
+    c->last_thread = me;
     if (resident)
     {
         /* (the first call of a sequence takes the ordinary road: a caller that asks for one strip only pays for no band) */
@@ -1933,8 +1942,26 @@ smol_hip_plan_resident_source (SmolHipPlan *plan, int resident)
         plan->rc = new (std::nothrow) SmolRowCache;
     if (!plan->rc)
         return SMOL_HIP_E_INVALID;
-    plan->rc->resident = resident ? 1 : 0;
-    plan->rc->valid = false;
+    SmolRowCache *c = plan->rc;
+    const int want = resident ? 1 : 0;
+    /* Whatever was computed ahead under the old setting is dropped, in flight or not: a caller that takes the promise back,
+     * rewrites its source and gives the promise again for the same pointer must not be served rows of the old bytes -- under
+     * the promise nothing is compared. */
+    for (SmolRowCache::Band &b : c->band)
+    {
+        if (b.pending)
+        {
+            (void) hipSetDevice (plan->device);
+            (void) hipEventSynchronize (b.ev);
+            (void) hipGetLastError ();
+            b.pending = false;
+        }
+        b.valid = false;
+    }
+    c->valid = false;
+    c->src = nullptr;
+    c->last_src = nullptr;              /* (the next call starts a new sequence) */
+    c->resident = want;
     return 0;
 }
 

@@ -267,7 +267,7 @@ emu_strip_chunks_agree (const SmolHipJob *job, uint32_t src_pitch, uint32_t dst_
         fill_jobdev (jd, *job, reinterpret_cast<const void *> (uintptr_t (16)), src_pitch,
                      reinterpret_cast<void *> (uintptr_t (16)), dst_pitch, first_row + done, rows);
         if (use_force)
-            jd.box_force = sc.box_force;
+            strip_force (jd, sc);
         const KClass k = classify (jd);
         const bool flip = (k == KC_BOX2) != (sc.k == KC_BOX2) || (k == KC_BOX2 && box2_tmp_bytes (jd) > sc.tmp_bytes);
         if (flip)

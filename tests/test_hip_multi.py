@@ -552,7 +552,38 @@ def test_resident_source_promise_and_read_ahead_off(monkeypatch):
     s2[:] = 0
     plan.scale_rows_host(s2, w_in * 4, dst[2 * w_out * 4:], w_out * 4, 2, 1)    # from the band: the old image
     assert np.array_equal(dst[:3 * w_out * 4], want[:3 * w_out * 4])
+    # the promise taken back and given again for the SAME pointer after a rewrite -- nothing computed ahead
+    # under the old promise (valid or in flight) may serve the new sequence
+    plan.resident_source(False)
+    plan.resident_source(True)
+    want0 = H.oracle_scale(s2, t_in, w_in, h_in, t_out, w_out, h_out)
+    for y in range(3, 9):
+        plan.scale_rows_host(s2, w_in * 4, dst[y * w_out * 4:], w_out * 4, y, 1)
+    assert np.array_equal(dst[3 * w_out * 4:9 * w_out * 4], want0[3 * w_out * 4:9 * w_out * 4])
     plan.destroy()
+
+
+def test_worker_threads_with_small_row_batches_share_one_context():
+    """threads that share one context and ask for small row batches (test.c:838-883 with many more strips
+    than threads) neither wait for each other's read-ahead bands nor continue each other's sequences; every row equals the
+    oracle's."""
+    import threading
+    t_in, w_in, h_in, t_out, w_out, h_out = 0, 1280, 960, 0, 800, 600
+    src = H.make_input(t_in, w_in, h_in, seed=3, valid=True, pad=16)
+    want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out)
+    dst = np.zeros(h_out * w_out * 4, np.uint8)
+    ctx = sm.SmolScaleCtx(src, t_in, w_in, h_in, w_in * 4, dst, t_out, w_out, h_out, w_out * 4, 0)
+    n_threads, step = 6, 2
+    def work(k):
+        # thread k takes the rows of its own strip two at a time (consecutive calls of one thread continue each other)
+        per = -(-h_out // n_threads)
+        for y in range(k * per, min(h_out, (k + 1) * per), step):
+            ctx.batch(y, min(step, h_out - y))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    ctx.destroy()
+    assert np.array_equal(dst, want)
 
 
 MAPPED_SPECS = [

@@ -399,6 +399,52 @@ def test_two_pass_box_thumbnails_single_and_batched():
         ddst.free()
 
 
+def test_two_pass_batch_mixes_pixel_types_and_gamma_at_one_geometry():
+    """the two k_lin* passes take their flavour (11-bit, 24-bit rows, 19-bit, premul16) from the
+    launch group's representative, so a batch that mixes premultiplied, unassociated (premul16) and gamma-correct images of ONE
+    geometry must not put them into one group. Bilinear H x tall box V (vertical sums in pass 1's registers) and box H x
+    bilinear V, every image against the oracle."""
+    lib = sm.lib()
+    for (w_in, h_in, w_out, h_out) in ((300, 3000, 200, 10), (3000, 300, 10, 200)):
+        flavours = [(0, 0, 0), (5, 5, 0), (5, 5, 1), (0, 0, 1), (8, 8, 1), (8, 0, 0), (6, 7, 1), (1, 0, 0)]
+        images, bufs, wants = [], [], []
+        for k, (t_in, t_out, srgb) in enumerate(flavours):
+            src = H.make_input(t_in, w_in, h_in, seed=70 + k, valid=True, pad=0)
+            wants.append(H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb))
+            dsrc = sm.DeviceBuffer(src.size + 16)
+            dsrc.upload(src)
+            ddst = sm.DeviceBuffer(wants[-1].size + 16)
+            ddst.fill(0)
+            im = sm.SmolHipImage()
+            im.job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+            im.src, im.dst = dsrc.ptr, ddst.ptr
+            im.rowstride_in, im.rowstride_out = w_in * H.bpp(t_in), w_out * H.bpp(t_out)
+            im.first_row, im.n_rows = 0, h_out
+            images.append(im)
+            bufs.append((dsrc, ddst))
+        batch = sm.HipBatch(images)
+        batch.launch()
+        sm.check(lib.smol_hip_device_synchronize(0))
+        for k, (want, (dsrc, ddst)) in enumerate(zip(wants, bufs)):
+            assert np.array_equal(ddst.download(want.size), want), (w_in, h_in, w_out, h_out, flavours[k])
+        batch.destroy()
+        for dsrc, ddst in bufs:
+            dsrc.free()
+            ddst.free()
+
+
+def test_host_strip_in_chunks_keeps_the_splits_of_its_tall_box():
+    """bilinear H x tall box V keeps per-split partial sums in the lane's intermediate image, sized
+    from the strip; the strip's chunks (fewer rows each) would pick more splits on their own. 96 x 32768 -> 400 x 512 from
+    pageable memory is cut into chunks on both host roads; gamma-correct and premul16, whole image and a strip."""
+    for (t_in, t_out, srgb) in ((5, 5, 1), (4, 4, 0), (0, 0, 1)):
+        w_in, h_in, w_out, h_out = 96, 32768, 400, 512
+        src = H.make_input(t_in, w_in, h_in, seed=9, valid=True, pad=0)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        got = H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(got, want), (t_in, t_out, srgb)
+
+
 def test_box_filter_single_pass_in_launches_of_150_mb_and_more():
     """64bpp class, box on both axes: one image or a few go through the two passes (k_boxh + k_boxv), a launch that reads
     150 MB or more at ratios up to 12 (300 MB up to 24; 24-bit sources up to 19) through the single-pass k_tile

@@ -195,6 +195,38 @@ def test_chunks_of_a_host_strip_take_the_road_the_strip_chose():
     assert seen == {KC_TILE, KC_BOX2}
 
 
+def test_chunks_of_a_host_strip_keep_the_splits_of_a_tall_box():
+    """bilinear (COPY, ONE) H x tall box V in the 128bpp class keeps one 16-byte partial sum per output
+    pixel and SPLIT of the row's span; twopass_setup takes more splits the fewer rows a call has, so the chunks of a strip
+    would outgrow the intermediate image the strip's probe sized. The strip's count travels to its chunks
+    (JobDev::hbox_force). Replayed on the dispatcher, no GPU: with the verdict every chunk fits, without it the
+    advisor's reproducer does not."""
+    import ctypes
+    emu = H.emu()
+    emu.emu_strip_chunks_agree.restype = ctypes.c_int
+    KC_BOX2 = 10
+    hazard = 0
+    for (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in (
+            (5, 96, 32768, 5, 400, 512, 1),        # the advisor's reproducer: 1 split for the strip, 2 for 320-row chunks
+            (4, 96, 32768, 4, 400, 512, 0),        # premul16
+            (0, 96, 32768, 0, 400, 512, 1),
+            (0, 300, 20000, 0, 200, 40, 0),        # compressed storage (ratio 500)
+            (5, 64, 60000, 5, 100, 4, 1),
+            (8, 640, 65535, 8, 641, 200, 1),
+            (4, 2000, 40000, 5, 1500, 900, 1)):
+        job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        sp, dp = w_in * H.bpp(t_in), w_out * H.bpp(t_out)
+        for first, n in ((0, h_out), (h_out // 3, max(1, h_out // 2))):
+            for rpc in sorted({1, 3, max(1, n // 7), max(1, n // 2), n, 320}):
+                k, flips = ctypes.c_int(), ctypes.c_int()
+                rc = emu.emu_strip_chunks_agree(ctypes.byref(job), sp, dp, first, n, rpc, 1, ctypes.byref(k), ctypes.byref(flips))
+                assert k.value == KC_BOX2, (w_in, h_in, w_out, h_out, k.value)
+                assert rc == 0 and flips.value == 0, (t_in, w_in, h_in, w_out, h_out, srgb, first, n, rpc, flips.value)
+                rc = emu.emu_strip_chunks_agree(ctypes.byref(job), sp, dp, first, n, rpc, 0, ctypes.byref(k), ctypes.byref(flips))
+                hazard += rc != 0
+    assert hazard > 0
+
+
 def test_mapped_road_chunks_fit_their_ring_slots():
     """The mapped road (smol_rt_lanes.hip: kernels on page-locked host rows) cuts a strip with a pageable side into chunks whose source
     rows / output rows pass through ONE ring slot each: the plan (smol_rt_chunks.h) replayed without a GPU over random jobs, row
