@@ -155,6 +155,7 @@ class Work:
     workload = ""
     config = None
     keep = None                 # tensors the batch points into
+    placement = None            # pick_destination ()'s report
 
     def check(self):            # -> True / False / None (nothing to check on this rank)
         return None
@@ -167,6 +168,85 @@ def _image(job, src_ptr, dst_ptr, s_in, s_out, first, n):
     im.rowstride_in, im.rowstride_out = s_in, s_out
     im.first_row, im.n_rows = first, n
     return im
+
+
+# Where the arenas lie in HBM is worth 3.5 % on the headline, 5 % on config 5 and 14 % on its mixed-type form
+# (profiles/r06_headline_modes.txt). Rounds 4-5 saw "two modes per process" (337 / 325 us) and could not steer them. Round 6: arenas
+# that are alive TOGETHER in one process run in different modes -- the mode follows the allocations (sometimes the source arena alone,
+# sometimes the pair of source and destination allocation), not the process, the stream, the virtual addresses (identical addresses
+# with randomisation off: both modes) or offsets inside an allocation (every 64 MB window of a 4 GB destination region behaves
+# alike, shifts of 256 B ... 32 MB change nothing): a property of where the driver put the pages. A caller that keeps its buffers
+# (any pipeline that scales frame after frame) settles it ONCE: allocate a few candidate arenas, time a handful of launches on each
+# pair, keep the best. Arenas of 128 MB - 2 GB cost nothing on a 288 GB device. The candidates stay allocated until the process ends:
+# handing gigabytes back to the driver slows the launches that follow for a while (same file). --no-placement takes the first
+# allocation as rounds 1-5 did; the line reports every candidate's time either way.
+PLACEMENT_DST_TRIES = 4
+PLACEMENT_SRC_TRIES = 3
+PLACEMENT_SPACER = 3 << 30
+PLACEMENT_HOLD = []             # candidates and spacers that were not picked: kept until exit
+
+
+def placement_on():
+    return PLACEMENT_DST_TRIES > 1
+
+
+def pick_destination(dev, local_rank, n_img, slot_out, make_images, settle=True):
+    """-> (seconds per launch, dst tensor, batch, candidate times in us). make_images (dst) builds the image descriptors for a
+    destination arena of n_img slots."""
+    tries = PLACEMENT_DST_TRIES
+    cands = []
+    for k in range(max(1, tries)):
+        dst = torch.zeros((n_img, slot_out), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        b = sm.HipBatch(make_images(dst), device=local_rank)
+        t = 0.0
+        if tries > 1:
+            # the clock governor needs load to ramp, and building a candidate (a descriptor table of 10 000 thumbnails: tens of
+            # milliseconds on the host) lets it fall back: 0.15 s of launches before the first candidate is judged, 0.05 s before
+            # each of the others (config 5's mixed-type kernel read 465 us in a cold probe and 405 in the timed region)
+            probe = max(b.time(1, 3) / 3, 1e-3)
+            b.time(0, max(1, int((150.0 if (k == 0 and settle) else 50.0) / probe)))
+            n = max(4, min(16, int(8.0 / probe)))
+            t = b.time(1, n) / n
+        cands.append((t, dst, b))
+        if k + 1 < tries:
+            try:
+                PLACEMENT_HOLD.append(torch.empty(PLACEMENT_SPACER, dtype=torch.uint8, device=dev))
+            except Exception:                       # noqa: BLE001 -- a device without room for spacers keeps what it has
+                break
+    best = min(range(len(cands)), key=lambda i: cands[i][0])
+    for i, (_, d, b) in enumerate(cands):
+        if i != best:
+            b.destroy()
+            PLACEMENT_HOLD.append(d)
+    return cands[best][0], cands[best][1], cands[best][2], [round(c[0] * 1e3, 1) for c in cands]
+
+
+def pick_placement(dev, local_rank, make_src, n_img, slot_out, make_images):
+    """Source candidates x destination candidates -> (src, dst, batch, report). make_src () allocates and fills a source arena,
+    make_images (src, dst) the descriptors. A second source arena is only tried while every pair seen so far runs alike (then
+    nothing says whether that is the fast mode or the slow one)."""
+    best = None
+    table = []
+    for k in range(PLACEMENT_SRC_TRIES if placement_on() else 1):
+        src = make_src()
+        torch.cuda.synchronize()
+        t, dst, b, us = pick_destination(dev, local_rank, n_img, slot_out, lambda d: make_images(src, d), settle=k == 0)
+        table.append(us)
+        if best is None or t < best[0]:
+            if best is not None:
+                best[3].destroy()
+                PLACEMENT_HOLD.extend([best[1], best[2]])
+            best = (t, src, dst, b)
+        else:
+            b.destroy()
+            PLACEMENT_HOLD.extend([src, dst])
+        flat = [x for row in table for x in row]
+        if not placement_on() or max(flat) > 1.02 * min(flat):
+            break                                   # both modes seen: the minimum is the fast one
+    report = {"candidates_us": table if placement_on() else None,
+              "picked_us": round(best[0] * 1e3, 1) if placement_on() else None}
+    return best[1], best[2], best[3], report
 
 
 def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out, h_out, n_frames, seed0_frame):
@@ -187,15 +267,14 @@ def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out
     # every frame starts on a 256-byte boundary, as buffers from any device allocator do
     slot_in = (slab_rows * s_in + 64 + 255) // 256 * 256
     slot_out = (n_rows * s_out + 64 + 255) // 256 * 256
-    src = torch.randint(0, 256, (n_frames, slot_in), dtype=torch.uint8, device=dev, generator=gen)
-    dst = torch.zeros((n_frames, slot_out), dtype=torch.uint8, device=dev)
+    src, dst, w.batch, w.placement = pick_placement(
+        dev, local_rank, lambda: torch.randint(0, 256, (n_frames, slot_in), dtype=torch.uint8, device=dev, generator=gen),
+        n_frames, slot_out,
+        lambda sr, d: [_image(job, sr[f].data_ptr() - r0 * s_in, d[f].data_ptr(), s_in, s_out, first_row, n_rows) for f in range(n_frames)])
     frame0 = seed0_frame()
     torch.cuda.synchronize()
     sm.upload(src[0].data_ptr(), frame0[r0 * s_in:(r1 + 1) * s_in], local_rank)
-    images = [_image(job, src[f].data_ptr() - r0 * s_in, dst[f].data_ptr(), s_in, s_out, first_row, n_rows)
-              for f in range(n_frames)]
     torch.cuda.synchronize()
-    w.batch = sm.HipBatch(images, device=local_rank)
     w.keep = (src, dst)
     # every source pixel of the strip read once, every destination pixel written once:
     # the strip's share of the input is n_rows/h_out of it (halo rows are re-reads, not counted)
@@ -262,10 +341,8 @@ def work_c5mix(rank, world, dev, local_rank, n_total=10000):
     slot_in, slot_out = 256 * 256 * 4, 64 * 64 * 4
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x5EED + rank)
-    src = torch.randint(0, 256, (len(mine), slot_in), dtype=torch.uint8, device=dev, generator=gen)
-    dst = torch.zeros((len(mine), slot_out), dtype=torch.uint8, device=dev)
     jobs = {}
-    images, algo = [], 0
+    specs, algo = [], 0
     n_check = min(24, len(mine))
     seeded = []
     for k, i in enumerate(mine):
@@ -274,15 +351,21 @@ def work_c5mix(rank, world, dev, local_rank, n_total=10000):
             jobs[(t_in, t_out)] = sm.plan_job(t_in, 256, 256, t_out, 64, 64, 0)
         bi, bo = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
         if k < n_check:
-            f = H.make_input(t_in, 256, 256, seed=i, valid=True, pad=0)
-            torch.cuda.synchronize()
-            sm.upload(src[k].data_ptr(), f, local_rank)
-            seeded.append((k, t_in, t_out, f))
-        images.append(_image(jobs[(t_in, t_out)], src[k].data_ptr(), dst[k].data_ptr(), 256 * bi, 64 * bo, 0, 64))
+            seeded.append((k, t_in, t_out, H.make_input(t_in, 256, 256, seed=i, valid=True, pad=0)))
+        specs.append((jobs[(t_in, t_out)], 256 * bi, 64 * bo))
         algo += 256 * 256 * bi + 64 * 64 * bo
-    torch.cuda.synchronize()
-    if images:
-        w.batch = sm.HipBatch(images, device=local_rank)
+    if specs:
+        src, dst, w.batch, w.placement = pick_placement(
+            dev, local_rank, lambda: torch.randint(0, 256, (len(mine), slot_in), dtype=torch.uint8, device=dev, generator=gen),
+            len(mine), slot_out,
+            lambda sr, d: [_image(j, sr[k].data_ptr(), d[k].data_ptr(), si, so, 0, 64) for k, (j, si, so) in enumerate(specs)])
+        torch.cuda.synchronize()
+        for k, t_in, t_out, f in seeded:
+            sm.upload(src[k].data_ptr(), f, local_rank)
+        torch.cuda.synchronize()
+    else:
+        src = torch.zeros((0, slot_in), dtype=torch.uint8, device=dev)
+        dst = torch.zeros((0, slot_out), dtype=torch.uint8, device=dev)
     w.keep = (src, dst)
     w.bytes_per_launch = algo
     w.out_pix_per_step = n_total * 64 * 64
@@ -334,20 +417,21 @@ def other_configs(dev, local_rank):
             rng = np.random.default_rng(20260202)
             slot_in = (h_in * (stride_in or w_in * 4) + 64 + 255) // 256 * 256      # 256-byte aligned images
             slot_out = (h_out * w_out * 4 + 64 + 255) // 256 * 256
-            src = torch.randint(0, 256, (n_img, slot_in), dtype=torch.uint8, device=dev)
-            dst = torch.zeros((n_img, slot_out), dtype=torch.uint8, device=dev)
-            jobs, images, algo = {}, [], 0
+            jobs, specs, algo = {}, [], 0
             for i in range(n_img):
                 t_in = int(rng.integers(0, 10)) if t_in0 < 0 else t_in0
                 t_out = int(rng.integers(0, 10)) if t_out0 < 0 else t_out0
                 if (t_in, t_out) not in jobs:
                     jobs[(t_in, t_out)] = sm.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
                 bi, bo = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
-                images.append(_image(jobs[(t_in, t_out)], src[i].data_ptr() + src_off, dst[i].data_ptr(),
-                                     stride_in or w_in * bi, w_out * bo, 0, h_out))
+                specs.append((jobs[(t_in, t_out)], stride_in or w_in * bi, w_out * bo))
                 algo += w_in * h_in * bi + w_out * h_out * bo
-            torch.cuda.synchronize()
-            b = sm.HipBatch(images, device=local_rank)
+            hold0 = len(PLACEMENT_HOLD)
+            src, dst, b, placement = pick_placement(
+                dev, local_rank, lambda: torch.randint(0, 256, (n_img, slot_in), dtype=torch.uint8, device=dev), n_img, slot_out,
+                lambda sr, d: [_image(j, sr[i].data_ptr() + src_off, d[i].data_ptr(), si, so, 0, h_out) for i, (j, si, so) in enumerate(specs)])
+            if not placement_on():
+                placement = None
             n_launches, kname = b.info()
             probe = b.time(2, 5) / 5
             each = b.time_each(int(200.0 / max(probe, 1e-3)), 20)
@@ -358,7 +442,7 @@ def other_configs(dev, local_rank):
                          "GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                          "frac_of_peak_best": round(algo / (st["min"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                          "Mpix_out_per_s": round(n_img * w_out * h_out / (st["mean"] * 1e-6) / 1e6, 1),
-                         "algorithmic_bytes_per_step": algo}
+                         "algorithmic_bytes_per_step": algo, "placement": placement}
             tr = traffic_all.get(name.split(" ", 1)[0])
             if tr and tr.get("algorithmic_bytes_per_step") == algo:
                 out[name]["traffic"] = tr.get("hbm_bytes_per_launch")
@@ -366,6 +450,7 @@ def other_configs(dev, local_rank):
                 out[name]["traffic_source"] = "static: %s (rocprofv3 --pmc, not this run)" % tr.get("source", "?")
             b.destroy()
             del src, dst
+            del PLACEMENT_HOLD[hold0:]               # (the side table comes after everything that is timed for the line's value)
         except Exception as e:                      # noqa: BLE001 -- a side table must not break the bench line
             out[name] = {"error": repr(e)}
     torch.cuda.empty_cache()
@@ -624,6 +709,9 @@ def main():
                     help="skip the side table of the other BASELINE configs (N=1 only, a few seconds)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the host-memory legs through the public API (N=1, c2: a few seconds)")
+    ap.add_argument("--no-placement", action="store_true",
+                    help="take the first source and destination arenas the allocator hands out (rounds 1-5) instead of probing "
+                         "a few candidates (pick_placement)")
     ap.add_argument("--backend", default="auto",
                     help="process group for the timing barrier: auto = RCCL ('nccl') when it comes up on every rank, "
                          "else gloo; or force 'nccl' / 'gloo'")
@@ -631,6 +719,8 @@ def main():
                     help="testing aid: rank r uses GPU r %% device_count (several ranks on one GPU)")
     args = ap.parse_args()
 
+    if args.no_placement:
+        globals()["PLACEMENT_DST_TRIES"] = 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -773,6 +863,10 @@ def main():
                 "step_us_each": stats_us(each) if each else None,
             },
             "verified_vs_oracle": {"all_ranks_ok": all_ok, "ranks_that_checked": n_checked},
+            # where the destination arena lies against the source arena (pick_destination, rank 0's report): us per launch
+            # into each candidate, and which one the timed region used
+            "placement": dict(w.placement or {}, what="arenas: best of the (source, destination) candidates listed (us per launch, a "
+                                                      "handful of launches each; one row per source arena); --no-placement takes the first"),
         }
         if args.config == "c5mix":
             line["images_per_s"] = round(10000 * args.steps / elapsed, 1)

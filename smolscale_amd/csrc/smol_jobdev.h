@@ -91,6 +91,7 @@ struct JobDev
     uint8_t hbox_force;            /* host side only, twopass_setup: bilinear x tall box (box2 == 3) -- 0 pick the splits of an output row's span from this
                                     * call's rows, n use n splits. A strip cut into chunks decides ONCE (its intermediate image is sized for the
                                     * strip's splits; a chunk of fewer rows would pick more: ADVICE round 5) */
+    uint8_t tile_ring;             /* k_tile: the LDS holds a RING of group_rows source rows, refilled row by row (smol_kernel_tile.hip.h) */
     uint32_t span_chunks;          /* 16-byte chunks per staged row (LDS row pitch / 16) */
     uint32_t span_chunks_inv;      /* floor(2^32 / span_chunks) + 1                      */
     uint32_t box_nmax;             /* horizontal box: most interior pixels any column has */
@@ -390,6 +391,38 @@ tile_setup (JobDev &d)
     /* (any row alignment since round 3: the dword-granular 24-bit store shifts the tile's byte run onto aligned dwords
      * itself, smol_kernel_tile.hip.h tile_store_cols; SMOL_OUT3_ALIGNED in tuning builds = the old 4-byte rule, for A/B) */
     d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && (!tune_env ("SMOL_OUT3_ALIGNED") || ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0));
+
+    /* Ring staging (round 6; smol_kernel_tile.hip.h): plain DMA staging only (tapsel 0, 2, 3). The ring holds enough rows
+     * that N DMA instructions stay in flight behind the row being consumed: a row of an interior tile takes at least kmin
+     * instructions of up to 1 KB. */
+    d.tile_ring = 0;
+    if (!d.wide && (tapsel == 0 || tapsel == 2 || tapsel == 3) && tune_env ("SMOL_TILE_RING"))
+    {
+        uint32_t n = (uint32_t) atoi (tune_env ("SMOL_TILE_RING"));
+        if (n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12)
+        {
+            uint64_t px_min;
+            if (d.filter_h == F_BOX)
+                px_min = (cols * d.step_x) >> 16;
+            else if (d.filter_h == F_BILINEAR)
+                px_min = ((((cols << d.halv_h) - 1u) * d.step_x) >> 32) + 1u;
+            else
+                px_min = (d.filter_h == F_ONE) ? 1 : cols;
+            if (px_min > d.w_in)
+                px_min = d.w_in;
+            const uint32_t kmin = ((((uint32_t) px_min * d.bpp_in + 15u) & ~15u) + 1023u) / 1024u;
+            uint32_t ring_rows = (n + kmin - 1u) / kmin + 1u;
+            if (const char *e = tune_env ("SMOL_TILE_RING_ROWS"))
+                ring_rows = (uint32_t) atoi (e);
+            if (ring_rows >= 2u && ring_rows <= 64u && ring_rows * d.span_chunks * 16u <= 48u * 1024u)
+            {
+                d.tile_ring = (uint8_t) n;
+                d.group_rows = (uint16_t) ring_rows;
+                d.tile_single = 1;              /* (one region of group_rows rows: tile_lds_bytes) */
+                return;
+            }
+        }
+    }
 
     /* ONE staging buffer of twice the size and no prefetch of the next row group (the resident waves cover
      * each other's latency, as in k_boxh) for the entry points where it measured ahead -- compiled in there

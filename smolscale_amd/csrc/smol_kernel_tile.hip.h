@@ -428,6 +428,14 @@ __device__ __forceinline__ void smol_wait_vmcnt0 ()
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+/* all but the wave's N youngest vector-memory operations are done (loads, LDS-DMA and stores count together, in issue
+ * order: MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)") */
+template <int N>
+__device__ __forceinline__ void smol_wait_vmcnt ()
+{
+    asm volatile ("s_waitcnt vmcnt(%0)" :: "n" (N) : "memory");
+}
+
 /* issue priority of this wave among the waves of its SIMD (0-3): raised while a wave requests its next row group, so
  * that the request is not queued behind the arithmetic of the waves next door */
 template <int P>
@@ -1023,11 +1031,334 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
     const uint32_t *inv_tab = nullptr;
     if (OUT == OUT_U4 || (OUT == OUT_ANY && J.unassoc_out))
     {
-        uint8_t *tab = sbuf + (single ? 1u : 2u) * buf_bytes;
+        uint8_t *tab = sbuf + ((single || (STAGE == TILE_STAGE_DMA && J.tile_ring)) ? 1u : 2u) * buf_bytes;
         smol_global_load_lds16 (reinterpret_cast<const uint8_t *> (smol_inv_p8_lut) + lane * 16u, tab, lane);
         if (!DMA)
             smol_wait_vmcnt0 ();
         inv_tab = reinterpret_cast<const uint32_t *> (tab);
+    }
+
+    /* ---- one staged source row: horizontal taps of this lane's columns, then whatever the vertical filter can emit ----
+     * rowbase: the row's 16-byte aligned start in LDS; r: its index in the source image; ra_lo: low bits of the address
+     * of the span's first byte in memory (its misalignment) */
+    auto consume_row = [&] (const uint8_t *rowbase, const uint32_t r, const uint32_t ra_lo) __attribute__ ((always_inline))
+    {
+        const uint32_t mis = ra_lo & 15u;
+        /* TAP_A4: mis is a multiple of 4, fold it into the row base. Otherwise keep
+         * the base 16-byte aligned and add mis to each tap's byte offset, so the
+         * unaligned reader's dword loads stay 4-byte aligned in LDS. */
+        const uint8_t *rowb = rowbase + ((TAP == TAP_A4) ? mis : 0u);
+        const uint32_t tmis = (TAP == TAP_A4) ? 0u : mis;
+
+        Px2 h [CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++)
+        {
+            if (dbg_notaps)
+            {
+                h [c].lo = tap_ofs [c][0] + r; h [c].hi = tap_f [c][0];
+            }
+            else if (HBOX && LPC == 1 && SMOL_TILE_BOXBATCH)
+            {
+                /* One lane per column: both edges and the interior in batches of four independent LDS
+                 * reads. Every column of an axis has fs - 2, fs - 1 or fs interior pixels (fs = floor of
+                 * the ratio; fs - 2 only where the last box is clipped at the image edge): the first
+                 * fs - 2 need no test, the last two are masked per lane (box_m0 / box_m1, set up once per
+                 * tile). The old loop read one pixel, waited, added: eleven LDS round trips per row. */
+                Px2 pp, qq;
+                const uint32_t off0 = tap_ofs [0][0] + tmis;
+                const TapRaw e0 = tile_tap_load<TAP, false> (rowb, off0);
+                const TapRaw e1 = tile_tap_load<TAP, false> (rowb, box_last + tmis);
+                uint32_t off = off0 + BPP;
+                uint32_t left = box_nfree;
+                Px2 a = { 0, 0 };
+                while (left >= 4u)
+                {
+                    /* the four pixels of a batch in a per-lane rotated order (box_rot [k] = BPP * ((k + lane) & 3)):
+                     * at ratios like 64/7 the lanes 7 apart start a whole number of bank rows apart and every read
+                     * of the plain order is a 5-way bank conflict (80 % of the LDS cycles of 4096 -> 448 were
+                     * conflict cycles: profiles/r03c_sq_box.txt); rotated, those lanes read four different words */
+                    TapRaw q4 [4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        q4 [k] = tile_tap_load<TAP, false> (rowb, off + (SMOL_TILE_BOXROT ? box_rot [k] : k * BPP));
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                    {
+                        tile_tap_unpack<TAP, false> (J, q4 [k], off + (SMOL_TILE_BOXROT ? box_rot [k] : k * BPP), pp, qq);
+                        a = px2_add (a, pp);
+                    }
+                    off += 4u * BPP;
+                    left -= 4u;
+                }
+                {
+                    /* 0-3 untested pixels, then the two masked ones: one batch of up to five reads */
+                    TapRaw q5 [5];
+#pragma unroll
+                    for (uint32_t k = 0; k < 3; k++)
+                        if (k < left)
+                            q5 [k] = tile_tap_load<TAP, false> (rowb, off + k * BPP);
+                    const uint32_t offm = off + left * BPP;
+                    q5 [3] = tile_tap_load<TAP, false> (rowb, offm);
+                    q5 [4] = tile_tap_load<TAP, false> (rowb, offm + BPP);
+#pragma unroll
+                    for (uint32_t k = 0; k < 3; k++)
+                        if (k < left)
+                        {
+                            tile_tap_unpack<TAP, false> (J, q5 [k], off + k * BPP, pp, qq);
+                            a = px2_add (a, pp);
+                        }
+                    tile_tap_unpack<TAP, false> (J, q5 [3], offm, pp, qq);
+                    pp.lo &= box_m0; pp.hi &= box_m0;
+                    a = px2_add (a, pp);
+                    tile_tap_unpack<TAP, false> (J, q5 [4], offm + BPP, pp, qq);
+                    pp.lo &= box_m1; pp.hi &= box_m1;
+                    a = px2_add (a, pp);
+                }
+                /* the edges were requested first and are consumed last */
+                tile_tap_unpack<TAP, false> (J, e0, off0, pp, qq);
+                a = px2_add (a, px2_mulw (pp, box_wl));
+                tile_tap_unpack<TAP, false> (J, e1, box_last + tmis, pp, qq);
+                a = px2_add (a, px2_mulw (pp, box_fr));
+                h [c] = px2_box_scale (a, J.span_mul_x);
+            }
+            else if (HBOX)
+            {
+                Px2 pp, qq;
+                Px2 a = { 0, 0 };
+                if (sub == 0)
+                {
+                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis, pp, qq);
+                    a = px2_mulw (pp, box_wl);
+                    tile_read_pair<TAP, false> (J, rowb, box_last + tmis, pp, qq);
+                    a = px2_add (a, px2_mulw (pp, box_fr));
+                }
+                /* interior pixels: lane `sub' of the group takes every LPC-th one */
+                for (uint32_t ii = sub; ii < J.box_nmax; ii += LPC)
+                {
+                    if (ii < box_n)
+                    {
+                        tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis + (ii + 1) * BPP, pp, qq);
+                        a = px2_add (a, pp);
+                    }
+                }
+                if (LPC > 1)
+                {
+#pragma unroll
+                    for (uint32_t m = 1; m < LPC; m <<= 1)
+                    {
+                        Px2 o2;
+                        o2.lo = smol_shfl_xor (a.lo, m);
+                        o2.hi = smol_shfl_xor (a.hi, m);
+                        a = px2_add (a, o2);
+                    }
+                }
+                h [c] = px2_box_scale (a, J.span_mul_x);
+            }
+            else if (HM == 0)
+            {
+                Px2 pp, qq;
+                tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, pp, qq);
+                h [c] = pp;
+            }
+            else
+            {
+#pragma unroll
+                for (uint32_t s = 0; s < NSX; s++)
+                {
+                    Px2 pp, qq;
+                    tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
+                    const Px2 t = tap2 (pp, qq, tap_f [c][s]);
+                    h [c] = s ? px2_add (h [c], t) : t;
+                }
+                if (HX)
+                    h [c] = px2_shr (h [c], HX);
+            }
+        }
+
+        if (vbox)
+        {
+            /* vertical box (smolscale-generic.c:2026-2161): rows arrive in order;
+             * the box's first row is weighted vw1, interior rows count in full, its
+             * last row (oy) is weighted Fy and, weighted 255 - Fy, also opens the
+             * next box. Sums stay below 2^16 per lane, as in the reference. */
+            if (r == vy0)
+                acc [0] = px2_mulw (h [0], vw1);
+            else if (r < oy)
+                acc [0] = px2_add (acc [0], h [0]);
+            if (r == oy)
+            {
+                Px2 o [CPL];
+                o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
+                if (!dbg_nostore)
+                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, full24, o, inv_tab);
+                out_row += J.dst_stride;
+                ks++;
+                vy0 = oy;
+                vw1 = 255u - Fy;
+                acc [0] = px2_mulw (h [0], vw1);
+                e = smol_readlane (sched, ks);      /* past the last sample: the sentinel */
+                oy = e & 0xffffu;
+                Fy = e >> 16;
+            }
+        }
+        else if (VCOPY)
+        {
+            /* vertical copy: this row is an output row */
+            if (!dbg_nostore)
+                tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, h, inv_tab);
+            out_row += J.dst_stride;
+        }
+        else
+        /* vertical: emit every sample whose last row is r */
+        while (oy + vlag == r)
+        {
+            if (hv == 0)
+            {
+                /* no vertical halvings: the sample is the output row */
+                Px2 o [CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    o [c] = vpair ? tap2 (hprev [c], h [c], Fy) : h [c];
+                if (!dbg_nostore)
+                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o, inv_tab);
+                out_row += J.dst_stride;
+                ks++;
+                e = smol_readlane (sched, ks);
+                oy = e & 0xffffu;
+                Fy = e >> 16;
+                continue;
+            }
+            /* acc is zero at the first sample of an output row */
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+            {
+                Px2 t = h [c];
+                if (vpair)
+                    t = tap2 (hprev [c], h [c], Fy);
+                acc [c] = px2_add (acc [c], t);
+            }
+            s_y++;
+            ks++;
+            if (s_y == nsy)
+            {
+                Px2 o [CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                {
+                    o [c] = px2_shr (acc [c], hv);
+                    acc [c].lo = acc [c].hi = 0;
+                }
+                if (!dbg_nostore)
+                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o, inv_tab);
+                s_y = 0;
+                out_row += J.dst_stride;
+            }
+            e = smol_readlane (sched, ks);          /* past the last sample: the sentinel */
+            oy = e & 0xffffu;
+            Fy = e >> 16;
+        }
+        if (!VCOPY)
+        {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                hprev [c] = h [c];
+        }
+    };
+
+    /* ---- ring staging (round 6) -------------------------------------------------------------------------------------
+     * The two-buffer scheme keeps ONE row group in flight per wave while the other is consumed, and a tile of 13 source rows
+     * pays the memory latency two or three times in a row. Here the LDS holds a ring of J.group_rows rows: the tile's first
+     * rows are all requested up front, a row is consumed as soon as IT has landed -- vector-memory operations retire in
+     * issue order, so "all but the N youngest are done" (s_waitcnt vmcnt(N)) means row r is there once the ring's other
+     * rows, at least N DMA instructions, were requested after it -- and its slot is handed to the next row at once: the
+     * ring's other rows stay in flight through the arithmetic. The wait takes an immediate, so N = J.tile_ring is one of a
+     * few values; the host sizes the ring so that the rows behind any row make up at least N instructions (tile_setup),
+     * tiles whose rows are shorter than that (clipped at the image's edge) drain instead. */
+    if (DMA && STAGE == TILE_STAGE_DMA && J.tile_ring)
+    {
+        const uint32_t ring_n = J.tile_ring;                    /* 2, 3, 4, 6, 8 or 12 (tile_setup) */
+        const uint32_t ring_rows = J.group_rows;
+        const uint32_t total = row_last - row_first + 1u;
+        const uintptr_t ra = src_base + (size_t) row_first * J.src_stride + g0;
+        const uint8_t *a0 = reinterpret_cast<const uint8_t *> (ra & ~(uintptr_t) 15);  /* aligned start of the next row to request */
+        uint32_t imis = (uint32_t) ra & 15u;
+        const uint32_t span15 = g1 - g0 + 15u;
+        const uint32_t lane16 = lane * 16u;
+        uint8_t *const ring_end = sbuf + ring_rows * row_pitch;
+        uint8_t *slot = sbuf;                                   /* the slot that is consumed next; once consumed, requested into */
+        uint32_t to_issue = total;
+        /* DMA instructions a row of this tile takes at least (its span with no misalignment in front) */
+        const uint32_t kmin = ((span15 & ~15u) + TILE_COLS * 16u - 1u) / (TILE_COLS * 16u);
+        const bool counted = (ring_rows - 1u) * kmin >= ring_n;
+
+        auto request_row = [&] (uint8_t *rowdst) __attribute__ ((always_inline))
+        {
+            const uint32_t nbytes = (imis + span15) & ~15u;     /* whole 16-byte chunks from the aligned start */
+            if (!dbg_nostage)
+            {
+                uint32_t k0 = 0;
+                do
+                {
+                    if (k0 + lane16 < nbytes)
+                        smol_global_load_lds16 (a0 + (k0 + lane16), rowdst + k0, lane);
+                    k0 += TILE_COLS * 16u;
+                }
+                while (k0 < nbytes);
+            }
+            const uint32_t t = imis + (uint32_t) J.src_stride;
+            a0 += t & ~15u;
+            imis = t & 15u;
+            to_issue--;
+        };
+
+        {
+            uint8_t *d = sbuf;
+            smol_setprio<3> ();
+            for (uint32_t n = total < ring_rows ? total : ring_rows; n; n--, d += row_pitch)
+                request_row (d);
+            smol_setprio<0> ();
+        }
+        uint32_t ra_lo = (uint32_t) ra;
+        uint32_t r = row_first;
+        /* steady state: one row out, one row in */
+        for (; to_issue; r++, ra_lo += J.src_stride)
+        {
+            if (!counted)
+                smol_wait_vmcnt0 ();
+            else if (ring_n == 8u)
+                smol_wait_vmcnt<8> ();
+            else if (ring_n == 4u)
+                smol_wait_vmcnt<4> ();
+            else if (ring_n == 6u)
+                smol_wait_vmcnt<6> ();
+            else if (ring_n == 12u)
+                smol_wait_vmcnt<12> ();
+            else if (ring_n == 3u)
+                smol_wait_vmcnt<3> ();
+            else
+                smol_wait_vmcnt<2> ();
+            smol_wave_sync ();
+            consume_row (slot, r, ra_lo);
+            smol_wave_sync ();
+            smol_setprio<3> ();
+            request_row (slot);
+            smol_setprio<0> ();
+            slot += row_pitch;
+            if (slot == ring_end)
+                slot = sbuf;
+        }
+        /* the ring's last rows: everything is requested */
+        smol_wait_vmcnt0 ();
+        smol_wave_sync ();
+        for (; r <= row_last; r++, ra_lo += J.src_stride)
+        {
+            consume_row (slot, r, ra_lo);
+            slot += row_pitch;
+            if (slot == ring_end)
+                slot = sbuf;
+        }
+        return;
     }
 
     if (DMA && !dbg_nostage && !single)
@@ -1090,230 +1421,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
         uint32_t ra_lo = (uint32_t) (src_base + (size_t) gfirst * J.src_stride + g0);   /* low bits of the row's first byte */
         const uint8_t *rowbase = buf;
         for (uint32_t i = 0; i < nrows; i++, ra_lo += J.src_stride, rowbase += row_pitch)
-        {
-            const uint32_t r = gfirst + i;
-            const uint32_t mis = ra_lo & 15u;
-            /* TAP_A4: mis is a multiple of 4, fold it into the row base. Otherwise keep
-             * the base 16-byte aligned and add mis to each tap's byte offset, so the
-             * unaligned reader's dword loads stay 4-byte aligned in LDS. */
-            const uint8_t *rowb = rowbase + ((TAP == TAP_A4) ? mis : 0u);
-            const uint32_t tmis = (TAP == TAP_A4) ? 0u : mis;
-
-            Px2 h [CPL];
-#pragma unroll
-            for (int c = 0; c < CPL; c++)
-            {
-                if (dbg_notaps)
-                {
-                    h [c].lo = tap_ofs [c][0] + r; h [c].hi = tap_f [c][0];
-                }
-                else if (HBOX && LPC == 1 && SMOL_TILE_BOXBATCH)
-                {
-                    /* One lane per column: both edges and the interior in batches of four independent LDS
-                     * reads. Every column of an axis has fs - 2, fs - 1 or fs interior pixels (fs = floor of
-                     * the ratio; fs - 2 only where the last box is clipped at the image edge): the first
-                     * fs - 2 need no test, the last two are masked per lane (box_m0 / box_m1, set up once per
-                     * tile). The old loop read one pixel, waited, added: eleven LDS round trips per row. */
-                    Px2 pp, qq;
-                    const uint32_t off0 = tap_ofs [0][0] + tmis;
-                    const TapRaw e0 = tile_tap_load<TAP, false> (rowb, off0);
-                    const TapRaw e1 = tile_tap_load<TAP, false> (rowb, box_last + tmis);
-                    uint32_t off = off0 + BPP;
-                    uint32_t left = box_nfree;
-                    Px2 a = { 0, 0 };
-                    while (left >= 4u)
-                    {
-                        /* the four pixels of a batch in a per-lane rotated order (box_rot [k] = BPP * ((k + lane) & 3)):
-                         * at ratios like 64/7 the lanes 7 apart start a whole number of bank rows apart and every read
-                         * of the plain order is a 5-way bank conflict (80 % of the LDS cycles of 4096 -> 448 were
-                         * conflict cycles: profiles/r03c_sq_box.txt); rotated, those lanes read four different words */
-                        TapRaw q4 [4];
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++)
-                            q4 [k] = tile_tap_load<TAP, false> (rowb, off + (SMOL_TILE_BOXROT ? box_rot [k] : k * BPP));
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++)
-                        {
-                            tile_tap_unpack<TAP, false> (J, q4 [k], off + (SMOL_TILE_BOXROT ? box_rot [k] : k * BPP), pp, qq);
-                            a = px2_add (a, pp);
-                        }
-                        off += 4u * BPP;
-                        left -= 4u;
-                    }
-                    {
-                        /* 0-3 untested pixels, then the two masked ones: one batch of up to five reads */
-                        TapRaw q5 [5];
-#pragma unroll
-                        for (uint32_t k = 0; k < 3; k++)
-                            if (k < left)
-                                q5 [k] = tile_tap_load<TAP, false> (rowb, off + k * BPP);
-                        const uint32_t offm = off + left * BPP;
-                        q5 [3] = tile_tap_load<TAP, false> (rowb, offm);
-                        q5 [4] = tile_tap_load<TAP, false> (rowb, offm + BPP);
-#pragma unroll
-                        for (uint32_t k = 0; k < 3; k++)
-                            if (k < left)
-                            {
-                                tile_tap_unpack<TAP, false> (J, q5 [k], off + k * BPP, pp, qq);
-                                a = px2_add (a, pp);
-                            }
-                        tile_tap_unpack<TAP, false> (J, q5 [3], offm, pp, qq);
-                        pp.lo &= box_m0; pp.hi &= box_m0;
-                        a = px2_add (a, pp);
-                        tile_tap_unpack<TAP, false> (J, q5 [4], offm + BPP, pp, qq);
-                        pp.lo &= box_m1; pp.hi &= box_m1;
-                        a = px2_add (a, pp);
-                    }
-                    /* the edges were requested first and are consumed last */
-                    tile_tap_unpack<TAP, false> (J, e0, off0, pp, qq);
-                    a = px2_add (a, px2_mulw (pp, box_wl));
-                    tile_tap_unpack<TAP, false> (J, e1, box_last + tmis, pp, qq);
-                    a = px2_add (a, px2_mulw (pp, box_fr));
-                    h [c] = px2_box_scale (a, J.span_mul_x);
-                }
-                else if (HBOX)
-                {
-                    Px2 pp, qq;
-                    Px2 a = { 0, 0 };
-                    if (sub == 0)
-                    {
-                        tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis, pp, qq);
-                        a = px2_mulw (pp, box_wl);
-                        tile_read_pair<TAP, false> (J, rowb, box_last + tmis, pp, qq);
-                        a = px2_add (a, px2_mulw (pp, box_fr));
-                    }
-                    /* interior pixels: lane `sub' of the group takes every LPC-th one */
-                    for (uint32_t ii = sub; ii < J.box_nmax; ii += LPC)
-                    {
-                        if (ii < box_n)
-                        {
-                            tile_read_pair<TAP, false> (J, rowb, tap_ofs [0][0] + tmis + (ii + 1) * BPP, pp, qq);
-                            a = px2_add (a, pp);
-                        }
-                    }
-                    if (LPC > 1)
-                    {
-#pragma unroll
-                        for (uint32_t m = 1; m < LPC; m <<= 1)
-                        {
-                            Px2 o2;
-                            o2.lo = smol_shfl_xor (a.lo, m);
-                            o2.hi = smol_shfl_xor (a.hi, m);
-                            a = px2_add (a, o2);
-                        }
-                    }
-                    h [c] = px2_box_scale (a, J.span_mul_x);
-                }
-                else if (HM == 0)
-                {
-                    Px2 pp, qq;
-                    tile_read_pair<TAP, false> (J, rowb, tap_ofs [c][0] + tmis, pp, qq);
-                    h [c] = pp;
-                }
-                else
-                {
-#pragma unroll
-                    for (uint32_t s = 0; s < NSX; s++)
-                    {
-                        Px2 pp, qq;
-                        tile_read_pair<TAP, true> (J, rowb, tap_ofs [c][s] + tmis, pp, qq);
-                        const Px2 t = tap2 (pp, qq, tap_f [c][s]);
-                        h [c] = s ? px2_add (h [c], t) : t;
-                    }
-                    if (HX)
-                        h [c] = px2_shr (h [c], HX);
-                }
-            }
-
-            if (vbox)
-            {
-                /* vertical box (smolscale-generic.c:2026-2161): rows arrive in order;
-                 * the box's first row is weighted vw1, interior rows count in full, its
-                 * last row (oy) is weighted Fy and, weighted 255 - Fy, also opens the
-                 * next box. Sums stay below 2^16 per lane, as in the reference. */
-                if (r == vy0)
-                    acc [0] = px2_mulw (h [0], vw1);
-                else if (r < oy)
-                    acc [0] = px2_add (acc [0], h [0]);
-                if (r == oy)
-                {
-                    Px2 o [CPL];
-                    o [0] = px2_box_scale (px2_add (acc [0], px2_mulw (h [0], Fy)), J.span_mul_y);
-                    if (!dbg_nostore)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, false, full24, o, inv_tab);
-                    out_row += J.dst_stride;
-                    ks++;
-                    vy0 = oy;
-                    vw1 = 255u - Fy;
-                    acc [0] = px2_mulw (h [0], vw1);
-                    e = smol_readlane (sched, ks);      /* past the last sample: the sentinel */
-                    oy = e & 0xffffu;
-                    Fy = e >> 16;
-                }
-            }
-            else if (VCOPY)
-            {
-                /* vertical copy: this row is an output row */
-                if (!dbg_nostore)
-                    tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, h, inv_tab);
-                out_row += J.dst_stride;
-            }
-            else
-            /* vertical: emit every sample whose last row is r */
-            while (oy + vlag == r)
-            {
-                if (hv == 0)
-                {
-                    /* no vertical halvings: the sample is the output row */
-                    Px2 o [CPL];
-#pragma unroll
-                    for (int c = 0; c < CPL; c++)
-                        o [c] = vpair ? tap2 (hprev [c], h [c], Fy) : h [c];
-                    if (!dbg_nostore)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o, inv_tab);
-                    out_row += J.dst_stride;
-                    ks++;
-                    e = smol_readlane (sched, ks);
-                    oy = e & 0xffffu;
-                    Fy = e >> 16;
-                    continue;
-                }
-                /* acc is zero at the first sample of an output row */
-#pragma unroll
-                for (int c = 0; c < CPL; c++)
-                {
-                    Px2 t = h [c];
-                    if (vpair)
-                        t = tap2 (hprev [c], h [c], Fy);
-                    acc [c] = px2_add (acc [c], t);
-                }
-                s_y++;
-                ks++;
-                if (s_y == nsy)
-                {
-                    Px2 o [CPL];
-#pragma unroll
-                    for (int c = 0; c < CPL; c++)
-                    {
-                        o [c] = px2_shr (acc [c], hv);
-                        acc [c].lo = acc [c].hi = 0;
-                    }
-                    if (!dbg_nostore)
-                        tile_store_cols<OUT, CPL> (J, out_row, xl, xn_store, interior && LPC == 1, full24, o, inv_tab);
-                    s_y = 0;
-                    out_row += J.dst_stride;
-                }
-                e = smol_readlane (sched, ks);          /* past the last sample: the sentinel */
-                oy = e & 0xffffu;
-                Fy = e >> 16;
-            }
-            if (!VCOPY)
-            {
-#pragma unroll
-                for (int c = 0; c < CPL; c++)
-                    hprev [c] = h [c];
-            }
-        }
+            consume_row (rowbase, gfirst + i, ra_lo);
 
         gfirst += nrows;
         if (gfirst > row_last)

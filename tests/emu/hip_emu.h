@@ -57,6 +57,7 @@ static inline void smol_global_load_lds16 (const void *gptr, uint8_t *lds_wave_b
     memcpy (lds_wave_base + 16 * lane, gptr, 16);
 }
 static inline void smol_wait_vmcnt0 (void) {}
+template <int N> static inline void smol_wait_vmcnt (void) {}
 static inline void smol_wave_sync (void) { __syncthreads (); }
 static inline uint32_t smol_wave_index (void) { return 0; }       /* emulated blocks are one wave */
 
