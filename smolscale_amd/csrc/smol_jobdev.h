@@ -392,13 +392,29 @@ tile_setup (JobDev &d)
      * itself, smol_kernel_tile.hip.h tile_store_cols; SMOL_OUT3_ALIGNED in tuning builds = the old 4-byte rule, for A/B) */
     d.out3_ok = (d.bpp_out == 3 && !d.unassoc_out && (!tune_env ("SMOL_OUT3_ALIGNED") || ((((uintptr_t) d.dst) | d.dst_stride) & 3) == 0));
 
-    /* Ring staging (round 6; smol_kernel_tile.hip.h): plain DMA staging only (tapsel 0, 2, 3). The ring holds enough rows
-     * that N DMA instructions stay in flight behind the row being consumed: a row of an interior tile takes at least kmin
-     * instructions of up to 1 KB. */
+    /* Ring staging (round 6; smol_kernel_tile.hip.h): the LDS holds a ring of source rows that is refilled row by row, so that
+     * N DMA instructions stay in flight behind the row being consumed -- instead of two buffers of which one is in flight and a
+     * tile that pays the memory latency once per row group. Plain DMA staging only (tapsel 0, 2, 3), bilinear on both axes,
+     * both minifying or both magnifying, N = 4: the reference's proportional sweep (every 5th size, device resident) one
+     * kernel per image 1080p 7.17e11 -> 7.47e11 pixels per second, 4K 1.03e12 -> 1.08e12, 8K 1.11e12 -> 1.16e12; as one launch
+     * 1.335e12 -> 1.369e12, 4K and 8K within the runs' spread; 4096^2 -> 1365^2 115 -> 109 us, -> 1170^2 107 -> 103, -> 819^2
+     * 107 -> 104, -> 2731^2 96 -> 93.5, 3840x2160 x1.1 73.7 -> 71.4. Deeper rings lose again (N = 12: every row slower), a box axis
+     * and mixed axes lose with every depth (4096x2048 -> 2731x3000 75 -> 89 us, 4096^2 -> 256^2 98 -> 106): they keep the two
+     * buffers (profiles/r06_tile_ring.txt). The ring holds enough rows that N instructions lie behind any row of an interior
+     * tile: such a row takes at least kmin instructions of up to 1 KB. */
     d.tile_ring = 0;
-    if (!d.wide && (tapsel == 0 || tapsel == 2 || tapsel == 3) && tune_env ("SMOL_TILE_RING"))
+    if (!d.wide && (tapsel == 0 || tapsel == 2 || tapsel == 3) && !tune_env ("SMOL_NO_TILE_RING"))
     {
-        uint32_t n = (uint32_t) atoi (tune_env ("SMOL_TILE_RING"));
+        uint32_t n = 4;
+        if (const char *e = tune_env ("SMOL_TILE_RING"))
+            n = (uint32_t) atoi (e);
+        /* which jobs: 1 bilinear minification on both axes, 2 magnification on both, 4 one of each, 8 a box axis, 16 a COPY / ONE axis */
+        const bool bil = d.filter_h == F_BILINEAR && d.filter_v == F_BILINEAR;
+        const bool dn_x = d.step_x >= ((uint64_t) 1 << 32), dn_y = d.step_y >= ((uint64_t) 1 << 32);
+        const uint32_t cls = (d.filter_h == F_BOX || d.filter_v == F_BOX) ? 8u : !bil ? 16u : (dn_x && dn_y) ? 1u : (!dn_x && !dn_y) ? 2u : 4u;
+        const uint32_t want = tune_env ("SMOL_TILE_RING_CLASS") ? (uint32_t) atoi (tune_env ("SMOL_TILE_RING_CLASS")) : 3u;
+        if (!(cls & want))
+            n = 0;
         if (n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12)
         {
             uint64_t px_min;

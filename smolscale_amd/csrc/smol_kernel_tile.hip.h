@@ -1326,10 +1326,10 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
         {
             if (!counted)
                 smol_wait_vmcnt0 ();
+            else if (ring_n == 4u)              /* (what the shipped rule picks; the others: tuning builds) */
+                smol_wait_vmcnt<4> ();
             else if (ring_n == 8u)
                 smol_wait_vmcnt<8> ();
-            else if (ring_n == 4u)
-                smol_wait_vmcnt<4> ();
             else if (ring_n == 6u)
                 smol_wait_vmcnt<6> ();
             else if (ring_n == 12u)

@@ -181,7 +181,7 @@ def natural_bytes(n_bytes, bytes_pp, width, rng):
 IMAGES_OVERRIDE = None      # --images N
 
 
-def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False, natural=False):
+def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False, natural=False, hold=None):
     if name.startswith("G:"):
         # ad-hoc geometry: G:t_in:w_in:h_in:t_out:w_out:h_out:n_images[:srgb]
         f = [int(v) for v in name.split(":")[1:]]
@@ -319,6 +319,13 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
         line["bit_exact_first_rows_vs_oracle"] = bool(
             checker(host_src_kept, t_in, w_in, h_in, s_in, t_out, w_out, h_out, s_out, srgb, got))
     batch.destroy()
+    if hold is not None:
+        # placement tries (main): this build's memory stays allocated until every try of the config is done -- freed now, the
+        # next build would get the same pages back (profiles/r06_headline_modes.txt)
+        hold.extend(x for ab in bufs for x in ab)
+        if arena_in is not None:
+            hold.extend([arena_in, arena_out])
+        return line
     for a, b in bufs:
         a.free()
         b.free()
@@ -342,12 +349,26 @@ def main(argv=None, checker=None):
     ap.add_argument("--natural", action="store_true", help="image-like source bytes (smooth ramps + a little noise) instead of white noise")
     ap.add_argument("--images", type=int, default=None, help="override the number of images per launch")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of warm-up load before timing (clock settling)")
+    ap.add_argument("--placement", type=int, default=1, help="build every config this many times (memory kept) and report the fastest build")
     args = ap.parse_args(argv)
     global IMAGES_OVERRIDE
     IMAGES_OVERRIDE = args.images
     for name in args.configs.split(","):
-        print(json.dumps(run_config(name, args.iters, args.warmup, checker, args.graph,
-                                    args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena, args.natural)), flush=True)
+        if args.placement <= 1:
+            print(json.dumps(run_config(name, args.iters, args.warmup, checker, args.graph,
+                                        args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena, args.natural)), flush=True)
+            continue
+        # where the driver puts a config's arenas is worth up to 14 % on the 2-3 GB configs (profiles/r06_headline_modes.txt; bench.py
+        # pick_placement): the config built `placement' times with every build's memory kept, the fastest build's line printed
+        hold, lines = [], []
+        for _ in range(args.placement):
+            lines.append(run_config(name, args.iters, args.warmup, checker, args.graph, args.tin, args.tout, args.srgb,
+                                    args.settle if not lines else min(args.settle, 0.1), args.opaque, args.no_arena, args.natural, hold=hold))
+        best = min(lines, key=lambda ln: ln["step_us"])
+        best["placement_tries_us"] = [ln["step_us"] for ln in lines]
+        print(json.dumps(best), flush=True)
+        for x in hold:
+            x.free()
 
 
 if __name__ == "__main__":
