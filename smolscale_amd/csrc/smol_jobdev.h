@@ -1007,6 +1007,13 @@ boxh_lpc (const JobDev &d)
     return (d.step_x > (boxh_lpc8_min () << 16)) ? 8u : 1u;
 }
 
+/* k_boxh without a row buffer (smol_kernel_box2.hip.h: boxh_direct_body): the 128bpp class's whole-wave-per-column flavour */
+inline bool
+boxh_direct_ok (const JobDev &d, uint32_t lpc)
+{
+    return d.wide && lpc == 64u && !tune_env ("SMOL_NO_BOXH_DIRECT");
+}
+
 inline bool
 box2_setup (JobDev &d)
 {
@@ -1053,9 +1060,15 @@ box2_setup (JobDev &d)
     if (span_px > d.w_in)
         span_px = d.w_in;
     const uint32_t bytes = (uint32_t) span_px * d.bpp_in + 15 + 8;
-    const uint32_t chunks = (bytes + 15) / 16;
+    uint32_t chunks = (bytes + 15) / 16;
     if (chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
-        return false;                           /* four waves' row buffers must fit the LDS (nothing of d touched yet) */
+    {
+        /* four waves' row buffers must fit the LDS (nothing of d touched yet). A span beyond that -- more than ~9 600 pixels
+         * per column, the whole wave on one column -- is read straight from memory (boxh_direct_body, round 6): no chunks */
+        if (!boxh_direct_ok (d, lpc))
+            return false;
+        chunks = 0;
+    }
 
     boxh_geometry (d, lpc, span_px, chunks);
     d.box2_vlpc = (d.step_y > (lpc8_min << 16)) ? 8 : 1;
@@ -1081,7 +1094,7 @@ boxh_geometry (JobDev &d, uint32_t lpc, uint64_t span_px, uint32_t chunks)
     }
     d.span_px = (uint32_t) span_px;
     d.span_chunks = chunks;
-    d.span_chunks_inv = (uint32_t) (((uint64_t) 1 << 32) / chunks) + 1;
+    d.span_chunks_inv = chunks ? (uint32_t) (((uint64_t) 1 << 32) / chunks) + 1 : 0u;
     /* most interior pixels a lane walks: a column's span o0 .. o1 has o1 - o0 <= floor (step) + 1, its interior one less */
     d.box_nmax = ((uint32_t) (d.step_x >> 16) + lpc - 1) / lpc;
 }
@@ -1281,9 +1294,13 @@ twopass_setup (JobDev &d)
         uint64_t span_px = (((64u / lpc) * t.step_x) >> 16) + 2;
         if (span_px > t.w_in)
             span_px = t.w_in;
-        const uint32_t chunks = ((uint32_t) span_px * t.bpp_in + 15 + 8 + 15) / 16;
+        uint32_t chunks = ((uint32_t) span_px * t.bpp_in + 15 + 8 + 15) / 16;
         if (chunks * 16u * 4u + DOWN_LUT_BYTES_FWD + 64u > 160u * 1024u)
-            return false;
+        {
+            if (!boxh_direct_ok (t, lpc))
+                return false;
+            chunks = 0;                         /* (straight from memory: boxh_direct_body) */
+        }
         boxh_geometry (t, lpc, span_px, chunks);
     }
     else

@@ -385,6 +385,121 @@ __device__ __forceinline__ void boxh_body (const JobDev &J, uint8_t *lds, const 
     }
 }
 
+/* k_boxh for columns whose span does not fit the LDS (round 6): the whole wave on ONE column, its pixels read STRAIGHT from
+ * memory. A box that is summed reads every pixel once, so the LDS row buffer of boxh_body buys nothing but coalesced 16-byte
+ * loads -- and four waves' buffers hold 9 600 pixels per column at most: a 65 535-pixel row boxed into ONE pixel (and
+ * every horizontal ratio beyond 9 600) used to end in k_general<true>, one LANE walking the row (3.3 % of
+ * tools/fuzz/gpu_fuzz.py's cases, at a few per cent of the roofline). Here lane l takes the interior pixels l, l + 64,
+ * l + 128 ... of the column -- one dword per lane, a wave instruction reads 256 (192 for 24-bit rows) contiguous bytes,
+ * eight of them in flight --, converts (the wave's flavour, as boxh_body), sums in 32 bits; the lanes meet in a shuffle
+ * butterfly (sums of exact integers: smolscale-generic.c:1481-1556 adds them in pixel order, modulo 2^32 like these),
+ * lane 0 adds the two weighted edge pixels, normalises and writes the intermediate pixel. 128bpp class only (a ratio
+ * beyond 255). JobDev::span_chunks == 0 marks the job (smol_jobdev.h: box2_setup, twopass_setup). */
+template <typename UN>
+__device__ __forceinline__ void boxh_direct_rows (const JobDev &J, const UN &un, const uint32_t lane, const uint32_t x,
+                                                  const uint32_t r0, const uint32_t r1)
+{
+    uint32_t o0, o1, fr, wl;
+    box_span (J.step_x, J.w_in, x, o0, o1, fr, wl);
+    const uint32_t n_col = o1 - o0 - 1;                             /* interior pixels of the column */
+    const uint32_t bpp = J.bpp_in;
+    const uint32_t last_px = J.w_in - 1u;
+    constexpr uint32_t U = 8;
+
+    /* pixel p of the row as its bytes in memory order; a 24-bit pixel is the dword at its own byte address, the row's last
+     * one read a byte early and shifted (nothing past the row is touched: k_lind's rule) */
+    auto load_px = [&] (const gbyte *row, uint32_t p) -> uint32_t
+    {
+        uint32_t w;
+        if (bpp == 4)
+        {
+#ifdef SMOL_KERNEL_EMU
+            __builtin_memcpy (&w, row + (size_t) p * 4u, 4);
+#else
+            w = *reinterpret_cast<const SMOL_AS_GLOBAL u32a1 *> (row + (size_t) p * 4u);
+#endif
+            return w;
+        }
+        const uint32_t sh = (p == last_px && p != 0u) ? 1u : 0u;
+#ifdef SMOL_KERNEL_EMU
+        w = 0;
+        __builtin_memcpy (&w, row + (size_t) p * 3u - sh, (p == last_px && p == 0u) ? 3 : 4);
+#else
+        w = *reinterpret_cast<const SMOL_AS_GLOBAL u32a1 *> (row + (size_t) p * 3u - sh);
+#endif
+        return __builtin_amdgcn_alignbyte (0u, w, sh) | 0xff000000u;
+    };
+
+    for (uint32_t r = r0; r <= r1; r++)
+    {
+        const gbyte *row = gptr (J.src) + (size_t) r * J.src_stride;
+        uint32_t acc [4] = { 0, 0, 0, 0 };
+        for (uint32_t base = 0; base < n_col; base += 64u * U)     /* (wave-uniform trip count) */
+        {
+            const uint32_t i = base + lane;
+            uint32_t w [U], c [4];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++)
+            {
+                const uint32_t k = i + 64u * u;
+                w [u] = load_px (row, o0 + 1u + (k < n_col ? k : 0u));  /* (past the column: its first interior pixel again, masked below) */
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++)
+            {
+                un (w [u], c);
+                const uint32_t m = (i + 64u * u < n_col) ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                    acc [ch] += c [ch] & m;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+            acc [ch] = wave_sum (acc [ch]);
+        if (lane == 0)
+        {
+            uint32_t c [4];
+            un (load_px (row, o0), c);
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                acc [ch] += ((c [ch] * wl) >> 8) & 0x00ffffffu;
+            un (load_px (row, o1), c);
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                acc [ch] += ((c [ch] * fr) >> 8) & 0x00ffffffu;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                acc [ch] = box_scale<true> (acc [ch], J.span_mul_x);
+            *reinterpret_cast<SMOL_AS_GLOBAL u32x2a8 *> (gptr (J.tmp) + ((size_t) (r - J.tmp_row0) * J.w_out + x) * 8)
+                = u32x2a8 { acc [0] | (acc [1] << 16), acc [2] | (acc [3] << 16) };
+        }
+    }
+}
+
+__device__ __forceinline__ void boxh_direct_body (const JobDev &J, const uint8_t *lut_lds, const uint32_t lane,
+                                                  const uint32_t tx, const uint32_t tr)
+{
+    constexpr uint32_t BOXH_ROWS = SMOL_BOXH_ROWS_WIDE;             /* source rows per wave (smol_jobdev.h: boxh_rows) */
+    const uint32_t r0 = J.tmp_row0 + tr * BOXH_ROWS;
+    if (r0 > J.tmp_row1 || tx >= J.w_out)
+        return;
+    const uint32_t r1 = (r0 + BOXH_ROWS - 1 < J.tmp_row1) ? r0 + BOXH_ROWS - 1 : J.tmp_row1;
+    const LutLds lut (lut_lds, LUT_AT_LDS_0);
+    /* the conversion's flavour, fixed once per wave (as boxh_body) */
+    int uk = wide_unpack_kind (J);
+    if (uk == WU_ANY && !J.p16 && !J.linear && !J.unassoc_in && J.bpp_in == 4)
+        uk = WU_FLAT_P;
+    switch (uk)
+    {
+        case WU_LIN_P:  boxh_direct_rows (J, WideUnpack<WU_LIN_P> (J, lut), lane, tx, r0, r1); break;
+        case WU_LIN_U:  boxh_direct_rows (J, WideUnpack<WU_LIN_U> (J, lut), lane, tx, r0, r1); break;
+        case WU_LIN_O:  boxh_direct_rows (J, WideUnpack<WU_LIN_O> (J, lut), lane, tx, r0, r1); break;
+        case WU_FLAT_P: boxh_direct_rows (J, WideUnpack<WU_FLAT_P> (J, lut), lane, tx, r0, r1); break;
+        default:        boxh_direct_rows (J, WideUnpack<WU_ANY> (J, lut), lane, tx, r0, r1); break;
+    }
+}
+
 /* LPC = lanes per output pixel: 1, or 8 for tall boxes (the lanes take every 8th row of the
  * span and meet through wave shuffles) */
 template <bool WIDE, int LPC>
@@ -519,6 +634,8 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
     {
         if (J.tile_lpc == 16)
             boxh_body<WIDE, LPC64 ? 16 : 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
+        else if (WIDE && J.span_chunks == 0)
+            boxh_direct_body (J, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
         else
             boxh_body<WIDE, LPC64 ? 64 : 8> (J, lds, lut_lds, threadIdx.x, blockIdx.x % e_tiles_x, blockIdx.x / e_tiles_x);
     }
@@ -543,6 +660,8 @@ __device__ __forceinline__ void boxh_entry (const JobDev &J, uint8_t *lds)
         uint8_t *buf = lds + lut_bytes + wave * J.span_chunks * 16u;
         if (J.tile_lpc == 16)
             boxh_body<WIDE, LPC64 ? 16 : 8> (J, buf, lds, threadIdx.x & 63u, tx, tr);
+        else if (WIDE && J.span_chunks == 0)
+            boxh_direct_body (J, lds, threadIdx.x & 63u, tx, tr);        /* (a span too long for the LDS: straight from memory) */
         else
             boxh_body<WIDE, LPC64 ? 64 : 8> (J, buf, lds, threadIdx.x & 63u, tx, tr);
     }

@@ -546,3 +546,34 @@ def test_emulated_tile_kernel_one_column_into_24_bit_rows_behind_one_halving():
         seen += k == 3
         assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, sin, sout, first, n, k)
     assert seen >= 100
+
+
+WIDE_SPAN_CASES = [
+    # (t_in, w_in, h_in, t_out, w_out, h_out, srgb): a horizontal box of more than ~9 600 pixels per column, every vertical filter
+    (2, 65535, 9, 0, 1, 23, 0),         # bilinear V, compressed storage
+    (8, 20001, 6, 5, 1, 10, 0),         # 24-bit rows
+    (6, 20001, 10, 6, 1, 6, 1),         # premul16 + gamma
+    (0, 9855, 1, 7, 1, 39, 1),          # one source row
+    (6, 11376, 16, 1, 1, 16, 0),        # vertical COPY
+    (2, 20001, 11, 6, 1, 1, 1),         # box on both axes
+    (9, 65535, 11, 1, 1, 1, 0),         # 24-bit, box on both axes, the longest row there is
+    (8, 65535, 5, 9, 2, 3, 1),          # two columns of 32 767 pixels
+    (4, 30000, 7, 4, 3, 7, 0),          # just at the limit: three columns of 10 000
+]
+
+
+def test_emulated_boxes_wider_than_the_lds_read_straight_from_memory():
+    """Round 6: a column's span beyond ~9 600 pixels does not fit four waves' row buffers; k_boxh then reads its pixels straight from
+    memory (boxh_direct_body) instead of leaving the job to k_general<true>. Every vertical filter behind it, packed rows and
+    rows with a byte of padding (24-bit pixels then start on every byte phase), whole images and a strip."""
+    KC_BOX2 = 10
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in enumerate(WIDE_SPAN_CASES):
+        for pad in (0, 1):
+            sin = w_in * H.bpp(t_in) + pad
+            src = H.make_input(t_in, w_in, h_in, seed=k, valid=bool(k & 1), stride=sin, pad=0)
+            first = 0 if pad == 0 else h_out // 3
+            n = h_out - first
+            want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, first=first, n=n)
+            got, kc = H.emu_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, first=first, n=n)
+            assert kc == KC_BOX2, (t_in, w_in, h_in, t_out, w_out, h_out, srgb, kc)
+            assert np.array_equal(got, want), (t_in, w_in, h_in, t_out, w_out, h_out, srgb, pad)

@@ -445,6 +445,44 @@ def test_host_strip_in_chunks_keeps_the_splits_of_its_tall_box():
         assert np.array_equal(got, want), (t_in, t_out, srgb)
 
 
+def test_boxes_wider_than_the_lds_read_straight_from_memory():
+    """Round 6: horizontal boxes of more than ~9 600 pixels per column (a 65 535-pixel row boxed into one pixel) left the
+    backstop kernels: k_boxh reads them straight from memory (boxh_direct_body). Host API, device API with misaligned
+    pointers, and all of them as one batch."""
+    from test_emu_kernels import WIDE_SPAN_CASES
+    lib = sm.lib()
+    images, bufs, wants = [], [], []
+    for k, (t_in, w_in, h_in, t_out, w_out, h_out, srgb) in enumerate(WIDE_SPAN_CASES):
+        sin = w_in * H.bpp(t_in) + (k & 1)
+        src = H.make_input(t_in, w_in, h_in, seed=k, valid=bool(k & 1), stride=sin, pad=0)
+        want = H.oracle_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin)
+        name = sm.kernel_name(H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb), first_row=0, n_rows=h_out)
+        assert "k_boxh" in name, (name, t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        assert np.array_equal(H.hip_scale(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin), want), ("host", k)
+        got = H.hip_scale_device(src, t_in, w_in, h_in, t_out, w_out, h_out, srgb, sin, src_misalign=k % 3, dst_misalign=k & 1)
+        assert np.array_equal(got, want), ("device", k)
+        dsrc = sm.DeviceBuffer(src.size + 16)
+        dsrc.upload(src)
+        ddst = sm.DeviceBuffer(want.size + 16)
+        ddst.fill(0)
+        im = sm.SmolHipImage()
+        im.job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, srgb)
+        im.src, im.dst = dsrc.ptr, ddst.ptr
+        im.rowstride_in, im.rowstride_out = sin, w_out * H.bpp(t_out)
+        im.first_row, im.n_rows = 0, h_out
+        images.append(im)
+        bufs.append((dsrc, ddst))
+        wants.append(want)
+    batch = sm.HipBatch(images)
+    batch.launch()
+    sm.check(lib.smol_hip_device_synchronize(0))
+    for k, (want, (dsrc, ddst)) in enumerate(zip(wants, bufs)):
+        assert np.array_equal(ddst.download(want.size), want), ("batch", k)
+        dsrc.free()
+        ddst.free()
+    batch.destroy()
+
+
 def test_box_filter_single_pass_in_launches_of_150_mb_and_more():
     """64bpp class, box on both axes: one image or a few go through the two passes (k_boxh + k_boxv), a launch that reads
     150 MB or more at ratios up to 12 (300 MB up to 24; 24-bit sources up to 19) through the single-pass k_tile
