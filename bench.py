@@ -171,82 +171,122 @@ def _image(job, src_ptr, dst_ptr, s_in, s_out, first, n):
 
 
 # Where the arenas lie in HBM is worth 3.5 % on the headline, 5 % on config 5 and 14 % on its mixed-type form
-# (profiles/r06_headline_modes.txt). Rounds 4-5 saw "two modes per process" (337 / 325 us) and could not steer them. Round 6: arenas
-# that are alive TOGETHER in one process run in different modes -- the mode follows the allocations (sometimes the source arena alone,
-# sometimes the pair of source and destination allocation), not the process, the stream, the virtual addresses (identical addresses
-# with randomisation off: both modes) or offsets inside an allocation (every 64 MB window of a 4 GB destination region behaves
-# alike, shifts of 256 B ... 32 MB change nothing): a property of where the driver put the pages. A caller that keeps its buffers
-# (any pipeline that scales frame after frame) settles it ONCE: allocate a few candidate arenas, time a handful of launches on each
-# pair, keep the best. Arenas of 128 MB - 2 GB cost nothing on a 288 GB device. The candidates stay allocated until the process ends:
-# handing gigabytes back to the driver slows the launches that follow for a while (same file). --no-placement takes the first
-# allocation as rounds 1-5 did; the line reports every candidate's time either way.
-PLACEMENT_DST_TRIES = 4
-PLACEMENT_SRC_TRIES = 3
-PLACEMENT_SPACER = 3 << 30
-PLACEMENT_HOLD = []             # candidates and spacers that were not picked: kept until exit
+# (profiles/r06_headline_modes.txt). Rounds 4-5 saw "two modes per process" (337 / 325 us) and could not steer them. Round 6: the mode
+# follows the PHYSICAL placement of the arenas -- arenas alive together in one process differ; identical virtual addresses (randomisation
+# off) give both modes; and inside ONE 24-48 GB allocation a 2 GB source window is fast up to some offset and slow beyond it (or the other
+# way round), with a gradual transition while the window straddles the boundary. What decides is whether the SOURCE and the DESTINATION
+# lie in the same zone of the device's memory: with the destination at a region's end the source windows of its first part are fast and
+# those near the end slow, and with the source in the first part the destinations near it are slow and the far ones fast -- streaming
+# kernels run 3-14 % faster (k_pow2 3.5 %, k_tile's box 6 %, the mixed-type thumbnails 14 %) when their read stream and their write stream
+# go to different zones. The zones are large (boundaries seen 32 GB into a 64 GB region, 15 GB into a 24 GB one, none in some 48 GB
+# ones: consistent with thirds of the 288 GB, the three ranks of a 12-high HBM3E stack), and the driver hands out whichever it likes (the
+# first process on a fresh box often gets one zone for everything it allocates). A caller that keeps its buffers (any pipeline that
+# scales frame after frame) settles it ONCE: one region of more than a third of the device (104 GB; two fifths of what is free when
+# that is less), a handful of launches with the source arena at every 8 GB of it and the destination at its end, then the same for
+# the destination, the best pair kept; the region stays allocated (handing gigabytes back to the driver slows the launches that follow
+# for a while, same file). --no-placement allocates one arena per side as rounds 1-5 did; the line reports every window's time.
+PLACEMENT = True
+PLACEMENT_REGION_MAX = 104 << 30        # more than a third of the device's 288 GB: wherever the driver puts it, it crosses a zone boundary
+PLACEMENT_SRC_STEP = 8 << 30            # a source window every 8 GB of the region
+PLACEMENT_DST_WINDOWS = 6
+_region = {}                            # device index -> the region tensor (kept until exit)
 
 
 def placement_on():
-    return PLACEMENT_DST_TRIES > 1
+    return PLACEMENT
 
 
-def pick_destination(dev, local_rank, n_img, slot_out, make_images, settle=True):
-    """-> (seconds per launch, dst tensor, batch, candidate times in us). make_images (dst) builds the image descriptors for a
-    destination arena of n_img slots."""
-    tries = PLACEMENT_DST_TRIES
-    cands = []
-    for k in range(max(1, tries)):
+def placement_region(dev):
+    """The probing region of this device, allocated once and kept."""
+    key = dev.index or 0
+    if key not in _region:
+        free, _total = torch.cuda.mem_get_info(dev)
+        nbytes = min(PLACEMENT_REGION_MAX, free * 2 // 5) >> 30 << 30
+        _region[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # (a source window is filled when it is probed)
+    return _region[key]
+
+
+def _probe(b, first, settle=True):
+    # the clock governor needs load to ramp, and building a candidate's descriptor table lets it fall back: 0.15 s of launches before
+    # the first candidate is judged, 0.03 s before each of the others, then a dozen timed launches
+    probe = max(b.time(1, 3) / 3, 1e-3)
+    if settle:
+        b.time(0, max(1, int((150.0 if first else 30.0) / probe)))
+    n = max(4, min(12, int(6.0 / probe)))
+    return b.time(1, n) / n
+
+
+def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
+    """-> (src, dst, batch, report): src / dst are (n_img, slot) uint8 views of device memory, make_images (src, dst) builds the
+    descriptors. With placement: windows of the probing region; without: one allocation per side."""
+    src_bytes, dst_bytes = n_img * slot_in, n_img * slot_out
+
+    def plain():
+        src = torch.randint(0, 256, (n_img, slot_in), dtype=torch.uint8, device=dev)
         dst = torch.zeros((n_img, slot_out), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        b = sm.HipBatch(make_images(dst), device=local_rank)
-        t = 0.0
-        if tries > 1:
-            # the clock governor needs load to ramp, and building a candidate (a descriptor table of 10 000 thumbnails: tens of
-            # milliseconds on the host) lets it fall back: 0.15 s of launches before the first candidate is judged, 0.05 s before
-            # each of the others (config 5's mixed-type kernel read 465 us in a cold probe and 405 in the timed region)
-            probe = max(b.time(1, 3) / 3, 1e-3)
-            b.time(0, max(1, int((150.0 if (k == 0 and settle) else 50.0) / probe)))
-            n = max(4, min(16, int(8.0 / probe)))
-            t = b.time(1, n) / n
-        cands.append((t, dst, b))
-        if k + 1 < tries:
-            try:
-                PLACEMENT_HOLD.append(torch.empty(PLACEMENT_SPACER, dtype=torch.uint8, device=dev))
-            except Exception:                       # noqa: BLE001 -- a device without room for spacers keeps what it has
-                break
-    best = min(range(len(cands)), key=lambda i: cands[i][0])
-    for i, (_, d, b) in enumerate(cands):
-        if i != best:
-            b.destroy()
-            PLACEMENT_HOLD.append(d)
-    return cands[best][0], cands[best][1], cands[best][2], [round(c[0] * 1e3, 1) for c in cands]
+        return src, dst, sm.HipBatch(make_images(src, dst), device=local_rank), {"src_windows_us": None, "dst_windows_us": None}
 
+    if not placement_on():
+        return plain()
+    try:
+        region = placement_region(dev)
+    except Exception:                               # noqa: BLE001 -- no room for a region: the allocator's choice
+        return plain()
+    total = region.numel()
+    if src_bytes + 2 * dst_bytes + (1 << 20) > total:
+        return plain()
 
-def pick_placement(dev, local_rank, make_src, n_img, slot_out, make_images):
-    """Source candidates x destination candidates -> (src, dst, batch, report). make_src () allocates and fills a source arena,
-    make_images (src, dst) the descriptors. A second source arena is only tried while every pair seen so far runs alike (then
-    nothing says whether that is the fast mode or the slow one)."""
-    best = None
-    table = []
-    for k in range(PLACEMENT_SRC_TRIES if placement_on() else 1):
-        src = make_src()
-        torch.cuda.synchronize()
-        t, dst, b, us = pick_destination(dev, local_rank, n_img, slot_out, lambda d: make_images(src, d), settle=k == 0)
-        table.append(us)
+    def view(off, n_bytes, slot):
+        return region[off:off + n_bytes].view(n_img, slot)
+
+    def source(off):
+        v = view(off, src_bytes, slot_in)
+        v.random_(0, 256)                           # synthetic bytes, as torch.randint gave the one-allocation arenas
+        return v
+
+    # the destination used while the source windows are compared: the region's last bytes
+    dst_off0 = (total - dst_bytes) >> 12 << 12
+    dst0 = view(dst_off0, dst_bytes, slot_out)
+    src_offs = list(range(0, dst_off0 - src_bytes + 1, PLACEMENT_SRC_STEP)) or [0]
+    src_us, best = [], None
+    for k, off in enumerate(src_offs):
+        b = sm.HipBatch(make_images(source(off), dst0), device=local_rank)
+        t = _probe(b, k == 0)
+        src_us.append(round(t * 1e3, 1))
+        b.destroy()
         if best is None or t < best[0]:
-            if best is not None:
-                best[3].destroy()
-                PLACEMENT_HOLD.extend([best[1], best[2]])
-            best = (t, src, dst, b)
+            best = (t, off)
+    src_off = best[1]
+    src = view(src_off, src_bytes, slot_in)
+    # destination windows: spread over what the source window leaves free (4 KB aligned), the first one = dst0
+    cands = [dst_off0]
+    free_spans = [(0, src_off), (src_off + src_bytes, dst_off0)]
+    for lo, hi in free_spans:
+        room = hi - lo - dst_bytes
+        if room <= 0:
+            continue
+        n_here = max(1, round((PLACEMENT_DST_WINDOWS - 1) * (hi - lo) / max(1, total - src_bytes)))
+        for j in range(n_here):
+            cands.append((lo + (room * (2 * j + 1)) // (2 * n_here)) >> 12 << 12)
+    dst_us, bestd = [], None
+    for k, off in enumerate(cands):
+        d = view(off, dst_bytes, slot_out)
+        b = sm.HipBatch(make_images(src, d), device=local_rank)
+        t = _probe(b, False)
+        dst_us.append(round(t * 1e3, 1))
+        if bestd is None or t < bestd[0]:
+            if bestd is not None:
+                bestd[2].destroy()
+            bestd = (t, d, b)
         else:
             b.destroy()
-            PLACEMENT_HOLD.extend([src, dst])
-        flat = [x for row in table for x in row]
-        if not placement_on() or max(flat) > 1.02 * min(flat):
-            break                                   # both modes seen: the minimum is the fast one
-    report = {"candidates_us": table if placement_on() else None,
-              "picked_us": round(best[0] * 1e3, 1) if placement_on() else None}
-    return best[1], best[2], best[3], report
+    dst = bestd[1]
+    dst.zero_()
+    torch.cuda.synchronize()
+    report = {"region_GB": total >> 30, "src_windows_us": src_us, "src_offset_GB": round(src_off / 2.0 ** 30, 2),
+              "dst_windows_us": dst_us, "picked_us": round(bestd[0] * 1e3, 1)}
+    return src, dst, bestd[2], report
 
 
 def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out, h_out, n_frames, seed0_frame):
@@ -262,14 +302,11 @@ def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out
     if n_rows == 0:
         return w, job                   # more ranks than rows: this rank only joins the barriers
     slab_rows = r1 - r0 + 1
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x9E3779B9 + rank)
     # every frame starts on a 256-byte boundary, as buffers from any device allocator do
     slot_in = (slab_rows * s_in + 64 + 255) // 256 * 256
     slot_out = (n_rows * s_out + 64 + 255) // 256 * 256
     src, dst, w.batch, w.placement = pick_placement(
-        dev, local_rank, lambda: torch.randint(0, 256, (n_frames, slot_in), dtype=torch.uint8, device=dev, generator=gen),
-        n_frames, slot_out,
+        dev, local_rank, n_frames, slot_in, slot_out,
         lambda sr, d: [_image(job, sr[f].data_ptr() - r0 * s_in, d[f].data_ptr(), s_in, s_out, first_row, n_rows) for f in range(n_frames)])
     frame0 = seed0_frame()
     torch.cuda.synchronize()
@@ -339,8 +376,6 @@ def work_c5mix(rank, world, dev, local_rank, n_total=10000):
     types = rng.integers(0, 10, size=(n_total, 2))
     mine = list(range(rank, n_total, world))
     slot_in, slot_out = 256 * 256 * 4, 64 * 64 * 4
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED + rank)
     jobs = {}
     specs, algo = [], 0
     n_check = min(24, len(mine))
@@ -356,8 +391,7 @@ def work_c5mix(rank, world, dev, local_rank, n_total=10000):
         algo += 256 * 256 * bi + 64 * 64 * bo
     if specs:
         src, dst, w.batch, w.placement = pick_placement(
-            dev, local_rank, lambda: torch.randint(0, 256, (len(mine), slot_in), dtype=torch.uint8, device=dev, generator=gen),
-            len(mine), slot_out,
+            dev, local_rank, len(mine), slot_in, slot_out,
             lambda sr, d: [_image(j, sr[k].data_ptr(), d[k].data_ptr(), si, so, 0, 64) for k, (j, si, so) in enumerate(specs)])
         torch.cuda.synchronize()
         for k, t_in, t_out, f in seeded:
@@ -426,9 +460,8 @@ def other_configs(dev, local_rank):
                 bi, bo = sm.bytes_per_pixel(t_in), sm.bytes_per_pixel(t_out)
                 specs.append((jobs[(t_in, t_out)], stride_in or w_in * bi, w_out * bo))
                 algo += w_in * h_in * bi + w_out * h_out * bo
-            hold0 = len(PLACEMENT_HOLD)
             src, dst, b, placement = pick_placement(
-                dev, local_rank, lambda: torch.randint(0, 256, (n_img, slot_in), dtype=torch.uint8, device=dev), n_img, slot_out,
+                dev, local_rank, n_img, slot_in, slot_out,
                 lambda sr, d: [_image(j, sr[i].data_ptr() + src_off, d[i].data_ptr(), si, so, 0, h_out) for i, (j, si, so) in enumerate(specs)])
             if not placement_on():
                 placement = None
@@ -450,7 +483,6 @@ def other_configs(dev, local_rank):
                 out[name]["traffic_source"] = "static: %s (rocprofv3 --pmc, not this run)" % tr.get("source", "?")
             b.destroy()
             del src, dst
-            del PLACEMENT_HOLD[hold0:]               # (the side table comes after everything that is timed for the line's value)
         except Exception as e:                      # noqa: BLE001 -- a side table must not break the bench line
             out[name] = {"error": repr(e)}
     torch.cuda.empty_cache()
@@ -710,8 +742,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the host-memory legs through the public API (N=1, c2: a few seconds)")
     ap.add_argument("--no-placement", action="store_true",
-                    help="take the first source and destination arenas the allocator hands out (rounds 1-5) instead of probing "
-                         "a few candidates (pick_placement)")
+                    help="one allocation per side, wherever the allocator puts it (rounds 1-5), instead of the best windows of a "
+                         "probing region (pick_placement)")
     ap.add_argument("--backend", default="auto",
                     help="process group for the timing barrier: auto = RCCL ('nccl') when it comes up on every rank, "
                          "else gloo; or force 'nccl' / 'gloo'")
@@ -720,7 +752,7 @@ def main():
     args = ap.parse_args()
 
     if args.no_placement:
-        globals()["PLACEMENT_DST_TRIES"] = 1
+        globals()["PLACEMENT"] = False
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -865,8 +897,8 @@ def main():
             "verified_vs_oracle": {"all_ranks_ok": all_ok, "ranks_that_checked": n_checked},
             # where the destination arena lies against the source arena (pick_destination, rank 0's report): us per launch
             # into each candidate, and which one the timed region used
-            "placement": dict(w.placement or {}, what="arenas: best of the (source, destination) candidates listed (us per launch, a "
-                                                      "handful of launches each; one row per source arena); --no-placement takes the first"),
+            "placement": dict(w.placement or {}, what="arenas: the best source window, then the best destination window, of one probing "
+                                                      "region (us per launch, a dozen launches each); --no-placement = one allocation per side"),
         }
         if args.config == "c5mix":
             line["images_per_s"] = round(10000 * args.steps / elapsed, 1)

@@ -181,7 +181,19 @@ def natural_bytes(n_bytes, bytes_pp, width, rng):
 IMAGES_OVERRIDE = None      # --images N
 
 
-def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False, natural=False, hold=None):
+REGION_BYTES = 104 << 30
+_REGION = []
+
+
+def placement_region():
+    """one 104 GB allocation per process (kept until exit): more than a third of the device, so its head and its tail lie in
+    different zones of the device's memory wherever the driver puts it (profiles/r06_headline_modes.txt)"""
+    if not _REGION:
+        _REGION.append(sm.DeviceBuffer(REGION_BYTES))
+    return _REGION[0]
+
+
+def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=None, srgb_override=None, settle=0.3, opaque=False, no_arena=False, natural=False, placement="off"):
     if name.startswith("G:"):
         # ad-hoc geometry: G:t_in:w_in:h_in:t_out:w_out:h_out:n_images[:srgb]
         f = [int(v) for v in name.split(":")[1:]]
@@ -212,20 +224,31 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
     class _Slot:
         def __init__(self, arena, off, n):
             self.arena, self.off, self.ptr, self.n = arena, off, arena.ptr + off, n
-        def upload(self, host):
-            self.arena.upload(host, offset=self.off)
+        def upload(self, host, offset=0):
+            self.arena.upload(host, offset=self.off + offset)
         def download(self, n_bytes=None):
             return self.arena.download(self.n if n_bytes is None else n_bytes, offset=self.off)
         def free(self):
             pass
     arena_in = arena_out = None
     use_arena = (w_in * h_in * 4 <= (1 << 22)) and not no_arena
+    # placement (round 6, profiles/r06_headline_modes.txt): source and destination memory of a config as windows of ONE large region --
+    # "far": the sources at its head, the destinations at its end (another zone of the device's memory: the streaming kernels' fast
+    # mode), "near": right behind the sources (the same zone: the slow mode); "off": separate allocations wherever the allocator puts them
+    region = placement_region() if placement in ("far", "near") else None
+    reg_in = reg_out = 0
     slot_in = ((h_in * (stride_in or w_in * 4) + 64 + 255) // 256) * 256        # sized for 4-byte pixels
     slot_out = ((h_out * w_out * 4 + 64 + 255) // 256) * 256
     if os.environ.get("SMOL_BENCH_SLOT_PAD"):           # experiment: another pitch between the images of an arena
         slot_in += int(os.environ["SMOL_BENCH_SLOT_PAD"]) // 256 * 256
         slot_out += int(os.environ.get("SMOL_BENCH_SLOT_PAD_OUT", "0")) // 256 * 256
-    if use_arena:
+    if region is not None:
+        in_total = n_images * (slot_in + 256)
+        out_total = n_images * (slot_out + 256)
+        reg_out = ((region.n_bytes - out_total - (1 << 21)) if placement == "far" else (in_total + (1 << 21))) >> 21 << 21
+        if in_total + out_total + (8 << 20) > region.n_bytes:
+            region = None               # (does not fit the region: separate allocations)
+    if use_arena and region is None:
         arena_in, arena_out = sm.DeviceBuffer(n_images * slot_in), sm.DeviceBuffer(n_images * slot_out)
         if os.environ.get("SMOL_BENCH_PRINT_ARENA"):
             print("arena %s in %x out %x" % (name, arena_in.ptr, arena_out.ptr), file=sys.stderr)
@@ -239,7 +262,12 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
         s_out = w_out * bpp(t_out)
         n_in = h_in * s_in
         n_out = h_out * s_out
-        if use_arena:
+        if region is not None:
+            dsrc = _Slot(region, reg_in, n_in + 64 + src_off)
+            ddst = _Slot(region, reg_out, n_out + 64)
+            reg_in += (n_in + 64 + src_off + 255) // 256 * 256 if not use_arena else slot_in
+            reg_out += (n_out + 64 + 255) // 256 * 256 if not use_arena else slot_out
+        elif use_arena:
             dsrc = _Slot(arena_in, off_in, n_in)
             ddst = _Slot(arena_out, off_out, n_out)
             off_in += slot_in
@@ -270,6 +298,32 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
         total_out += w_out * h_out * bpp(t_out)
 
     batch = sm.HipBatch(images)
+    placement_us = None
+    if region is not None and placement == "far":
+        # "far" = the best of six destination positions spread over the region (the zones of the device's memory do not lie where
+        # one would guess: bench.py's pick_placement scans the same way). Only the destinations move; the probes are a dozen launches
+        # after 0.03 s of load each.
+        lo, hi = (in_total + (1 << 21)) >> 21 << 21, (region.n_bytes - out_total - (1 << 21)) >> 21 << 21
+        bases = [hi] + [(lo + (hi - lo) * k // 5) >> 21 << 21 for k in range(5)]
+        rel = [b.off - bufs[0][1].off for (_, b) in bufs]
+        best, placement_us = None, []
+        for base in bases:
+            for im, r in zip(images, rel):
+                im.dst = region.ptr + base + r
+            cand = sm.HipBatch(images)
+            p_ms = max(cand.time(1, 3) / 3, 1e-3)
+            cand.time(0, max(1, int(30.0 / p_ms)))
+            n = max(4, min(12, int(6.0 / p_ms)))
+            t = cand.time(1, n) / n
+            placement_us.append(round(t * 1e3, 1))
+            cand.destroy()
+            if best is None or t < best[0]:
+                best = (t, base)
+        batch.destroy()
+        for k, (im, r) in enumerate(zip(images, rel)):
+            im.dst = region.ptr + best[1] + r
+            bufs[k] = (bufs[k][0], _Slot(region, best[1] + r, bufs[k][1].n))
+        batch = sm.HipBatch(images)
     n_launches, kname = batch.info()
     if graph:
         batch.use_graph(True)
@@ -318,14 +372,10 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
         got = bufs[0][1].download(h_out * s_out)
         line["bit_exact_first_rows_vs_oracle"] = bool(
             checker(host_src_kept, t_in, w_in, h_in, s_in, t_out, w_out, h_out, s_out, srgb, got))
-    if hold is not None:
-        # placement tries (main): this build's memory stays allocated until every try of the config is done -- freed now, the
-        # next build would get the same pages back (profiles/r06_headline_modes.txt) -- and so does its batch
-        hold.extend(x for ab in bufs for x in ab)
-        if arena_in is not None:
-            hold.extend([arena_in, arena_out])
-        line["_batch"] = batch
-        return line
+    if region is not None:
+        line["placement"] = placement
+        if placement_us:
+            line["placement_dst_windows_us"] = placement_us
     batch.destroy()
     for a, b in bufs:
         a.free()
@@ -350,30 +400,15 @@ def main(argv=None, checker=None):
     ap.add_argument("--natural", action="store_true", help="image-like source bytes (smooth ramps + a little noise) instead of white noise")
     ap.add_argument("--images", type=int, default=None, help="override the number of images per launch")
     ap.add_argument("--settle", type=float, default=0.3, help="seconds of warm-up load before timing (clock settling)")
-    ap.add_argument("--placement", type=int, default=1, help="build every config this many times (memory kept) and report the fastest build")
+    ap.add_argument("--placement", default="off", choices=["off", "far", "near"],
+                    help="sources and destinations as windows of ONE 104 GB region: 'far' = sources at its head, destinations at its end (the fast mode "
+                         "of the streaming kernels), 'near' = destinations right behind the sources (the slow mode); default: separate allocations")
     args = ap.parse_args(argv)
     global IMAGES_OVERRIDE
     IMAGES_OVERRIDE = args.images
     for name in args.configs.split(","):
-        if args.placement <= 1:
-            print(json.dumps(run_config(name, args.iters, args.warmup, checker, args.graph,
-                                        args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena, args.natural)), flush=True)
-            continue
-        # where the driver puts a config's arenas is worth up to 14 % on the 2-3 GB configs (profiles/r06_headline_modes.txt; bench.py
-        # pick_placement): the config built `placement' times with every build's memory kept, the fastest build's line printed
-        hold, lines = [], []
-        for _ in range(args.placement):
-            lines.append(run_config(name, args.iters, args.warmup, checker, args.graph, args.tin, args.tout, args.srgb,
-                                    args.settle if not lines else min(args.settle, 0.1), args.opaque, args.no_arena, args.natural, hold=hold))
-        best = min(lines, key=lambda ln: ln["step_us"])
-        best["placement_tries_us"] = [ln["step_us"] for ln in lines]
-        # (under a kernel trace the run's LAST dispatches are what tools/profile_summary.py reads: once more on the picked build)
-        best["step_us_again"] = round(best["_batch"].time(args.warmup, args.iters) / args.iters * 1e3, 2)
-        for ln in lines:
-            ln.pop("_batch").destroy()
-        print(json.dumps(best), flush=True)
-        for x in hold:
-            x.free()
+        print(json.dumps(run_config(name, args.iters, args.warmup, checker, args.graph,
+                                    args.tin, args.tout, args.srgb, args.settle, args.opaque, args.no_arena, args.natural, args.placement)), flush=True)
 
 
 if __name__ == "__main__":

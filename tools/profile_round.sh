@@ -19,16 +19,16 @@ python3 bench.py --config c5mix --steps 20 --warmup 5 > $O/c5mix_line.json 2> $O
 python3 bench.py --config c4 --steps 20 --warmup 5 > $O/c4_line.json 2> $O/c4_err.txt
 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o b --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-e2e > $O/kt_bench.log 2>&1
 for c in $LINE_CFGS; do
-  # (--placement 3: the config built three times with every build's memory kept, the fastest re-timed last -- what bench.py's side
-  # table does with its candidates: profiles/r06_headline_modes.txt)
-  rocprofv3 --kernel-trace --stats -d $O/kt_cfg_$c -o c --output-format csv -- python3 tools/bench_configs.py --iters 20 --warmup 3 --placement 3 --configs $c > $O/kt_cfg_$c.log 2>&1
+  # (--placement far: sources and destinations as windows of one region, 32 GB apart -- what bench.py's placement probe finds:
+  # profiles/r06_headline_modes.txt)
+  rocprofv3 --kernel-trace --stats -d $O/kt_cfg_$c -o c --output-format csv -- python3 tools/bench_configs.py --iters 20 --warmup 3 --placement far --configs $c > $O/kt_cfg_$c.log 2>&1
 done
-SMOL_BENCH_GPU_STATE=1 python3 tests/bench_configs_checked.py --iters 50 --warmup 3 --placement 2 --configs $TABLE > $O/configs.jsonl 2> $O/configs_err.txt
-python3 tests/bench_configs_checked.py --iters 50 --warmup 3 --opaque --configs SRGB,SRGBUP,SRGBHALF,SRGBPNG,SRGBBOX,C5mix > $O/configs_opaque.jsonl 2>> $O/configs_err.txt
+SMOL_BENCH_GPU_STATE=1 python3 tests/bench_configs_checked.py --iters 50 --warmup 3 --placement far --configs $TABLE > $O/configs.jsonl 2> $O/configs_err.txt
+python3 tests/bench_configs_checked.py --iters 50 --warmup 3 --placement far --opaque --configs SRGB,SRGBUP,SRGBHALF,SRGBPNG,SRGBBOX,C5mix > $O/configs_opaque.jsonl 2>> $O/configs_err.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $O/pmc_bench_$c -o p --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --no-e2e > $O/pmc_bench_$c.log 2>&1
   for k in $LINE_CFGS R3; do
-    rocprofv3 --pmc $c -d $O/pmc_cfg_${k}_$c -o p --output-format csv -- python3 tools/bench_configs.py --iters 5 --warmup 1 --settle 0.05 --configs $k > $O/pmc_cfg_${k}_$c.log 2>&1
+    rocprofv3 --pmc $c -d $O/pmc_cfg_${k}_$c -o p --output-format csv -- python3 tools/bench_configs.py --iters 5 --warmup 1 --settle 0.05 --placement far --configs $k > $O/pmc_cfg_${k}_$c.log 2>&1
   done
 done
 i=0

@@ -66,8 +66,7 @@ for d in sorted(glob.glob(os.path.join(O, "kt_cfg_*"))):
     if os.path.isdir(d):
         c = os.path.basename(d)[len("kt_cfg_"):]
         # tools/bench_configs.py --iters 20: settle + warm-up, `iters' launches in one timed region, then 20 single steps
-        # (--placement 3 since round 6: the picked build is timed once more at the end, warm-up 3 + 20 launches: the last 20)
-        by_grid(c, os.path.basename(d), 20, rows)
+        by_grid(c, os.path.basename(d), 40, rows)
 with open(os.path.join(P, tag + "_kernel_by_grid.csv"), "w", newline="") as fh:
     wr = csv.DictWriter(fh, fieldnames=["run", "kernel", "grid", "workgroup", "dispatches", "timed", "mean_us", "min_us", "median_us", "mean_all_us"])
     wr.writeheader()
