@@ -185,6 +185,23 @@ def _image(job, src_ptr, dst_ptr, s_in, s_out, first, n):
 # that is less), a handful of launches with the source arena at every 8 GB of it and the destination at its end, then the same for
 # the destination, the best pair kept; the region stays allocated (handing gigabytes back to the driver slows the launches that follow
 # for a while, same file). --no-placement allocates one arena per side as rounds 1-5 did; the line reports every window's time.
+# ... and the OUTPUT must really leave the Infinity Cache (256 MB, memory side): a batch launched again and again into one arena of
+# 128 MB has its writes absorbed there -- the headline runs 324 us per launch into one destination arena and 334 us when four arenas
+# take turns (tools/exp_dst_rotation.py, profiles/r06_dst_rotation.txt; two arenas = 256 MB: still 324). A pipeline writes every
+# frame's output somewhere new, so the timed launches ROTATE over enough destination arenas that 512 MB of other output lie between
+# two writes of the same line (4 for the headline, up to 32 for small outputs); --no-rotation is rounds 1-5's protocol (one arena),
+# and the line carries that number too (`same_destination`).
+ROTATION_BYTES = 512 << 20
+ROTATION_MAX = 32
+ROTATE = True
+
+
+def rotation_count(dst_bytes):
+    if not ROTATE:
+        return 1
+    return max(1, min(ROTATION_MAX, -(-ROTATION_BYTES // max(1, dst_bytes))))
+
+
 PLACEMENT = True
 PLACEMENT_REGION_MAX = 104 << 30        # more than a third of the device's 288 GB: wherever the driver puts it, it crosses a zone boundary
 PLACEMENT_SRC_STEP = 8 << 30            # a source window every 8 GB of the region
@@ -221,11 +238,15 @@ def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
     descriptors. With placement: windows of the probing region; without: one allocation per side."""
     src_bytes, dst_bytes = n_img * slot_in, n_img * slot_out
 
+    n_rot = rotation_count(dst_bytes)
+
     def plain():
         src = torch.randint(0, 256, (n_img, slot_in), dtype=torch.uint8, device=dev)
-        dst = torch.zeros((n_img, slot_out), dtype=torch.uint8, device=dev)
+        dsts = [torch.zeros((n_img, slot_out), dtype=torch.uint8, device=dev) for _ in range(n_rot)]
         torch.cuda.synchronize()
-        return src, dst, sm.HipBatch(make_images(src, dst), device=local_rank), {"src_windows_us": None, "dst_windows_us": None}
+        rot = sm.HipBatchRotation([sm.HipBatch(make_images(src, d), device=local_rank) for d in dsts])
+        rot.keep = dsts
+        return src, dsts[0], rot, {"src_windows_us": None, "dst_windows_us": None, "dst_rotation": n_rot}
 
     if not placement_on():
         return plain()
@@ -234,7 +255,7 @@ def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
     except Exception:                               # noqa: BLE001 -- no room for a region: the allocator's choice
         return plain()
     total = region.numel()
-    if src_bytes + 2 * dst_bytes + (1 << 20) > total:
+    if src_bytes + (2 + n_rot) * (dst_bytes + (1 << 20)) > total:
         return plain()
 
     def view(off, n_bytes, slot):
@@ -278,15 +299,27 @@ def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
         if bestd is None or t < bestd[0]:
             if bestd is not None:
                 bestd[2].destroy()
-            bestd = (t, d, b)
+            bestd = (t, d, b, off)
         else:
             b.destroy()
     dst = bestd[1]
     dst.zero_()
+    # the other arenas of the rotation: side by side with the picked one (the same zone), downwards unless the source window or the
+    # region's start is in the way
+    dst_off = bestd[3]
+    pitch = (dst_bytes + (1 << 20)) >> 12 << 12
+    lo_end = dst_off - (n_rot - 1) * pitch
+    down = lo_end >= 0 and not (lo_end < src_off + src_bytes and src_off < dst_off)
+    dsts = [dst] + [view(dst_off + (-k if down else k) * pitch, dst_bytes, slot_out) for k in range(1, n_rot)]
+    if not down and (dst_off + (n_rot - 1) * pitch + dst_bytes > total
+                     or (dst_off < src_off + src_bytes and src_off < dst_off + (n_rot - 1) * pitch + dst_bytes)):
+        dsts = [dst]                                # (no room on either side: one arena)
     torch.cuda.synchronize()
+    rot = sm.HipBatchRotation([bestd[2]] + [sm.HipBatch(make_images(src, d), device=local_rank) for d in dsts[1:]])
+    rot.keep = dsts
     report = {"region_GB": total >> 30, "src_windows_us": src_us, "src_offset_GB": round(src_off / 2.0 ** 30, 2),
-              "dst_windows_us": dst_us, "picked_us": round(bestd[0] * 1e3, 1)}
-    return src, dst, bestd[2], report
+              "dst_windows_us": dst_us, "picked_us": round(bestd[0] * 1e3, 1), "dst_rotation": len(dsts)}
+    return src, dst, rot, report
 
 
 def work_rows(rank, world, dev, local_rank, t_in, w_in, h_in, s_in, t_out, w_out, h_out, n_frames, seed0_frame):
@@ -741,6 +774,9 @@ def main():
                     help="skip the side table of the other BASELINE configs (N=1 only, a few seconds)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the host-memory legs through the public API (N=1, c2: a few seconds)")
+    ap.add_argument("--no-rotation", action="store_true",
+                    help="every launch into the same destination arena (rounds 1-5: the Infinity Cache absorbs 128 MB of output per "
+                         "launch) instead of rotating over enough arenas that 512 MB of output lie between two writes of a line")
     ap.add_argument("--no-placement", action="store_true",
                     help="one allocation per side, wherever the allocator puts it (rounds 1-5), instead of the best windows of a "
                          "probing region (pick_placement)")
@@ -753,6 +789,8 @@ def main():
 
     if args.no_placement:
         globals()["PLACEMENT"] = False
+    if args.no_rotation:
+        globals()["ROTATE"] = False
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -838,6 +876,10 @@ def main():
         torch.cuda.synchronize()
         ref_equal = bool(np.array_equal(sm.download(w.keep[1][0].data_ptr(), W_OUT * H_OUT * 4, local_rank), ref_want))
     each = w.batch.time_each(2, 20) if w.batch is not None else []
+    # rounds 1-5's protocol beside it: every launch into the SAME destination arena (the Infinity Cache absorbs the writes)
+    same_ms = None
+    if w.batch is not None and len(getattr(w.batch, "batches", [])) > 1:
+        same_ms = w.batch.batches[0].time(2, args.steps) / args.steps
 
     if dist is not None:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
@@ -898,6 +940,12 @@ def main():
                 "bytes_per_launch": w.bytes_per_launch // max(1, n_launches),
                 "launch_us": round(launch_ms * 1e3, 3),
                 "step_us_each": stats_us(each) if each else None,
+                # the timed launches rotate over this many destination arenas (>= 512 MB of output between two writes of a line: the
+                # output really leaves the 256 MB Infinity Cache); `same_destination' = every launch into one arena, as rounds 1-5 timed
+                "destination_arenas": len(getattr(w.batch, "batches", [None])) if w.batch is not None else 0,
+                "same_destination": ({"launch_us": round(same_ms * 1e3 / max(1, n_launches), 3),
+                                      "frac": round(w.bytes_per_launch / max(1, n_launches) / (same_ms / max(1, n_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                     if same_ms else None),
             },
             "verified_vs_oracle": {"all_ranks_ok": all_ok, "ranks_that_checked": n_checked},
             # where the destination arena lies against the source arena (pick_destination, rank 0's report): us per launch

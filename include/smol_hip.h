@@ -236,6 +236,14 @@ int smol_hip_batch_time (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, f
 /* The same with one event between consecutive launches: ms_each [i] = duration of timed
  * launch i (for min / median). */
 int smol_hip_batch_time_each (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, float *ms_each);
+/* Several batches of ONE device launched in rotation on one stream (launch i = batches [i % n_batches]): the same work
+ * into several destination arenas, so that the bytes written between two writes of the same line exceed the device's
+ * 256 MB Infinity Cache and every output byte has to leave it -- a batch launched again and again into one small arena
+ * has its writes absorbed there (round 6: the headline's 128 MB of output per launch, 324 us; four arenas in rotation,
+ * 334 us). `warmup' untimed then `iters' timed launches; *ms_total = the timed launches together; ms_each (may be NULL)
+ * receives the `iters' single durations. */
+int smol_hip_batch_time_rotating (SmolHipBatch *const *batches, uint32_t n_batches, uint32_t warmup, uint32_t iters,
+                                  float *ms_total, float *ms_each);
 
 /* A batch spread over several GPUs by image: image i belongs to devices [i % n_devices]
  * and its src/dst must be device pointers valid there (thumbnails: no image is split).

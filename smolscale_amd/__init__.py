@@ -114,6 +114,7 @@ EXPORTS = {
     "smol_hip_batch_destroy": (None, [_vp]),
     "smol_hip_batch_time": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
     "smol_hip_batch_time_each": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
+    "smol_hip_batch_time_rotating": (_int, [ctypes.POINTER(_vp), _u32, _u32, _u32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "smol_hip_batch_create_multi": (_int, [ctypes.POINTER(SmolHipImage), _u32, ctypes.POINTER(_int), _u32,
                                            ctypes.POINTER(_vp)]),
     "smol_hip_batch_multi_launch": (_int, [_vp]),
@@ -287,6 +288,45 @@ class HipBatch:
         if self._h:
             lib().smol_hip_batch_destroy(self._h)
             self._h = None
+
+
+class HipBatchRotation:
+    """smol_hip_batch_time_rotating(): several batches of one device -- the same work into several destination arenas -- launched in
+    rotation on one stream. Quacks like HipBatch for timing (time / time_each / info / destroy); batches [0] is the one whose outputs
+    a checker reads."""
+
+    def __init__(self, batches):
+        self.batches = list(batches)
+        self._arr = (_vp * len(self.batches))(*[b._h for b in self.batches])
+
+    def _run(self, warmup, iters, each):
+        ms = ctypes.c_float(0)
+        arr = (ctypes.c_float * iters)() if each else None
+        check(lib().smol_hip_batch_time_rotating(self._arr, len(self.batches), warmup, iters, ctypes.byref(ms), arr),
+              "smol_hip_batch_time_rotating")
+        return ms.value, (list(arr) if each else None)
+
+    def time(self, warmup, iters):
+        return self._run(warmup, iters, False)[0]
+
+    def time_each(self, warmup, iters):
+        return self._run(warmup, iters, True)[1]
+
+    def info(self):
+        return self.batches[0].info()
+
+    def launch(self, stream=None):
+        for b in self.batches:
+            b.launch(stream)
+
+    def use_graph(self, enable=True):
+        for b in self.batches:
+            b.use_graph(enable)
+
+    def destroy(self):
+        for b in self.batches:
+            b.destroy()
+        self.batches = []
 
 
 class HipBatchMulti:

@@ -504,6 +504,50 @@ smol_hip_batch_time_each (SmolHipBatch *batch, uint32_t warmup, uint32_t iters, 
     return rc;
 }
 
+int
+smol_hip_batch_time_rotating (SmolHipBatch *const *batches, uint32_t n_batches, uint32_t warmup, uint32_t iters,
+                              float *ms_total, float *ms_each)
+{
+    if (!batches || !n_batches || !ms_total || !iters)
+        return SMOL_HIP_E_INVALID;
+    for (uint32_t k = 0; k < n_batches; k++)
+        if (!batches [k] || batches [k]->device != batches [0]->device)
+            return SMOL_HIP_E_INVALID;
+
+    SmolHipBatch *lead = batches [0];               /* its stream and events time the whole rotation */
+    int rc = batch_timing_setup (lead);
+    if (rc)
+        return rc;
+    while (ms_each && lead->tev.size () < (size_t) iters + 1)
+    {
+        hipEvent_t ev;
+        HIP_TRY (hipEventCreate (&ev));
+        lead->tev.push_back (ev);
+    }
+    const hipStream_t s = lead->tstream;
+
+    for (uint32_t i = 0; i < warmup && !rc; i++)
+        rc = smol_hip_batch_launch (batches [i % n_batches], s);
+    if (rc)
+        return rc;
+    HIP_TRY (hipStreamSynchronize (s));
+    HIP_TRY (hipEventRecord (lead->te0, s));
+    if (ms_each)
+        HIP_TRY (hipEventRecord (lead->tev [0], s));
+    for (uint32_t i = 0; i < iters && !rc; i++)
+    {
+        rc = smol_hip_batch_launch (batches [(warmup + i) % n_batches], s);
+        if (ms_each)
+            HIP_TRY (hipEventRecord (lead->tev [i + 1], s));
+    }
+    HIP_TRY (hipEventRecord (lead->te1, s));
+    HIP_TRY (hipEventSynchronize (lead->te1));
+    HIP_TRY (hipEventElapsedTime (ms_total, lead->te0, lead->te1));
+    for (uint32_t i = 0; ms_each && i < iters; i++)
+        HIP_TRY (hipEventElapsedTime (&ms_each [i], lead->tev [i], lead->tev [i + 1]));
+    return rc;
+}
+
 /* ---- a batch over several devices (image i -> devices [i % n_devices]) ------------- */
 
 int

@@ -182,6 +182,7 @@ IMAGES_OVERRIDE = None      # --images N
 
 
 REGION_BYTES = 104 << 30
+ROTATE = True
 _REGION = []
 
 
@@ -324,6 +325,38 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
             im.dst = region.ptr + best[1] + r
             bufs[k] = (bufs[k][0], _Slot(region, best[1] + r, bufs[k][1].n))
         batch = sm.HipBatch(images)
+    # The timed launches rotate over enough destination sets that 512 MB of other output lie between two writes of the same line: a
+    # batch launched again and again into one small arena has its writes absorbed by the 256 MB Infinity Cache (round 6,
+    # profiles/r06_dst_rotation.txt: the headline 324 -> 334 us, the sweep's cliff where 19 outputs pass 256 MB). --no-rotate = one set.
+    dst0_ptrs = [im.dst for im in images]
+    one_set = max(1, sum(getattr(b, "n", None) or b.n_bytes for (_, b) in bufs))
+    n_rot = max(1, min(32, -(-(512 << 20) // one_set))) if ROTATE else 1
+    extra, rot_batches = [], [batch]
+    for k in range(1, n_rot):
+        if region is not None:
+            set_pitch = (out_total + (1 << 21)) >> 21 << 21
+            base0 = bufs[0][1].off
+            down = base0 - (n_rot - 1) * set_pitch >= in_total + (1 << 21)
+            shift = (-k if down else k) * set_pitch
+            if not down and base0 + (n_rot - 1) * set_pitch + out_total > region.n_bytes:
+                break                               # (no room: fewer sets)
+            for im, p0 in zip(images, dst0_ptrs):
+                im.dst = p0 + shift
+        elif arena_out is not None:
+            a = sm.DeviceBuffer(n_images * slot_out)
+            extra.append(a)
+            for i, im in enumerate(images):
+                im.dst = a.ptr + i * slot_out
+        else:
+            for im, (_, b) in zip(images, bufs):
+                d = sm.DeviceBuffer(b.n_bytes)
+                extra.append(d)
+                im.dst = d.ptr
+        rot_batches.append(sm.HipBatch(images))
+    for im, p0 in zip(images, dst0_ptrs):
+        im.dst = p0
+    if len(rot_batches) > 1:
+        batch = sm.HipBatchRotation(rot_batches)
     n_launches, kname = batch.info()
     if graph:
         batch.use_graph(True)
@@ -336,7 +369,7 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
     per_step_ms = ms / iters
     algo = total_in + total_out
     # SURVEY 8d asks for min and median too: 20 single-step timings (hipEvents around one step each)
-    singles = sorted(batch.time(0, 1) * 1e3 for _ in range(20))
+    singles = sorted(x * 1e3 for x in batch.time_each(0, 20))
     state = {}
     if os.environ.get("SMOL_BENCH_GPU_STATE"):
         batch.time(0, max(20, iters))           # (the readout samples the clock the GPU runs at under this load)
@@ -376,7 +409,10 @@ def run_config(name, iters, warmup, checker=None, graph=False, tin=None, tout=No
         line["placement"] = placement
         if placement_us:
             line["placement_dst_windows_us"] = placement_us
+    line["destination_sets"] = len(rot_batches)
     batch.destroy()
+    for x in extra:
+        x.free()
     for a, b in bufs:
         a.free()
         b.free()
@@ -403,8 +439,10 @@ def main(argv=None, checker=None):
     ap.add_argument("--placement", default="off", choices=["off", "far", "near"],
                     help="sources and destinations as windows of ONE 104 GB region: 'far' = sources at its head, destinations at its end (the fast mode "
                          "of the streaming kernels), 'near' = destinations right behind the sources (the slow mode); default: separate allocations")
+    ap.add_argument("--no-rotate", action="store_true", help="every launch into the same destinations (rounds 1-5; the Infinity Cache absorbs small outputs)")
     args = ap.parse_args(argv)
-    global IMAGES_OVERRIDE
+    global IMAGES_OVERRIDE, ROTATE
+    ROTATE = not args.no_rotate
     IMAGES_OVERRIDE = args.images
     for name in args.configs.split(","):
         print(json.dumps(run_config(name, args.iters, args.warmup, checker, args.graph,

@@ -14,6 +14,8 @@ for ln in sys.stdin:
         continue
     d = json.loads(ln)
     r = d["roofline"]
-    print("frac %.4f launch %.1f us ok %s  %s" % (r["frac"], r["launch_us"], d["verified_vs_oracle"]["all_ranks_ok"], pl(d.get("placement"))))
+    sd = r.get("same_destination") or {}
+    print("frac %.4f launch %.1f us (x%s arenas; same destination: %s us, %s) ok %s  %s" % (r["frac"], r["launch_us"], r.get("destination_arenas"), sd.get("launch_us"), sd.get("frac"),
+                                                                                         d["verified_vs_oracle"]["all_ranks_ok"], pl(d.get("placement"))))
     for k, v in (d.get("other_baseline_configs") or {}).items():
-        print("   %-8s %7.1f us %.3f  %s" % (k.split()[0], v.get("step_us", 0), v.get("frac_of_peak", 0), pl(v.get("placement")) if "error" not in v else v["error"]))
+        print("   %-8s %7.1f us %.3f  x%s  %s" % (k.split()[0], v.get("step_us", 0), v.get("frac_of_peak", 0), (v.get("placement") or {}).get("dst_rotation"), pl(v.get("placement")) if "error" not in v else v["error"]))

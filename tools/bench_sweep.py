@@ -66,6 +66,7 @@ def main(argv=None, reference_rows=None):
     ap.add_argument("--pixel-type", type=int, default=ARGB_P, help="pixel type of both sides (default ARGB8 premultiplied, as the reference's matrix; 32-bit types only)")
     ap.add_argument("--srgb", type=int, default=0, help="with_srgb (the reference's matrix runs without)")
     ap.add_argument("--no-host-row", action="store_true", help="skip the host-pointer row (device rows only: quick looks)")
+    ap.add_argument("--no-rotate", action="store_true", help="device rows into ONE output set per size (rounds 2-5's protocol)")
     ap.add_argument("--placement", action="store_true",
                     help="device rows: source frames at the head of ONE 104 GB region, outputs at the best of six positions in it (probed once "
                          "per test at half size): source and destination in different zones of the device's memory, the streaming kernels' "
@@ -150,20 +151,44 @@ def main(argv=None, reference_rows=None):
                 im.first_row, im.n_rows = 0, h_out
                 images.append(im)
             batch = sm.HipBatch(images)
+            # (round 6) the one-launch row rotates over enough output sets that 512 MB of other output lie between two writes of a line
+            # -- into ONE set the Infinity Cache absorbs the writes while the set stays below 256 MB, and the sweep showed a cliff where
+            # 19 outputs pass that size (profiles/r06_dst_rotation.txt); --no-rotate: one set, as rounds 2-5
+            n_rot = 1 if args.no_rotate else max(1, min(16, -(-(512 << 20) // (out_slot * n_frames))))
+            extra_dst, rot = [], [batch]
+            for k in range(1, n_rot):
+                if region is not None:
+                    base_k = out_base - k * ((out_slot * n_frames + (2 << 20)) >> 21 << 21)
+                    if base_k < n_frames * pitch + (2 << 20):
+                        break
+                    dk_ptr = region.ptr + base_k
+                else:
+                    dk = sm.DeviceBuffer(out_slot * n_frames)
+                    extra_dst.append(dk)
+                    dk_ptr = dk.ptr
+                for f, im in enumerate(images):
+                    im.dst = dk_ptr + f * out_slot
+                rot.append(sm.HipBatch(images))
+            for f, im in enumerate(images):
+                im.dst = ddst.ptr + f * out_slot
+            timed = sm.HipBatchRotation(rot) if len(rot) > 1 else batch
             # The clock governor needs tens of milliseconds of load to settle and the host-pointer row above leaves the
             # GPU idle most of the time: rounds 2-3 timed 2 launches after 1 warm-up and read instruction-bound sizes
             # 20-30 % slow (ratio 1.1 at 4K: 0.55 of the roofline here, 0.79 in tools/bench_configs.py, which settles
             # for 0.3 s). Now: ~40 ms of warm-up launches, then the fastest of three groups of four (the reference
             # takes the fastest of its repetitions too: test.c:319-340).
-            probe = batch.time(1, 2) / 2
+            probe = timed.time(1, 2) / 2
             n_warm = max(2, min(400, int(40.0 / max(probe, 1e-3))))
-            batch.time(n_warm, 1)
-            t = min(batch.time(0, 4) / 4 for _ in range(3)) * 1e-3 / n_frames
+            timed.time(n_warm, 1)
+            t = min(timed.time(0, 4) / 4 for _ in range(3)) * 1e-3 / n_frames
             bat.append((w_out, h_out, t, (w_in * h_in + w_out * h_out) / t))
-            batch.use_graph(True)                           # one kernel node per image
-            t = min(batch.time(1, 4) / 4 for _ in range(2)) * 1e-3 / n_frames
+            timed.use_graph(True)                           # one kernel node per image
+            t = min(timed.time(1, 4) / 4 for _ in range(2)) * 1e-3 / n_frames
             dev.append((w_out, h_out, t, (w_in * h_in + w_out * h_out) / t))
-            batch.destroy()
+            for b in rot:
+                b.destroy()
+            for x in extra_dst:
+                x.free()
             ddst.free()
         for d in dsrcs:
             d.free()
