@@ -693,3 +693,52 @@ def test_resident_source_bands_in_flight_for_page_locked_sources():
                     break
             plan.destroy()                                  # (a band may still be in flight)
         pin.free()
+
+
+def test_batches_in_rotation_write_every_destination_arena():
+    """smol_hip_batch_time_rotating (): the same images into K destination arenas, launch i = batch i % K on one stream (bench.py's
+    timed launches since round 6: the output has to leave the Infinity Cache). Every arena ends up equal to the oracle, the single
+    durations add up to the total, and batches of different devices or a NULL are refused."""
+    import ctypes
+    lib = sm.lib()
+    t_in, w_in, h_in, t_out, w_out, h_out = 0, 512, 384, 1, 200, 150
+    n_img, K = 5, 3
+    srcs = [H.make_input(t_in, w_in, h_in, seed=30 + i, valid=True, pad=0) for i in range(n_img)]
+    wants = [H.oracle_scale(s, t_in, w_in, h_in, t_out, w_out, h_out) for s in srcs]
+    dsrc = [sm.DeviceBuffer(s.size + 16) for s in srcs]
+    for d, s in zip(dsrc, srcs):
+        d.upload(s)
+    job = H.plan_job(t_in, w_in, h_in, t_out, w_out, h_out, 0)
+    arenas, batches = [], []
+    for k in range(K):
+        dd = [sm.DeviceBuffer(wants[0].size + 16) for _ in range(n_img)]
+        for d in dd:
+            d.fill(0)
+        ims = []
+        for i in range(n_img):
+            im = sm.SmolHipImage()
+            im.job = job
+            im.src, im.dst = dsrc[i].ptr, dd[i].ptr
+            im.rowstride_in, im.rowstride_out = w_in * 4, w_out * 4
+            im.first_row, im.n_rows = 0, h_out
+            ims.append(im)
+        arenas.append(dd)
+        batches.append(sm.HipBatch(ims))
+    rot = sm.HipBatchRotation(batches)
+    total = rot.time(1, 7)                      # 8 launches: every batch runs at least twice
+    each = rot.time_each(0, 6)
+    assert total > 0 and len(each) == 6 and all(x > 0 for x in each)
+    sm.check(lib.smol_hip_device_synchronize(0))
+    for k in range(K):
+        for i in range(n_img):
+            assert np.array_equal(arenas[k][i].download(wants[i].size), wants[i]), (k, i)
+    ms = ctypes.c_float(0)
+    arr = (ctypes.c_void_p * 2)(batches[0]._h, None)
+    assert lib.smol_hip_batch_time_rotating(arr, 2, 0, 1, ctypes.byref(ms), None) < 0
+    assert lib.smol_hip_batch_time_rotating(None, 1, 0, 1, ctypes.byref(ms), None) < 0
+    rot.destroy()
+    for d in dsrc:
+        d.free()
+    for dd in arenas:
+        for d in dd:
+            d.free()
