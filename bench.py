@@ -368,9 +368,12 @@ def work_c2(rank, world, dev, local_rank, frames_per_gpu):
     w.out_pix_per_step = n_frames * W_OUT * H_OUT
     w.in_pix_per_step = n_frames * W_IN * H_IN
     w.scaling = "weak"
+    n_arenas = (w.placement or {}).get("dst_rotation", 1)
     w.workload = ("4096x4096->1024x1024 RGBA8 premultiplied (reference filter: BILINEAR_1H x BILINEAR_1H), "
-                  "batch of %d distinct frames per step resident in HBM, output-row strips sharded over %d rank(s)"
-                  % (n_frames, world))
+                  "batch of %d distinct frames per step resident in HBM, output-row strips sharded over %d rank(s); "
+                  "consecutive steps write into %d destination arenas in rotation (>= 512 MB of output between two writes of a "
+                  "line, so that the output really leaves the 256 MB Infinity Cache; roofline.same_destination = one arena)"
+                  % (n_frames, world, n_arenas))
     w.config["frames_per_step"] = n_frames
     return w
 
@@ -879,7 +882,8 @@ def main():
     # rounds 1-5's protocol beside it: every launch into the SAME destination arena (the Infinity Cache absorbs the writes)
     same_ms = None
     if w.batch is not None and len(getattr(w.batch, "batches", [])) > 1:
-        same_ms = w.batch.batches[0].time(2, args.steps) / args.steps
+        # (0.1 s of launches first: the checker above left the GPU idle, and instruction-heavier kernels read slow until the clock is back)
+        same_ms = w.batch.batches[0].time(max(2, int(100.0 / max(kernel_ms / args.steps, 1e-3))), args.steps) / args.steps
 
     if dist is not None:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
