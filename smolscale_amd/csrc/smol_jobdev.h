@@ -308,9 +308,22 @@ tile_setup (JobDev &d)
          * rows, ratio 2.5 and 3 four, ratio 6 two; below ~1.4 sixteen) */
         const uint64_t rows_per_out = d.step_y << d.halv_v;                 /* 32.32 source rows per output row */
         if (d.step_y < ((uint64_t) 1 << 32))
-            /* magnification on both axes (below ~1.7: smol_jobdev.h up_setup sends it here): 12 rows
+        {
+            /* magnification on both axes (below x2.25: smol_jobdev.h up_setup sends it here): 12 rows
              * (3840x2160 x1.1: 12 rows 72 us, 8 rows 75, 32 rows 78; profiles/r03d_vec_store_align.txt) */
             th = (d.filter_h == F_BILINEAR && d.step_x < ((uint64_t) 1 << 32) && !d.wide) ? 12 : 32;
+            /* (round 6) ... which was measured into ONE output set that the Infinity Cache kept. With the outputs really going to
+             * memory (in rotation) and the arenas placed, flat tiles win for plain 32-bit pixels -- about 4.4 SOURCE rows per tile:
+             * 3840x2160 x1.03 118 -> 99 us with 4 rows, x1.09 119 -> 106 (4), x1.17 134 -> 117 (5), x1.29 157 -> 132 (5),
+             * x1.41 135 -> 112 (5-6), x1.65 149 -> 141 (6-8), x1.81 123 -> 112 (6), x2 and x2.15 within 2 % for 8-12
+             * (profiles/r06_tile_rows_near1.txt) */
+            if (th == 12 && d.bpp_in == 4 && !d.unassoc_in && d.bpp_out == 4 && d.out_dword_ok && !tune_env ("SMOL_TILE_ROWS_R5"))
+            {
+                th = (uint32_t) ((((uint64_t) 44 << 32) / 10 + d.step_y / 2) / d.step_y);
+                if (th < 4) th = 4;
+                if (th > 12) th = 12;
+            }
+        }
         else if (!d.wide && d.tile_cpl == 4 && d.halv_v == 0 && d.halv_h == 0 && d.filter_h == F_BILINEAR
                  && d.bpp_in == 4 && !d.unassoc_in && d.bpp_out == 4 && d.step_y < ((uint64_t) 2 << 32))
         {
@@ -318,6 +331,10 @@ tile_setup (JobDev &d)
             th = (uint32_t) ((((uint64_t) 8 << 32) + d.step_y / 2) / d.step_y);
             if (th < 4) th = 4;
             if (th > 8) th = 8;
+            /* (round 6, outputs in rotation: at most 5 rows -- ratio 1.03 111 -> 107 us, 1.1 (3494 wide) 105 -> 98-100, 1.2 141 ->
+             * 135, ratios 1.3-1.9 within 2 %; profiles/r06_tile_rows_near1.txt) */
+            if (th > 5 && !tune_env ("SMOL_TILE_ROWS_R5"))
+                th = 5;
         }
         else if (d.wide || (d.unassoc_in && d.bpp_in == 4))
             th = d.halv_v ? (16u >> d.halv_v) : 8u;                         /* k_wtile, and sources premultiplied group by group in LDS
