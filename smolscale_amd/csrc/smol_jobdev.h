@@ -595,6 +595,8 @@ inline uint32_t
 pow2_block_rows (const JobDev &d)
 {
     uint32_t by = pow2_shared_lines (d) ? 8 : 16;
+    /* (round 6, outputs in rotation: four rows per workgroup for exact 2:1 of small frames looked 4 % ahead on BASELINE config 1 in a
+     * knob sweep and 0-3 % in an interleaved A/B, behind by 5 % on 4096^2 -> 2048^2: not kept; profiles/r06_retune_rot.txt) */
     if (const char *e = tune_env ("SMOL_POW2_BY"))
         if (atoi (e) >= 1 && atoi (e) <= 16)
             by = (uint32_t) atoi (e);
@@ -764,8 +766,12 @@ up_setup (JobDev &d)
      * x2.6 91 -> 88, odd widths 95 -> 87 and 99 -> 97; from x2.8 eight rows are ahead, 95 against 98: profiles/r05_up_handover.txt) */
     /* (unassociated output is bound by its multiplies, not by its stores, and copies the inverse table into LDS once per tile:
      * twenty rows -- x4 128 -> 115 us, on an odd width 138 -> 127, x8 118 -> 105: profiles/r05_up_rgb8.txt) */
+    /* (round 6, outputs in rotation: 24-bit rows from x2.75 sixteen -- RGB8 -> RGB8 x4 87 -> 74 us, RGBA -> RGB8 x4 85 -> 70, x3 89 -> 85;
+     * from x6 twelve, x8 77 -> 70; below x2.75 twelve as before; profiles/r06_retune_rot.txt) */
+    const bool out24_rows = flavour == 0 && d.out3_ok && (d.tile_variant & 3u) == 2u /* OUT_ANY */ && !tune_env ("SMOL_UP_ROWS_R5");
     const uint64_t flat_rows = (flavour == 0 && (d.tile_variant & 3u) == 1u /* OUT_U4 */) ? 20
-                             : (flavour == 0 && d.step_y > ((uint64_t) 4 << 32) / 11) ? 12 : 8;
+                             : (flavour == 0 && d.step_y > ((uint64_t) 4 << 32) / 11) ? 12
+                             : out24_rows ? (d.step_y > ((uint64_t) 1 << 32) / 6 ? 16 : 12) : 8;
     if (flavour == 0 && tr > flat_rows)
         tr = flat_rows;
     if (flavour != 0 && tr > 16)
