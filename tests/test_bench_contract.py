@@ -38,6 +38,12 @@ def test_single_gpu_line():
     assert line["verified_vs_oracle"] == {"all_ranks_ok": True, "ranks_that_checked": 1}
     assert set(line["roofline"]["step_us_each"]) == {"min", "median", "mean"}
     assert "traffic_source" in line["roofline"]
+    # round 6: the arenas are placed by probing (every probe reported) and the timed launches rotate over destination arenas -- 512 MB of
+    # output between two writes of a line -- with the one-arena figure of rounds 1-5 beside
+    assert r["destination_arenas"] == 4 and r["same_destination"]["launch_us"] > 0 and 0.3 < r["same_destination"]["frac"] < 1.0
+    pl = line["placement"]
+    assert pl["dst_rotation"] == 4 and len(pl["src_windows_us"]) >= 2 and len(pl["dst_windows_us"]) >= 2 and pl["picked_us"] > 0
+    assert "destination arenas" in line["config"]["workload"]
     rows = line["other_baseline_configs"]
     assert len(rows) == 7 and all("error" not in r for r in rows.values()), rows
     assert any(k.startswith("BOX") for k in rows) and any(k.startswith("C5mix") for k in rows)
