@@ -233,6 +233,23 @@ def _probe(b, first, settle=True):
     return b.time(1, n) / n
 
 
+PLACEMENT_ZONE_WINDOW = 2 << 30
+_ZONES = {}
+
+
+def placement_zones(region, local_rank):
+    """The library's own labels of the region's 2 GB windows (smol_hip_memory_zones: which kind of device memory a window lies in,
+    profiles/r06_zone_map.txt), once per process: reported beside the probes below, which time the workload itself."""
+    key = region.data_ptr()
+    if key not in _ZONES:
+        try:
+            z, kinds, contrast = sm.memory_zones(region.data_ptr(), region.numel(), PLACEMENT_ZONE_WINDOW, device=local_rank)
+            _ZONES[key] = {"labels": z, "kinds": kinds, "contrast": round(contrast, 3)}
+        except Exception as e:                      # noqa: BLE001 -- a report, not a decision
+            _ZONES[key] = {"labels": [], "kinds": 0, "contrast": None, "error": str(e)[:80]}
+    return _ZONES[key]
+
+
 def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
     """-> (src, dst, batch, report): src / dst are (n_img, slot) uint8 views of device memory, make_images (src, dst) builds the
     descriptors. With placement: windows of the probing region; without: one allocation per side."""
@@ -319,6 +336,17 @@ def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
     rot.keep = dsts
     report = {"region_GB": total >> 30, "src_windows_us": src_us, "src_offset_GB": round(src_off / 2.0 ** 30, 2),
               "dst_windows_us": dst_us, "picked_us": round(bestd[0] * 1e3, 1), "dst_rotation": len(dsts)}
+    zones = placement_zones(region, local_rank)
+    if zones["labels"]:
+        lab = zones["labels"]
+
+        def kinds_of(off, n_bytes):                 # the kinds a byte range touches
+            return sorted({lab[min(len(lab) - 1, o // PLACEMENT_ZONE_WINDOW)] for o in (off, off + n_bytes - 1)})
+
+        lo_dst = min(d.data_ptr() for d in dsts) - region.data_ptr()
+        hi_dst = max(d.data_ptr() for d in dsts) - region.data_ptr() + dst_bytes
+        report["zones"] = {"window_GB": PLACEMENT_ZONE_WINDOW >> 30, "labels": "".join(str(v) for v in lab), "kinds": zones["kinds"],
+                           "contrast": zones["contrast"], "src": kinds_of(src_off, src_bytes), "dst": kinds_of(lo_dst, hi_dst - lo_dst)}
     return src, dst, rot, report
 
 

@@ -115,6 +115,7 @@ EXPORTS = {
     "smol_hip_batch_time": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
     "smol_hip_batch_time_each": (_int, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_float)]),
     "smol_hip_batch_time_rotating": (_int, [ctypes.POINTER(_vp), _u32, _u32, _u32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    "smol_hip_memory_zones": (_int, [_int, _vp, _u64, _u64, ctypes.POINTER(ctypes.c_uint8), _u32, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_float)]),
     "smol_hip_batch_create_multi": (_int, [ctypes.POINTER(SmolHipImage), _u32, ctypes.POINTER(_int), _u32,
                                            ctypes.POINTER(_vp)]),
     "smol_hip_batch_multi_launch": (_int, [_vp]),
@@ -327,6 +328,19 @@ class HipBatchRotation:
         for b in self.batches:
             b.destroy()
         self.batches = []
+
+
+def memory_zones(base, n_bytes, window, device=0):
+    """smol_hip_memory_zones(): (labels, kinds, contrast) for the windows of `window' bytes (>= 512 MB) of the device region
+    [base, base + n_bytes) -- a source arena and a destination arena in windows with DIFFERENT labels make a fast pair for a
+    streaming kernel; sources that one launch reads together belong in windows with the SAME label (include/smol_hip.h)."""
+    n = int(n_bytes) // int(window)
+    z = (ctypes.c_uint8 * max(n, 1))()
+    k = _u32(0)
+    c = ctypes.c_float(0)
+    check(lib().smol_hip_memory_zones(device, _vp(int(base)), int(n_bytes), int(window), z, n, ctypes.byref(k), ctypes.byref(c)),
+          "smol_hip_memory_zones")
+    return list(z)[:n], k.value, c.value
 
 
 class HipBatchMulti:

@@ -44,6 +44,8 @@ void hspan (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, 
 void wtile (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, uint32_t lds, hipStream_t s);
 void wavepx (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, bool wide, hipStream_t s);
 void general (const JobDev *jobs_dev, const JobDev &rep, dim3 grid, bool wide, hipStream_t s);
+/* smol_hip_memory_zones' probe: `bytes_each' (a multiple of 16 KiB) read from a and from b side by side (smol_k_probe.hip) */
+void zone_read2 (const void *a, const void *b, uint64_t bytes_each, hipStream_t s);
 
 } /* namespace launch */
 } /* namespace smolhip */

@@ -42,6 +42,12 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.smol_hip_plan_job(0, 65536, 4, 0, 4, 4, 0, ctypes.byref(job)) < 0
     assert lib.smol_hip_plan_job(0, 65535, 1, 9, 1, 65535, 1, ctypes.byref(job)) == 0
     assert b"invalid" in lib.smol_hip_strerror(-10001)
+    # smol_hip_memory_zones checks its arguments before it touches a device
+    z = (ctypes.c_uint8 * 4)()
+    assert lib.smol_hip_memory_zones(0, None, 4 << 30, 1 << 30, z, 4, None, None) == -10001
+    assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(1 << 40), 4 << 30, 256 << 20, z, 16, None, None) == -10001     # window below 512 MB
+    assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(1 << 40), 8 << 30, 1 << 30, z, 4, None, None) == -10001         # 8 windows, 4 labels
+    assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(1 << 40), 1 << 29, 1 << 30, z, 4, None, None) == -10001         # region below one window
 
 
 def test_no_product_code_touches_the_oracle():

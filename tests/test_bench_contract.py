@@ -43,6 +43,12 @@ def test_single_gpu_line():
     assert r["destination_arenas"] == 4 and r["same_destination"]["launch_us"] > 0 and 0.3 < r["same_destination"]["frac"] < 1.0
     pl = line["placement"]
     assert pl["dst_rotation"] == 4 and len(pl["src_windows_us"]) >= 2 and len(pl["dst_windows_us"]) >= 2 and pl["picked_us"] > 0
+    # the library's own labels of the region's windows (smol_hip_memory_zones) beside the probes: where the region spans more than
+    # one kind of memory, the probes pick a source and a destination of different kinds
+    zn = pl["zones"]
+    assert len(zn["labels"]) == pl["region_GB"] // zn["window_GB"] and zn["kinds"] >= 1
+    if zn["kinds"] > 1 and len(zn["src"]) == 1 and len(zn["dst"]) == 1:
+        assert zn["src"] != zn["dst"], pl
     assert "destination arenas" in line["config"]["workload"]
     rows = line["other_baseline_configs"]
     assert len(rows) == 7 and all("error" not in r for r in rows.values()), rows

@@ -742,3 +742,62 @@ def test_batches_in_rotation_write_every_destination_arena():
     for dd in arenas:
         for d in dd:
             d.free()
+
+
+def test_memory_zones_say_which_arena_pairs_are_fast():
+    """smol_hip_memory_zones (): the windows of a region labelled by kind of memory (round 6, profiles/r06_zone_map.txt). The labels are
+    the same when asked twice, the arguments are checked, and -- where the region spans more than one kind -- the headline's kernel
+    is faster from a window of one kind into a window of another than into a window of its own kind."""
+    import ctypes
+    lib = sm.lib()
+    gb = 160
+    window = 4 << 30
+    try:
+        region = sm.DeviceBuffer(gb << 30)
+    except Exception:
+        pytest.skip("no %d GB of device memory free" % gb)
+    try:
+        z, kinds, contrast = sm.memory_zones(region.ptr, gb << 30, window)
+        z2, kinds2, _ = sm.memory_zones(region.ptr, gb << 30, window)
+        assert len(z) == gb * (1 << 30) // window and z[0] == 0 and max(z) == kinds - 1
+        assert z == z2 and kinds == kinds2, (z, z2)
+        k = ctypes.c_uint32(0)
+        buf = (ctypes.c_uint8 * 64)()
+        assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(region.ptr), gb << 30, 64 << 20, buf, 64, ctypes.byref(k), None) < 0    # window too small
+        assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(region.ptr), gb << 30, window, buf, 8, ctypes.byref(k), None) < 0        # too few labels
+        assert lib.smol_hip_memory_zones(0, None, gb << 30, window, buf, 64, ctypes.byref(k), None) < 0
+        assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(region.ptr), window, window, buf, 64, None, None) == 0 and buf[0] == 0  # one window
+        if kinds < 2:
+            pytest.skip("the region lies in one kind of memory (contrast %.3f)" % contrast)
+        assert 1.04 < contrast < 1.25, contrast
+
+        # the headline's job, 8 frames (512 MB of source): from window a (kind A) into a window of kind A and into one of another kind
+        w_in = h_in = 4096
+        w_out = h_out = 1024
+        job = H.plan_job(0, w_in, h_in, 0, w_out, h_out, 0)
+        a = 0
+        same = next(i for i in range(1, len(z)) if z[i] == z[a])
+        other = next(i for i in range(1, len(z)) if z[i] != z[a])
+
+        def launch_us(dst_window):
+            ims = []
+            for f in range(8):
+                im = sm.SmolHipImage()
+                im.job = job
+                im.src = region.ptr + a * window + f * w_in * h_in * 4
+                im.dst = region.ptr + dst_window * window + f * w_out * h_out * 4
+                im.rowstride_in, im.rowstride_out = w_in * 4, w_out * 4
+                im.first_row, im.n_rows = 0, h_out
+                ims.append(im)
+            b = sm.HipBatch(ims)
+            b.time(20, 20)
+            t = min(b.time(0, 20) for _ in range(3)) / 20 * 1e3
+            b.destroy()
+            return t
+
+        launch_us(other)                                    # the clocks
+        t_same, t_other = launch_us(same), launch_us(other)
+        t_same2, t_other2 = launch_us(same), launch_us(other)
+        assert max(t_other, t_other2) < 0.99 * min(t_same, t_same2), (t_same, t_other, t_same2, t_other2, z)
+    finally:
+        region.free()
