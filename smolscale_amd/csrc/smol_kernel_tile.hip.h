@@ -1340,6 +1340,25 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
                 smol_wait_vmcnt<2> ();
             smol_wave_sync ();
             consume_row (slot, r, ra_lo);
+#if defined (SMOL_TUNING) && !defined (SMOL_KERNEL_EMU)
+            /* sensitivity probes (profiles/r06_sq_tile_classes.txt): sixteen more scalar (8) or vector (16) instructions per source row */
+            if (dbg & 8)
+            {
+                uint32_t pad = r;
+                asm volatile ("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"
+                              "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"
+                              "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\t"
+                              "s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s" (pad) : : "scc");
+            }
+            if (dbg & 16)
+            {
+                uint32_t pad = lane;
+                asm volatile ("v_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\t"
+                              "v_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\t"
+                              "v_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\t"
+                              "v_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1" : "+v" (pad));
+            }
+#endif
             smol_wave_sync ();
             smol_setprio<3> ();
             request_row (slot);
