@@ -251,13 +251,13 @@ int smol_hip_batch_time_rotating (SmolHipBatch *const *batches, uint32_t n_batch
  * one that reads and writes the same kind (the headline: 325 against 336 us per launch; a plain copy likewise), whichever
  * kernel, stream or process; a kernel that reads two streams at once runs 7-9 % faster when both are of ONE kind. Nothing in an
  * address tells the kinds apart, so this call measures them: [base, base + bytes) is cut into windows of `window' bytes
- * (>= 512 MB; a trailing partial window is left out), pairs of windows are read side by side (256 MB of each, a few launches),
+ * (>= 512 MB, a multiple of 16, base 16-byte aligned; a trailing partial window is left out), pairs of windows are read side by side (256 MB of each, a few launches),
  * and zones [i] receives the kind of window i as a small number -- window 0 is kind 0, the first window of another kind is
  * kind 1, ... Two windows with DIFFERENT labels are a fast pair for source and destination; windows with the SAME label are
  * where to keep several sources that one launch reads. *n_kinds (may be NULL) = labels handed out (3 on a region that spans
  * them all; a window that straddles a border can come out as a kind of its own; at most 8); *contrast (may be NULL) = the
  * slowest pair against two halves of one window, 1.07-1.09 where more than one kind is present. The caller's memory is only
- * read; no device memory is allocated. n_zones >= bytes / window. ~1.2 ms per window and kind.
+ * read; no device memory is allocated. n_zones >= bytes / window. About 1 s for 120 windows (0.15-0.5 s of it settling the clocks), 3 s for 480.
  * Replaces nothing in the reference (its buffers are the caller's, smolscale.h:56-67): it is advice for callers who hand
  * this library device pointers, and what bench.py's placement step reports beside its own probes. */
 int smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t window,

@@ -63,7 +63,7 @@ extern "C" int
 smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t window,
                        uint8_t *zones, uint32_t n_zones, uint32_t *n_kinds, float *contrast)
 {
-    if (!base || !zones || window < 2 * PROBE_BYTES || bytes < window || ((uintptr_t) base & 15u))
+    if (!base || !zones || window < 2 * PROBE_BYTES || (window & 15u) || bytes < window || ((uintptr_t) base & 15u))
         return SMOL_HIP_E_INVALID;
     const uint64_t n = bytes / window;
     if (n > n_zones)
@@ -79,10 +79,25 @@ smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t wi
     int rc;
     float ms;
 
-    /* the clocks first: ~10 ms of launches nobody times */
-    for (uint32_t i = 0; i < 128; i++)
-        smolhip::launch::zone_read2 (b, b + PROBE_BYTES, PROBE_BYTES, P.s);
-    HIP_TRY (hipStreamSynchronize (P.s));
+    /* The clocks first. A device that wakes up runs its first 0.1-0.2 s 2-3 % faster than it settles at, and a sweep that starts in the
+     * one state and ends in the other smears the two clusters into each other (three processes in twenty mislabelled windows of
+     * their first sweep): batches of 128 launches nobody uses, until two in a row agree within 0.5 % after at least 120 ms, at most 0.5 s. */
+    {
+        float prev = 0.f, spent = 0.f;
+        uint32_t calm = 0;
+        while (spent < 500.f && !(spent >= 120.f && calm >= 2))
+        {
+            HIP_TRY (hipEventRecord (P.e0, P.s));
+            for (uint32_t i = 0; i < 128; i++)
+                smolhip::launch::zone_read2 (b, b + PROBE_BYTES, PROBE_BYTES, P.s);
+            HIP_TRY (hipEventRecord (P.e1, P.s));
+            HIP_TRY (hipEventSynchronize (P.e1));
+            HIP_TRY (hipEventElapsedTime (&ms, P.e0, P.e1));
+            calm = (prev > 0.f && ms < prev * 1.005f && ms > prev * 0.995f) ? calm + 1 : 0;
+            prev = ms;
+            spent += ms;
+        }
+    }
 
     std::fill (zones, zones + n, UNLABELLED);
     std::vector<float> t (n);
@@ -149,6 +164,7 @@ smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t wi
                 }
             }
         }
+        uint64_t other = ref;                       /* the member of this kind farthest from its first window */
         for (uint64_t w = ref + 1; w < n; w++)
             if (zones [w] == UNLABELLED)
             {
@@ -160,8 +176,27 @@ smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t wi
                 }
                 worst = std::max (worst, t [w] / same);
                 if (t [w] < line)
+                {
                     zones [w] = (uint8_t) kinds;
+                    other = w;
+                }
             }
+        /* A fast pair is proof of one kind -- nothing makes two streams from two kinds fast --, a slow pair is only a hint: a
+         * disturbed measurement is slow too. Every window that read slowly beside the kind's first window is asked again beside
+         * another of its members before it is left for the next kind. */
+        if (other != ref)
+            for (uint64_t w = ref + 1; w < n; w++)
+                if (zones [w] == UNLABELLED)
+                    for (uint32_t k = 0; k < 2; k++)
+                    {
+                        if ((rc = P.pair (b + other * window, b + w * window, &ms)))
+                            return rc;
+                        if (ms < line)
+                        {
+                            zones [w] = (uint8_t) kinds;
+                            break;
+                        }
+                    }
         same = line / ZONE_LINE;            /* for the second look below */
         same_of [kinds] = same;
         kinds++;

@@ -48,6 +48,8 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(1 << 40), 4 << 30, 256 << 20, z, 16, None, None) == -10001     # window below 512 MB
     assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(1 << 40), 8 << 30, 1 << 30, z, 4, None, None) == -10001         # 8 windows, 4 labels
     assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(1 << 40), 1 << 29, 1 << 30, z, 4, None, None) == -10001         # region below one window
+    assert lib.smol_hip_memory_zones(0, ctypes.c_void_p((1 << 40) + 4), 4 << 30, 1 << 30, z, 4, None, None) == -10001   # base not 16-byte aligned
+    assert lib.smol_hip_memory_zones(0, ctypes.c_void_p(1 << 40), 4 << 30, (1 << 30) + 8, z, 4, None, None) == -10001   # window not a multiple of 16
 
 
 def test_no_product_code_touches_the_oracle():
