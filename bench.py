@@ -233,13 +233,13 @@ def _probe(b, first, settle=True):
     return b.time(1, n) / n
 
 
-PLACEMENT_ZONE_WINDOW = 2 << 30
+PLACEMENT_ZONE_WINDOW = 512 << 20
 _ZONES = {}
 
 
 def placement_zones(region, local_rank):
-    """The library's own labels of the region's 2 GB windows (smol_hip_memory_zones: which kind of device memory a window lies in,
-    profiles/r06_zone_map.txt), once per process: reported beside the probes below, which time the workload itself."""
+    """The library's own labels of the region's 512 MB windows (smol_hip_memory_zones: which kind of device memory the first 256 MB of a
+    window lie in, profiles/r06_zone_map.txt), once per process: reported beside the probes below, which time the workload itself."""
     key = region.data_ptr()
     if key not in _ZONES:
         try:
@@ -248,6 +248,25 @@ def placement_zones(region, local_rank):
         except Exception as e:                      # noqa: BLE001 -- a report, not a decision
             _ZONES[key] = {"labels": [], "kinds": 0, "contrast": None, "error": str(e)[:80]}
     return _ZONES[key]
+
+
+def finish_placement_report(report):
+    """The library's labels (smol_hip_memory_zones) of the windows the probes picked, into report["zones"]; after the timed regions."""
+    spans = report.pop("_spans", None) if report else None
+    if not spans:
+        return report
+    region, local_rank, src_off, src_bytes, dst_off, dst_bytes = spans
+    zones = placement_zones(region, local_rank)
+    if zones["labels"]:
+        lab = zones["labels"]
+
+        def kinds_of(off, n_bytes):                 # the kinds of the windows a byte range touches
+            w0, w1 = off // PLACEMENT_ZONE_WINDOW, (off + n_bytes - 1) // PLACEMENT_ZONE_WINDOW
+            return sorted({lab[min(len(lab) - 1, w)] for w in range(w0, w1 + 1)})
+
+        report["zones"] = {"window_MB": PLACEMENT_ZONE_WINDOW >> 20, "labels": "".join(str(v) for v in lab), "kinds": zones["kinds"],
+                           "contrast": zones["contrast"], "src": kinds_of(src_off, src_bytes), "dst": kinds_of(dst_off, dst_bytes)}
+    return report
 
 
 def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
@@ -336,17 +355,11 @@ def pick_placement(dev, local_rank, n_img, slot_in, slot_out, make_images):
     rot.keep = dsts
     report = {"region_GB": total >> 30, "src_windows_us": src_us, "src_offset_GB": round(src_off / 2.0 ** 30, 2),
               "dst_windows_us": dst_us, "picked_us": round(bestd[0] * 1e3, 1), "dst_rotation": len(dsts)}
-    zones = placement_zones(region, local_rank)
-    if zones["labels"]:
-        lab = zones["labels"]
-
-        def kinds_of(off, n_bytes):                 # the kinds a byte range touches
-            return sorted({lab[min(len(lab) - 1, o // PLACEMENT_ZONE_WINDOW)] for o in (off, off + n_bytes - 1)})
-
-        lo_dst = min(d.data_ptr() for d in dsts) - region.data_ptr()
-        hi_dst = max(d.data_ptr() for d in dsts) - region.data_ptr() + dst_bytes
-        report["zones"] = {"window_GB": PLACEMENT_ZONE_WINDOW >> 30, "labels": "".join(str(v) for v in lab), "kinds": zones["kinds"],
-                           "contrast": zones["contrast"], "src": kinds_of(src_off, src_bytes), "dst": kinds_of(lo_dst, hi_dst - lo_dst)}
+    # (the library's labels of these windows are added after everything is timed -- finish_placement_report: the labelling reads the
+    # region for 1-2 s at full rate, and the launches that followed it ran 1-3 % slower)
+    lo_dst = min(d.data_ptr() for d in dsts) - region.data_ptr()
+    hi_dst = max(d.data_ptr() for d in dsts) - region.data_ptr() + dst_bytes
+    report["_spans"] = (region, local_rank, src_off, src_bytes, lo_dst, hi_dst - lo_dst)
     return src, dst, rot, report
 
 
@@ -539,7 +552,8 @@ def other_configs(dev, local_rank):
                          "GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                          "frac_of_peak_best": round(algo / (st["min"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                          "Mpix_out_per_s": round(n_img * w_out * h_out / (st["mean"] * 1e-6) / 1e6, 1),
-                         "algorithmic_bytes_per_step": algo, "placement": placement}
+                         "algorithmic_bytes_per_step": algo,
+                         "placement": {k: v for k, v in (placement or {}).items() if k != "_spans"} or None}
             tr = traffic_all.get(name.split(" ", 1)[0])
             if tr and tr.get("algorithmic_bytes_per_step") == algo:
                 out[name]["traffic"] = tr.get("hbm_bytes_per_launch")
@@ -907,6 +921,7 @@ def main():
         torch.cuda.synchronize()
         ref_equal = bool(np.array_equal(sm.download(w.keep[1][0].data_ptr(), W_OUT * H_OUT * 4, local_rank), ref_want))
     each = w.batch.time_each(2, 20) if w.batch is not None else []
+    n_arenas = len(getattr(w.batch, "batches", [None])) if w.batch is not None else 0
     # rounds 1-5's protocol beside it: every launch into the SAME destination arena (the Infinity Cache absorbs the writes)
     same_ms = None
     if w.batch is not None and len(getattr(w.batch, "batches", [])) > 1:
@@ -972,6 +987,11 @@ def main():
                 "bytes_per_launch": w.bytes_per_launch // max(1, n_launches),
                 "launch_us": round(launch_ms * 1e3, 3),
                 "step_us_each": stats_us(each) if each else None,
+                # the same twenty single launches by destination arena (launch i of them wrote arena (2 + i) % arenas): an arena that
+                # straddles into the source's kind of memory shows here
+                "step_us_by_arena": ([round(1e3 * sum(each[i] for i in range(len(each)) if (2 + i) % n_arenas == k)
+                                            / max(1, sum(1 for i in range(len(each)) if (2 + i) % n_arenas == k)), 1) for k in range(n_arenas)]
+                                     if each and n_arenas > 1 else None),
                 # the timed launches rotate over this many destination arenas (>= 512 MB of output between two writes of a line: the
                 # output really leaves the 256 MB Infinity Cache); `same_destination' = every launch into one arena, as rounds 1-5 timed
                 "destination_arenas": len(getattr(w.batch, "batches", [None])) if w.batch is not None else 0,
@@ -982,7 +1002,7 @@ def main():
             "verified_vs_oracle": {"all_ranks_ok": all_ok, "ranks_that_checked": n_checked},
             # where the destination arena lies against the source arena (pick_destination, rank 0's report): us per launch
             # into each candidate, and which one the timed region used
-            "placement": dict(w.placement or {}, what="arenas: the best source window, then the best destination window, of one probing "
+            "placement": dict(finish_placement_report(w.placement) or {}, what="arenas: the best source window, then the best destination window, of one probing "
                                                       "region (us per launch, a dozen launches each); --no-placement = one allocation per side"),
         }
         if args.config == "c5mix":

@@ -17,13 +17,15 @@
 #include "smol_launch.h"
 
 #include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
 
 constexpr uint64_t PROBE_BYTES = 256ull << 20;         /* per stream: two streams together are twice the Infinity Cache */
 constexpr uint32_t PROBE_WARMUP = 1, PROBE_ITERS = 8, PROBE_PASSES = 3, PROBE_RETRIES = 4;
-constexpr float    ZONE_LINE = 1.04f, ZONE_DOUBT_LO = 1.02f, ZONE_DOUBT_HI = 1.06f, ZONE_GAP_MIN = 1.012f;
+constexpr float    ZONE_LINE = 1.04f, ZONE_DOUBT_LO = 1.02f, ZONE_DOUBT_HI = 1.075f, ZONE_GAP_MIN = 1.010f;
 constexpr uint32_t ZONE_KINDS_MAX = 8;
 constexpr uint8_t  UNLABELLED = 0xff;
 
@@ -99,6 +101,7 @@ smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t wi
         }
     }
 
+    const bool trace = getenv ("SMOL_HIP_ZONES_TRACE") != nullptr;    /* diagnostics: every sweep's times on stderr */
     std::fill (zones, zones + n, UNLABELLED);
     std::vector<float> t (n);
     uint32_t kinds = 0;
@@ -143,9 +146,20 @@ smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t wi
             }
         }
 
+        if (trace)
+        {
+            fprintf (stderr, "smol_hip_memory_zones: kind %u, first window %llu, its halves %.2f us; the others against that:", kinds,
+                     (unsigned long long) ref, same * 1e3f);
+            for (uint64_t w = ref + 1; w < n; w++)
+                if (zones [w] == UNLABELLED)
+                    fprintf (stderr, " %llu:%.3f", (unsigned long long) w, t [w] / same);
+            fprintf (stderr, "\n");
+        }
+
         /* Other kinds read 5-11 % slower beside this window, its own kind within 3 %: the line is drawn at 4 %, or in the middle
          * of the widest gap the sorted times show around there (the two clusters are tight, and the halves of one window are
-         * one sample of theirs); a window on the line is measured again. */
+         * one sample of theirs -- those of a region's FIRST window read 2-3 % faster than its other pairs of one kind, so the
+         * gap is looked for up to 7.5 %); a window on the line is measured again. */
         float line = same * ZONE_LINE;
         {
             std::vector<float> v;

@@ -46,7 +46,7 @@ def test_single_gpu_line():
     # the library's own labels of the region's windows (smol_hip_memory_zones) beside the probes: where the region spans more than
     # one kind of memory, the probes pick a source and a destination of different kinds
     zn = pl["zones"]
-    assert len(zn["labels"]) == pl["region_GB"] // zn["window_GB"] and zn["kinds"] >= 1
+    assert len(zn["labels"]) == pl["region_GB"] * 1024 // zn["window_MB"] and zn["kinds"] >= 1
     if zn["kinds"] > 1 and len(zn["src"]) == 1 and len(zn["dst"]) == 1:
         assert zn["src"] != zn["dst"], pl
     assert "destination arenas" in line["config"]["workload"]

@@ -38,7 +38,7 @@ def trace_rows(run_dir):
     if not f:
         return rows
     for r in csv.DictReader(open(f)):
-        if "smolhip" not in r["Kernel_Name"]:
+        if "smolhip" not in r["Kernel_Name"] or "k_zone_" in r["Kernel_Name"]:      # (k_zone_read2: smol_hip_memory_zones' probe, no part of a step)
             continue
         rows.append((int(r["Start_Timestamp"]), r["Kernel_Name"],
                      "%sx%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"]),
@@ -111,7 +111,7 @@ def hbm_bytes(fetch_dir, write_dir):
     fs, ws = pmc_per_kernel(fetch_dir), pmc_per_kernel(write_dir)
     per = {}
     for k in fs:
-        if "smolhip" not in k:
+        if "smolhip" not in k or "k_zone_" in k:
             continue
         f = fs[k].get("FETCH_SIZE", [])
         w = ws.get(k, {}).get("WRITE_SIZE", [])
@@ -182,7 +182,7 @@ with open(os.path.join(P, tag + "_sq_box.txt"), "w") as fh:
     fh.write("# SQ counters, BOX row (4096^2 -> 448^2 RGBA8 premultiplied, 8 frames per launch), mean per launch over the dispatches "
              "of each pass (tools/profile_round.sh)\n")
     for k, v in sq.items():
-        if "smolhip" not in k:
+        if "smolhip" not in k or "k_zone_" in k:
             continue
         fh.write(k[:110] + "\n")
         for c, x in sorted(v.items()):
