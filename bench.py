@@ -185,6 +185,9 @@ def _image(job, src_ptr, dst_ptr, s_in, s_out, first, n):
 # that is less), a handful of launches with the source arena at every 8 GB of it and the destination at its end, then the same for
 # the destination, the best pair kept; the region stays allocated (handing gigabytes back to the driver slows the launches that follow
 # for a while, same file). --no-placement allocates one arena per side as rounds 1-5 did; the line reports every window's time.
+# (Later in round 6, profiles/r06_zone_map.txt: the zones are three KINDS of memory of 96 GB each, a large allocation is a patchwork of
+# them, and the library can label a region's windows by kind without writing to it -- smol_hip_memory_zones(); the line carries its
+# labels of the arenas picked here, taken after the timed regions: placement.zones.)
 # ... and the OUTPUT must really leave the Infinity Cache (256 MB, memory side): a batch launched again and again into one arena of
 # 128 MB has its writes absorbed there -- the headline runs 324 us per launch into one destination arena and 334 us when four arenas
 # take turns (tools/exp_dst_rotation.py, profiles/r06_dst_rotation.txt; two arenas = 256 MB: still 324). A pipeline writes every
