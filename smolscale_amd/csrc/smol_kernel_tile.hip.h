@@ -1277,11 +1277,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
      * tiles whose rows are shorter than that (clipped at the image's edge) drain instead. */
     if (DMA && STAGE == TILE_STAGE_DMA && J.tile_ring)
     {
-#ifdef SMOL_TUNING
         const uint32_t ring_n = J.tile_ring;                    /* 2, 3, 4, 6, 8 or 12 (tile_setup) */
-#else
-        constexpr uint32_t ring_n = 4u;                         /* what tile_setup picks; the other depths: tuning builds */
-#endif
         const uint32_t ring_rows = J.group_rows;
         const uint32_t total = row_last - row_first + 1u;
         const uintptr_t ra = src_base + (size_t) row_first * J.src_stride + g0;
@@ -1291,34 +1287,24 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
         const uint32_t lane16 = lane * 16u;
         uint8_t *const ring_end = sbuf + ring_rows * row_pitch;
         uint8_t *slot = sbuf;                                   /* the slot that is consumed next; once consumed, requested into */
-        uint32_t to_issue = total;                              /* (prologue and tail only: the steady loop counts rows) */
+        uint32_t to_issue = total;
         /* DMA instructions a row of this tile takes at least (its span with no misalignment in front) */
         const uint32_t kmin = ((span15 & ~15u) + TILE_COLS * 16u - 1u) / (TILE_COLS * 16u);
         const bool counted = (ring_rows - 1u) * kmin >= ring_n;
-        const bool one_dma = ((15u + span15) & ~15u) <= TILE_COLS * 16u;
 
         auto request_row = [&] (uint8_t *rowdst) __attribute__ ((always_inline))
         {
             const uint32_t nbytes = (imis + span15) & ~15u;     /* whole 16-byte chunks from the aligned start */
             if (!dbg_nostage)
             {
-                if (one_dma)
+                uint32_t k0 = 0;
+                do
                 {
-                    /* every row of this tile is one instruction (at most 1 KB with any misalignment in front): no loop around it */
-                    if (lane16 < nbytes)
-                        smol_global_load_lds16 (a0 + lane16, rowdst, lane);
+                    if (k0 + lane16 < nbytes)
+                        smol_global_load_lds16 (a0 + (k0 + lane16), rowdst + k0, lane);
+                    k0 += TILE_COLS * 16u;
                 }
-                else
-                {
-                    uint32_t k0 = 0;
-                    do
-                    {
-                        if (k0 + lane16 < nbytes)
-                            smol_global_load_lds16 (a0 + (k0 + lane16), rowdst + k0, lane);
-                        k0 += TILE_COLS * 16u;
-                    }
-                    while (k0 < nbytes);
-                }
+                while (k0 < nbytes);
             }
             const uint32_t t = imis + (uint32_t) J.src_stride;
             a0 += t & ~15u;
@@ -1336,11 +1322,7 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
         uint32_t ra_lo = (uint32_t) ra;
         uint32_t r = row_first;
         /* steady state: one row out, one row in */
-        /* (one row counter: every pass consumes row r and requests row r + ring_rows, so the loop ends at r_stop = the first row whose
-         * successor in its slot does not exist -- the scalar unit is what ratio 2.5 with one column per lane runs out of first:
-         * profiles/r06_sq_tile_classes.txt) */
-        const uint32_t r_stop = row_first + to_issue;
-        for (; r != r_stop; r++, ra_lo += J.src_stride)
+        for (; to_issue; r++, ra_lo += J.src_stride)
         {
             if (!counted)
                 smol_wait_vmcnt0 ();
@@ -1378,13 +1360,9 @@ __device__ __forceinline__ void tile_body (const JobDev &J, uint8_t *sbuf, const
             }
 #endif
             smol_wave_sync ();
-#ifndef SMOL_TILE_RING_NO_SETPRIO
             smol_setprio<3> ();
-#endif
             request_row (slot);
-#ifndef SMOL_TILE_RING_NO_SETPRIO
             smol_setprio<0> ();
-#endif
             slot += row_pitch;
             if (slot == ring_end)
                 slot = sbuf;
