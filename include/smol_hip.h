@@ -256,8 +256,9 @@ int smol_hip_batch_time_rotating (SmolHipBatch *const *batches, uint32_t n_batch
  * kind 1, ... Two windows with DIFFERENT labels are a fast pair for source and destination; windows with the SAME label are
  * where to keep several sources that one launch reads. *n_kinds (may be NULL) = labels handed out (3 on a region that spans
  * them all; a window that straddles a border can come out as a kind of its own; at most 8); *contrast (may be NULL) = the
- * slowest pair against two halves of one window, 1.07-1.09 where more than one kind is present. The caller's memory is only
- * read; no device memory is allocated. n_zones >= bytes / window. About 1 s for 120 windows (0.15-0.5 s of it settling the clocks), 3 s for 480.
+ * slowest pair against two halves of one window, 1.07-1.12 where more than one kind is present (a disturbed measurement shows in it). The caller's memory is only
+ * read; no device memory is allocated. n_zones >= bytes / window. About 1 s for 120 windows (0.15-0.5 s of it settling the clocks), 3 s for 480. SMOL_HIP_ZONES_TRACE=1 in the
+ * environment prints every sweep's times on stderr.
  * Replaces nothing in the reference (its buffers are the caller's, smolscale.h:56-67): it is advice for callers who hand
  * this library device pointers, and what bench.py's placement step reports beside its own probes. */
 int smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t window,

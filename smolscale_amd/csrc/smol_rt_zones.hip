@@ -10,11 +10,13 @@
  *   - a kernel that reads TWO streams runs 7-9 % faster when both come from the same kind (300 against 327 us for 2 x 1 GB:
  *     consecutive reads from different ranks pay the rank switch on the data bus).
  * The second effect is the probe: it needs no scratch memory and only ever reads the caller's region. Window 0 is kind 0; every
- * window that reads as fast beside window 0 as window 0's own two halves do is kind 0 too; the first window left over is kind 1;
- * and so on until every window has a label. */
+ * window that reads as fast beside window 0 as the two halves of a window do is kind 0 too; the first window left over is kind 1;
+ * and so on until every window has a label. This file is the device side -- the measurement and the clocks --, the rules that
+ * turn durations into kinds are smol_zones_label.h. */
 
 #include "smol_rt.h"
 #include "smol_launch.h"
+#include "smol_zones_label.h"
 
 #include <algorithm>
 #include <stdio.h>
@@ -24,10 +26,7 @@
 namespace {
 
 constexpr uint64_t PROBE_BYTES = 256ull << 20;         /* per stream: two streams together are twice the Infinity Cache */
-constexpr uint32_t PROBE_WARMUP = 1, PROBE_ITERS = 8, PROBE_PASSES = 3, PROBE_RETRIES = 4;
-constexpr float    ZONE_LINE = 1.04f, ZONE_DOUBT_LO = 1.02f, ZONE_DOUBT_HI = 1.075f, ZONE_GAP_MIN = 1.010f;
-constexpr uint32_t ZONE_KINDS_MAX = 8;
-constexpr uint8_t  UNLABELLED = 0xff;
+constexpr uint32_t PROBE_WARMUP = 1, PROBE_ITERS = 8;
 
 struct ZoneProbe
 {
@@ -101,162 +100,16 @@ smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t wi
         }
     }
 
-    const bool trace = getenv ("SMOL_HIP_ZONES_TRACE") != nullptr;    /* diagnostics: every sweep's times on stderr */
-    std::fill (zones, zones + n, UNLABELLED);
-    std::vector<float> t (n);
+    const uint64_t window_bytes = window;
+    auto pair = [&] (uint64_t wa, uint64_t wb, float *out) -> int
+    {
+        const uint8_t *pa = b + wa * window_bytes;
+        return P.pair (pa, wa == wb ? pa + PROBE_BYTES : b + wb * window_bytes, out);
+    };
     uint32_t kinds = 0;
     float worst = 1.f;
-    uint64_t ref_of [ZONE_KINDS_MAX] = { 0 };
-    float same_of [ZONE_KINDS_MAX] = { 0.f };
-
-    for (uint64_t ref = 0; ref < n; ref++)
-    {
-        if (zones [ref] != UNLABELLED)
-            continue;
-        if (kinds == ZONE_KINDS_MAX - 1)
-        {
-            /* windows that straddle a border read like nothing else: they share the last label */
-            for (uint64_t w = ref; w < n; w++)
-                if (zones [w] == UNLABELLED)
-                    zones [w] = (uint8_t) kinds;
-            kinds++;
-            break;
-        }
-        const uint8_t *r = b + ref * window;
-        zones [ref] = (uint8_t) kinds;
-        ref_of [kinds] = ref;
-
-        /* what two streams of ONE kind take: the window's own two halves, once per pass like every other pair */
-        float same = 1e30f;
-        for (uint32_t pass = 0; pass < PROBE_PASSES; pass++)
-        {
-            for (uint32_t i = 0; i < 3; i++)
-            {
-                if ((rc = P.pair (r, r + PROBE_BYTES, &ms)))
-                    return rc;
-                same = std::min (same, ms);
-            }
-            for (uint64_t w = ref + 1; w < n; w++)
-            {
-                if (zones [w] != UNLABELLED)
-                    continue;
-                if ((rc = P.pair (r, b + w * window, &ms)))
-                    return rc;
-                t [w] = pass ? std::min (t [w], ms) : ms;           /* the quietest of the passes */
-            }
-        }
-
-        if (trace)
-        {
-            fprintf (stderr, "smol_hip_memory_zones: kind %u, first window %llu, its halves %.2f us; the others against that:", kinds,
-                     (unsigned long long) ref, same * 1e3f);
-            for (uint64_t w = ref + 1; w < n; w++)
-                if (zones [w] == UNLABELLED)
-                    fprintf (stderr, " %llu:%.3f", (unsigned long long) w, t [w] / same);
-            fprintf (stderr, "\n");
-        }
-
-        /* Other kinds read 5-11 % slower beside this window, its own kind within 3 %: the line is drawn at 4 %, or in the middle
-         * of the widest gap the sorted times show around there (the two clusters are tight, and the halves of one window are
-         * one sample of theirs -- those of a region's FIRST window read 2-3 % faster than its other pairs of one kind, so the
-         * gap is looked for up to 7.5 %); a window on the line is measured again. */
-        float line = same * ZONE_LINE;
-        {
-            std::vector<float> v;
-            for (uint64_t w = ref + 1; w < n; w++)
-                if (zones [w] == UNLABELLED)
-                    v.push_back (t [w]);
-            std::sort (v.begin (), v.end ());
-            float widest = ZONE_GAP_MIN;
-            for (size_t i = 0; i + 1 < v.size (); i++)
-            {
-                const float mid = 0.5f * (v [i] + v [i + 1]);
-                if (v [i + 1] / v [i] > widest && mid > same * ZONE_DOUBT_LO && mid < same * ZONE_DOUBT_HI)
-                {
-                    widest = v [i + 1] / v [i];
-                    line = mid;
-                }
-            }
-        }
-        uint64_t other = ref;                       /* the member of this kind farthest from its first window */
-        for (uint64_t w = ref + 1; w < n; w++)
-            if (zones [w] == UNLABELLED)
-            {
-                for (uint32_t k = 0; k < PROBE_RETRIES && t [w] > line * 0.995f && t [w] < line * 1.005f; k++)
-                {
-                    if ((rc = P.pair (r, b + w * window, &ms)))
-                        return rc;
-                    t [w] = std::min (t [w], ms);
-                }
-                worst = std::max (worst, t [w] / same);
-                if (t [w] < line)
-                {
-                    zones [w] = (uint8_t) kinds;
-                    other = w;
-                }
-            }
-        /* A fast pair is proof of one kind -- nothing makes two streams from two kinds fast --, a slow pair is only a hint: a
-         * disturbed measurement is slow too. Every window that read slowly beside the kind's first window is asked again beside
-         * another of its members before it is left for the next kind. */
-        if (other != ref)
-            for (uint64_t w = ref + 1; w < n; w++)
-                if (zones [w] == UNLABELLED)
-                    for (uint32_t k = 0; k < 2; k++)
-                    {
-                        if ((rc = P.pair (b + other * window, b + w * window, &ms)))
-                            return rc;
-                        if (ms < line)
-                        {
-                            zones [w] = (uint8_t) kinds;
-                            break;
-                        }
-                    }
-        same = line / ZONE_LINE;            /* for the second look below */
-        same_of [kinds] = same;
-        kinds++;
-    }
-
-    /* a kind of a few windows is a window that was disturbed during every one of its measurements, or one that straddles a
-     * border: ask again, at leisure, beside the first window of every populous kind */
-    std::vector<uint64_t> count (kinds, 0);
-    for (uint64_t w = 0; w < n; w++)
-        count [zones [w]]++;
-    const uint64_t few = std::max<uint64_t> (1, n / 8);
-    for (uint64_t w = 0; w < n; w++)
-    {
-        if (count [zones [w]] > few)
-            continue;
-        for (uint32_t k = 0; k < kinds; k++)
-        {
-            if (count [k] <= few)
-                continue;
-            float best = 1e30f;
-            for (uint32_t i = 0; i < 2 * PROBE_RETRIES; i++)
-            {
-                if ((rc = P.pair (b + ref_of [k] * window, b + w * window, &ms)))
-                    return rc;
-                best = std::min (best, ms);
-            }
-            if (best < same_of [k] * ZONE_LINE)
-            {
-                count [zones [w]]--;
-                zones [w] = (uint8_t) k;
-                count [k]++;
-                break;
-            }
-        }
-    }
-    /* labels in use, renumbered in order of first appearance */
-    uint8_t renum [ZONE_KINDS_MAX];
-    std::fill (renum, renum + ZONE_KINDS_MAX, UNLABELLED);
-    uint32_t used = 0;
-    for (uint64_t w = 0; w < n; w++)
-    {
-        if (renum [zones [w]] == UNLABELLED)
-            renum [zones [w]] = (uint8_t) used++;
-        zones [w] = renum [zones [w]];
-    }
-    kinds = used;
+    if ((rc = smolzones::label_windows (n, pair, zones, &kinds, &worst, getenv ("SMOL_HIP_ZONES_TRACE") != nullptr)))
+        return rc;      /* (SMOL_HIP_ZONES_TRACE: diagnostics, every sweep's times on stderr) */
     HIP_TRY (hipGetLastError ());
 
     if (n_kinds)

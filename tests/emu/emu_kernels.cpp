@@ -342,3 +342,42 @@ emu_lerp11_exhaustive (void)
     }
     return bad;
 }
+
+/* ---- smol_hip_memory_zones()'s labelling rules (smol_zones_label.h) against a simulated device ------------------------------------
+ * truth [w] = the kind of window w. Two streams of one kind take base x (0.985 .. 1.025), of two kinds base x (other_min .. other_min + 0.05), the halves
+ * of one window base x (0.995 .. 1.005) -- those of window 0 x first_fast (the device: 0.975) --, and with probability p_disturb a
+ * measurement is slowed by up to another 8 % (a disturbance only ever adds). */
+#include "smol_zones_label.h"
+
+extern "C" int
+emu_zones_label (uint32_t n, const uint8_t *truth, uint32_t seed, float p_disturb, float first_fast, float other_min,
+                 uint8_t *zones, uint32_t *kinds, float *contrast, uint32_t *n_measurements)
+{
+    uint64_t state = 0x9e3779b97f4a7c15ull ^ ((uint64_t) seed << 17);
+    auto uni = [&] () -> float
+    {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        return (float) ((state >> 40) & 0xffffff) / 16777216.0f;
+    };
+    uint32_t count = 0;
+    auto pair = [&] (uint64_t a, uint64_t b, float *ms) -> int
+    {
+        const float base = 0.076f;
+        float t;
+        if (a == b)
+            t = base * (a == 0 ? first_fast : 1.0f) * (0.995f + 0.01f * uni ());
+        else if (truth [a] == truth [b])
+            t = base * (0.985f + 0.04f * uni ());
+        else
+            t = base * (other_min + 0.05f * uni ());
+        if (uni () < p_disturb)
+            t *= 1.0f + 0.08f * uni ();
+        *ms = t;
+        count++;
+        return 0;
+    };
+    const int rc = smolzones::label_windows (n, pair, zones, kinds, contrast, false);
+    if (n_measurements)
+        *n_measurements = count;
+    return rc;
+}
