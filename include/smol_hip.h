@@ -247,18 +247,21 @@ int smol_hip_batch_time_rotating (SmolHipBatch *const *batches, uint32_t n_batch
 
 /* Where to put a streaming job's source and destination arenas (round 6, profiles/r06_zone_map.txt). Device memory on
  * MI355X comes in three kinds -- 96 GB of each, by every sign the three ranks of its 12-high HBM3E stacks -- and a large
- * allocation is a patchwork of them in pieces of 4-64 GB. A kernel that READS one kind and WRITES another runs 3-5 % faster than
- * one that reads and writes the same kind (the headline: 325 against 336 us per launch; a plain copy likewise), whichever
- * kernel, stream or process; a kernel that reads two streams at once runs 7-9 % faster when both are of ONE kind. Nothing in an
- * address tells the kinds apart, so this call measures them: [base, base + bytes) is cut into windows of `window' bytes
- * (>= 512 MB, a multiple of 16, base 16-byte aligned; a trailing partial window is left out), pairs of windows are read side by side (256 MB of each, a few launches),
- * and zones [i] receives the kind of window i (of its first 256 MB: borders fall on multiples of 2-4 GB, not of a window) as a small number -- window 0 is kind 0, the first window of another kind is
- * kind 1, ... Two windows with DIFFERENT labels are a fast pair for source and destination; windows with the SAME label are
- * where to keep several sources that one launch reads. *n_kinds (may be NULL) = labels handed out (3 on a region that spans
- * them all; a window that straddles a border can come out as a kind of its own; at most 8); *contrast (may be NULL) = the
- * slowest pair against two halves of one window, 1.07-1.12 where more than one kind is present (a disturbed measurement shows in it). The caller's memory is only
- * read; no device memory is allocated. n_zones >= bytes / window. About 1 s for 120 windows (0.15-0.5 s of it settling the clocks), 3 s for 480. SMOL_HIP_ZONES_TRACE=1 in the
- * environment prints every sweep's times on stderr.
+ * allocation is a patchwork of them in pieces of 4-64 GB. A kernel that READS one kind and WRITES another runs faster than
+ * one that reads and writes the same kind -- the headline 325 against 336 us per launch into one destination arena that
+ * the Infinity Cache absorbs, 326 against 350 us (7.5 %) once the output really goes to memory; a plain copy likewise --,
+ * whichever kernel, stream or process; a kernel that reads two streams at once runs 7-9 % faster when both are of ONE kind.
+ * Nothing in an address tells the kinds apart, so this call measures them: [base, base + bytes) is cut into windows of
+ * `window' bytes (>= 512 MB, a multiple of 16; base 16-byte aligned; a trailing partial window is left out), pairs of
+ * windows are read side by side (256 MB of each, a few launches), and zones [i] receives the kind of window i -- of its
+ * first 256 MB: borders fall on multiples of 2-4 GB, not of a window -- as a small number: window 0 is kind 0, the first
+ * window of another kind is kind 1, ... Two windows with DIFFERENT labels are a fast pair for source and destination;
+ * windows with the SAME label are where to keep several sources that one launch reads. *n_kinds (may be NULL) = labels
+ * handed out (3 on a region that spans them all; a window that straddles a border can come out as a kind of its own; at
+ * most 8); *contrast (may be NULL) = the slowest pair against two halves of one window, 1.07-1.12 where more than one kind
+ * is present (a disturbed measurement shows in it). The caller's memory is only read; no device memory is allocated.
+ * n_zones >= bytes / window. About 1 s for 120 windows (0.15-0.5 s of it settling the clocks), 3 s for 480.
+ * SMOL_HIP_ZONES_TRACE=1 in the environment prints every sweep's times on stderr.
  * Replaces nothing in the reference (its buffers are the caller's, smolscale.h:56-67): it is advice for callers who hand
  * this library device pointers, and what bench.py's placement step reports beside its own probes. */
 int smol_hip_memory_zones (int device, const void *base, uint64_t bytes, uint64_t window,
